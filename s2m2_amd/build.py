@@ -1,0 +1,72 @@
+"""Build libs2m2_hip.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
+
+    python -m s2m2_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels to the GPU box with the
+gpurun snapshot.  Objects are cached per source file (mtime based) under s2m2_amd/csrc/_obj.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libs2m2_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=on", "-fno-fast-math"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for f in os.listdir(root):
+            if f.endswith(".h"):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def _compile(src: str, force: bool, hdr_mtime: float) -> str:
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    spath = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
+            and os.path.getmtime(obj) > hdr_mtime):
+        return obj
+    cmd = [HIPCC, *FLAGS, "-c", spath, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = sources()
+    hdr = _deps_mtime()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[s2m2_amd.build] {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB) from {len(srcs)} sources")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

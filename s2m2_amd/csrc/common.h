@@ -1,0 +1,104 @@
+// Shared device/host helpers for the S2M2 gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/s2m2_hip.h"
+
+namespace s2m2 {
+
+// ------------------------------------------------------------------------------------------------
+// host: error reporting
+// ------------------------------------------------------------------------------------------------
+int set_error(const char* fmt, ...);            // stores a thread-local message, returns 1
+int check_launch(const char* what);             // hipGetLastError() -> set_error
+
+#define S2M2_REQUIRE(cond, ...)                        \
+    do {                                               \
+        if (!(cond)) return ::s2m2::set_error(__VA_ARGS__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// device: types
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half_t;
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+template <typename T> struct DT;
+template <> struct DT<float>  { static constexpr int code = S2M2_F32; static constexpr int vec = 4; };
+template <> struct DT<half_t> { static constexpr int code = S2M2_F16; static constexpr int vec = 8; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(half_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ half_t from_f32<half_t>(float x) { return (half_t)x; }
+
+// 16-byte vector of T (8 halfs / 4 floats)
+template <typename T> struct Vec16;
+template <> struct alignas(16) Vec16<half_t> { half_t v[8]; };
+template <> struct alignas(16) Vec16<float>  { float v[4]; };
+
+// ------------------------------------------------------------------------------------------------
+// MFMA wrappers.  One "k16 fragment" = 8 consecutive k elements of one row (lanes 0-31: k 0..7 of row lane,
+// lanes 32-63: k 8..15 of row lane-32) for BOTH dtypes: fp16 feeds one v_mfma_f32_32x32x16_f16, fp32 feeds
+// eight v_mfma_f32_32x32x2_f32 (element s of both operands in step s; the sum over k is order independent,
+// so relabelling k = 8*half + s -> step s, half is legal as long as A and B use the same map).
+// Accumulator layout (both): lane l holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31], r = 0..15.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<half_t> { half8_t v; };
+template <> struct Frag<float>  { float v[8]; };
+
+__device__ __forceinline__ void mma32(float16_t& acc, const Frag<half_t>& a, const Frag<half_t>& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(float16_t& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
+}
+
+// fragment <- LDS/global memory holding 8 consecutive T (16 B for half, 32 B for float), 16-B aligned
+__device__ __forceinline__ void load_frag(Frag<half_t>& f, const half_t* p) { f.v = *reinterpret_cast<const half8_t*>(p); }
+__device__ __forceinline__ void load_frag(Frag<float>& f, const float* p) {
+    float4_t a = *reinterpret_cast<const float4_t*>(p);
+    float4_t b = *reinterpret_cast<const float4_t*>(p + 4);
+    f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+    f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// ------------------------------------------------------------------------------------------------
+// wave-level helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------------
+template <int WIDTH> __device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) { return group_sum<64>(x); }
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+
+// XCD-aware, bijective remap of a linear block id so that consecutive logical ids share an XCD (and its L2):
+// hardware places block b on XCD b % 8 (observed, speed only).
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+}  // namespace s2m2

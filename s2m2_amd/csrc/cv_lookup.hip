@@ -1,0 +1,106 @@
+// K3 -- two-level, radius-r cost-volume lookup for the refinement loop (one thread per pixel and tap).
+//
+// Replaces CostVolume.__init__ (avg_pool2d copy of the volume) and CostVolume.__call__ (two F.grid_sample calls)
+// (/root/reference/src/s2m2/core/model/submodules.py:7-60; SURVEY.md A9+A10, Appendix A step 11).
+// The half-resolution level is averaged on the fly from cv (no +50 % copy).  The reference goes pixel ->
+// normalised (Python, `2*x/(W-1)-1`) -> pixel (ATen CPU kernel, `(g+1)*((size-1)/2)`) in fp32 on BOTH axes,
+// so the effective coordinate is off by ~1 ulp and a vanishing weight can land on the neighbouring row;
+// that arithmetic is reproduced here with contraction disabled.
+#include "common.h"
+
+namespace s2m2 {
+
+#pragma clang fp contract(off)
+__device__ __forceinline__ float roundtrip(float pix, float size) {
+    const float g = 2.0f * pix / (size - 1.0f) - 1.0f;     // reference Python (submodules.py:12-13)
+    return (g + 1.0f) * ((size - 1.0f) / 2.0f);            // ATen CPU unnormalize, align_corners=True
+}
+
+template <typename TI, int LEVEL>
+__device__ __forceinline__ float fetch(const TI* __restrict__ row, int x, int ws) {
+    // value of the sampled image at column x of this row; zeros padding outside [0, ws-1]
+    if (x < 0 || x >= ws) return 0.f;
+    if (LEVEL == 0) return to_f32(row[x]);
+    return (to_f32(row[2 * x]) + to_f32(row[2 * x + 1])) * 0.5f;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ cv, const float* __restrict__ disp,
+                                                        TO* __restrict__ corr1, TO* __restrict__ corr2, int B, int h, int w,
+                                                        int radius, long long batch_stride, long long pix_stride,
+                                                        long long tap_stride) {
+    const int T = 2 * radius + 1;
+    const long long total = (long long)B * h * w * 2 * T;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int t = (int)(gid % (2 * T));
+    const long long pix = gid / (2 * T);                  // (b*h + y)*w + i
+    const int i = (int)(pix % w);
+    const long long rowid = pix / w;                      // b*h + y
+    const int b = (int)(rowid / h);
+    const int level = t >= T;
+    const int k = level ? t - T : t;
+    const float d = disp[pix];
+    const float dx = (float)(k - radius);
+    const TI* img = cv + (size_t)rowid * w * w;           // (w rows = left pixel i) x (w cols = right pixel j)
+
+    float x, wsf;
+    int ws;
+    if (level == 0) { x = ((float)i - d) + dx; ws = w; }
+    else            { x = ((float)i / 2.0f - d / 2.0f) + dx; ws = w / 2; }
+    wsf = (float)ws;
+    const float ix = roundtrip(x, wsf);
+    const float iy = roundtrip((float)i, (float)w);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx = ix - x0f, wy = iy - y0f;
+    const float ex = 1.0f - wx, ey = 1.0f - wy;
+    // far out-of-range coordinates (huge |d|): every tap is zero padding
+    float out = 0.f;
+    if (x0f >= -2.0f && x0f <= wsf + 1.0f) {
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
+        if (y0 >= 0 && y0 < w) {
+            const TI* r0 = img + (size_t)y0 * w;
+            const float a = level ? fetch<TI, 1>(r0, x0, ws) : fetch<TI, 0>(r0, x0, ws);
+            const float c = level ? fetch<TI, 1>(r0, x0 + 1, ws) : fetch<TI, 0>(r0, x0 + 1, ws);
+            out = out + a * w00;
+            out = out + c * w01;
+        }
+        if (y0 + 1 >= 0 && y0 + 1 < w && wy != 0.0f) {
+            const TI* r1 = img + (size_t)(y0 + 1) * w;
+            const float a = level ? fetch<TI, 1>(r1, x0, ws) : fetch<TI, 0>(r1, x0, ws);
+            const float c = level ? fetch<TI, 1>(r1, x0 + 1, ws) : fetch<TI, 0>(r1, x0 + 1, ws);
+            out = out + a * w10;
+            out = out + c * w11;
+        }
+    }
+    TO* dst = (level ? corr2 : corr1) + (size_t)b * batch_stride + (size_t)(pix - (long long)b * h * w) * pix_stride + (size_t)k * tap_stride;
+    *dst = from_f32<TO>(out);
+}
+
+template <typename TI, typename TO>
+static int launch_lookup(const void* cv, const float* disp, void* c1, void* c2, int B, int h, int w, int radius, long long bs,
+                         long long ps, long long ts, hipStream_t st) {
+    const long long total = (long long)B * h * w * 2 * (2 * radius + 1);
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL((cv_lookup_kernel<TI, TO>), dim3(blocks), dim3(256), 0, st, static_cast<const TI*>(cv), disp,
+                       static_cast<TO*>(c1), static_cast<TO*>(c2), B, h, w, radius, bs, ps, ts);
+    return check_launch("cv_lookup");
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2, int B, int h, int w, int radius,
+                              int cv_dtype, int out_dtype, long long batch_stride, long long pix_stride, long long tap_stride,
+                              void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(cv && disp && corr1 && corr2, "cv_lookup: null pointer");
+    S2M2_REQUIRE(B > 0 && h > 0 && w > 1 && radius >= 0 && radius <= 16, "cv_lookup: bad arguments");
+    S2M2_REQUIRE(w % 2 == 0, "cv_lookup: w=%d must be even", w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (cv_dtype == S2M2_F16 && out_dtype == S2M2_F16) return launch_lookup<half_t, half_t>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
+    if (cv_dtype == S2M2_F16 && out_dtype == S2M2_F32) return launch_lookup<half_t, float>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
+    if (cv_dtype == S2M2_F32 && out_dtype == S2M2_F32) return launch_lookup<float, float>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
+    if (cv_dtype == S2M2_F32 && out_dtype == S2M2_F16) return launch_lookup<float, half_t>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
+    return set_error("cv_lookup: unsupported dtypes cv=%d out=%d", cv_dtype, out_dtype);
+}

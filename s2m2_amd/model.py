@@ -1,0 +1,107 @@
+"""Drop-in ``S2M2`` module: same constructor, ``forward`` and ``state_dict`` keys as the reference
+(/root/reference/src/s2m2/core/model/s2m2.py:13-197), different inside.
+
+* Parameters are generated from the flat table of :mod:`s2m2_amd.spec` (no per-layer ``nn.Module`` classes);
+  they live in a tree of plain containers only so that ``state_dict()`` / ``load_state_dict()`` produce the
+  reference's dotted names and real ``CH{C}NTR{n}.pth`` checkpoints load unchanged.
+* ``forward`` hands the images to :class:`s2m2_amd.engine.Engine`, which runs the hot path on gfx950 through
+  ``libs2m2_hip.so``.  There is no CPU implementation: inputs must be CUDA tensors and the kernel library must be
+  built, otherwise a ``RuntimeError`` is raised.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .spec import MODEL_CONFIGS, param_table
+
+
+class _Params(nn.Module):
+    """Anonymous container node of the parameter tree (children are named by the dotted-path components)."""
+
+    def extra_repr(self) -> str:
+        return f"{sum(p.numel() for p in self.parameters(recurse=False))} params"
+
+
+class S2M2(nn.Module):
+    def __init__(self, feature_channels: int, dim_expansion: int, num_transformer: int, use_positivity: bool = False,
+                 output_upsample: bool = False, refine_iter: int = 3):
+        super().__init__()
+        self.feature_channels = feature_channels
+        self.dim_expansion = dim_expansion
+        self.num_transformer = num_transformer
+        self.use_positivity = use_positivity
+        self.refine_iter = refine_iter
+        self.output_upsample = output_upsample
+        self._table = param_table(feature_channels, dim_expansion, num_transformer)
+        for name, shape in self._table.items():
+            node: nn.Module = self
+            *path, leaf = name.split(".")
+            for comp in path:
+                if comp not in node._modules:
+                    node.add_module(comp, _Params())
+                node = node._modules[comp]
+            node.register_parameter(leaf, nn.Parameter(torch.empty(shape), requires_grad=False))
+        self.reset_parameters()
+        self._engines: Dict[Tuple, "object"] = {}
+
+    # -- weights -------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def reset_parameters(self, seed: int = 0) -> None:
+        """Well-conditioned deterministic random weights (see s2m2_amd.weights); real use loads a checkpoint."""
+        from .weights import draw_tensor
+        for name, p in self.named_parameters():
+            p.copy_(draw_tensor(name, tuple(p.shape), seed))
+
+    def my_load_state_dict(self, state_dict) -> None:
+        """Shape-mismatch tolerant load, same behaviour as the reference (s2m2.py:69-78)."""
+        own = self.state_dict()
+        for k in state_dict:
+            if k in own and state_dict[k].shape != own[k].shape:
+                print(f"Skip loading parameter: {k}, required shape: {own[k].shape}, loaded shape: {state_dict[k].shape}")
+                state_dict[k] = own[k]
+        self.load_state_dict(state_dict, strict=False)
+
+    def _weights_version(self) -> Tuple:
+        return tuple(p._version for p in self.parameters()) + (next(self.parameters()).device, next(self.parameters()).dtype)
+
+    # -- inference -----------------------------------------------------------------------------------
+    def engine(self, dtype: torch.dtype):
+        from .engine import Engine
+        key = (dtype, self._weights_version())
+        eng = self._engines.get(key)
+        if eng is None:
+            self._engines.clear()                          # weights changed -> drop stale packed copies
+            eng = Engine(self, dtype)
+            self._engines[key] = eng
+        return eng
+
+    @torch.no_grad()
+    def forward(self, img0: torch.Tensor, img1: torch.Tensor, capture: Optional[dict] = None):
+        """img0/img1: (B,3,H,W) in [0,255], H and W multiples of 32 -> (disp, occ, conf), each (B,1,H,W) fp32
+        ((B,1,2H,2W), disparity x2, with output_upsample).  Compute dtype: fp16 under ``torch.autocast(float16)``
+        (how the reference is deployed, model_utils.py:76) or when the parameters are fp16, else fp32."""
+        if not img0.is_cuda:
+            raise RuntimeError("s2m2_amd.S2M2 runs on MI355X only: move the model and the images to a CUDA(HIP) device "
+                               "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
+        p0 = next(self.parameters())
+        if p0.device != img0.device:
+            raise RuntimeError(f"model parameters on {p0.device}, images on {img0.device}")
+        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16:
+            dtype = torch.float16
+        else:
+            dtype = torch.float16 if p0.dtype == torch.float16 else torch.float32
+        if img0.shape != img1.shape or img0.dim() != 4 or img0.shape[1] != 3:
+            raise ValueError(f"expected two (B,3,H,W) images, got {tuple(img0.shape)} and {tuple(img1.shape)}")
+        if img0.shape[-1] % 32 or img0.shape[-2] % 32:
+            raise ValueError("image height and width must be multiples of 32 (pad with image_pad first)")
+        with torch.autocast("cuda", enabled=False):
+            return self.engine(dtype).run(img0, img1, capture)
+
+
+def build_model(model_type: str, use_positivity: bool = True, refine_iter: int = 3, output_upsample: bool = False) -> S2M2:
+    """Model-size table of the reference's ``load_model`` (model_utils.py:12-17) without the checkpoint IO."""
+    c, ntr = MODEL_CONFIGS[model_type]
+    return S2M2(c, 1, ntr, use_positivity=use_positivity, output_upsample=output_upsample, refine_iter=refine_iter)

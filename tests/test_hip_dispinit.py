@@ -1,0 +1,147 @@
+"""GPU parity of K1 (LayerNorm+correlation), K2 (Sinkhorn+argmax+regression), K3 (cost-volume lookup) -- through the
+C ABI -- against (a) golden outputs of the reference, (b) the CPU oracle on seeded inputs, (c) size-independent
+properties at the BASELINE sizes.  Integer argmax: bit exact wherever the reference's own top-2 relative gap
+exceeds 1e-4 and on exact ties (first max wins); fp32 tolerances are written next to each assert."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from s2m2_amd import hip as h
+    h.load()
+    return h
+
+
+def _nhwc(feat_nchw, dtype):
+    return feat_nchw.permute(0, 2, 3, 1).contiguous().to("cuda", dtype)
+
+
+@pytest.mark.parametrize("name", ["op_dispinit_pos", "op_dispinit_neg"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_ln_corr_vs_reference_golden(hip, name, dtype):
+    g = load_golden(name + ".npz")
+    feat = _nhwc(T(g["feat"]), dtype)
+    cv = hip.ln_corr(feat, T(g["gamma"]).cuda(), T(g["beta"]).cuda()).float().cpu()
+    ref = T(g["cv"])
+    err = float((cv - ref).abs().max())
+    # fp32: exact fp32 MFMA chain vs MKL sgemm ordering, |cv| ~ 1e2;  fp16: operands + output rounded to fp16 (ulp 0.06-0.125 at 128-256)
+    assert err < (3e-4 if dtype == torch.float32 else 0.35), err
+
+
+@pytest.mark.parametrize("name", ["op_dispinit_pos", "op_dispinit_neg", "e2e_S_64x96_pos_r2", "e2e_S_96x160_neg_r1_b2"])
+def test_sinkhorn_regress_vs_reference_golden(hip, name):
+    g = load_golden(name + ".npz")
+    pos = bool(g["cfg"][4] if name.startswith("op_") else g["cfg"][5])
+    cv = T(g["cv"]).cuda()
+    disp, conf, occ, am = hip.sinkhorn_regress(cv, pos, 3, want_argmax=True)
+    disp, conf, occ, am = disp.cpu(), conf.cpu(), occ.cpu(), am.cpu()
+    rd, rc, ro = (T(g[k]) for k in (("disp", "conf", "occ") if name.startswith("op_") else ("disp0", "conf0", "occ0")))
+    top1, top2 = g["top2"][..., 0], g["top2"][..., 1]
+    sure = T((top1 - top2) > 1e-4 * top1) | T(top1 == top2)
+    same = am == T(g["argmax"])
+    assert bool(same[sure].all()), f"{int((~same[sure]).sum())} argmax mismatches on well separated pixels"
+    assert float(sure.float().mean()) > 0.97
+    # conf/disp are functions of the argmax: compare where it agrees (the rest are the reference's own near ties)
+    assert float(((conf - rc).abs()[:, 0][same]).max()) < 5e-5
+    assert float((occ - ro).abs().max()) < 5e-5
+    assert float(((disp - rd).abs()[:, 0][same]).max()) < 2e-4
+    assert float(same.float().mean()) > 0.995
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32])
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_lookup_vs_reference_golden(hip, out_dtype, channels_last):
+    g = load_golden("op_lookup.npz")
+    c1, c2 = hip.cv_lookup(T(g["cv"]).cuda(), T(g["disp"]).cuda(), 4, channels_last, out_dtype)
+    if channels_last:
+        c1, c2 = c1.permute(0, 3, 1, 2), c2.permute(0, 3, 1, 2)
+    # identical inputs; the grid_sample coordinate round trip is reproduced -> one ulp of |cv| ~ 1e2
+    assert float((c1.cpu() - T(g["corr1"])).abs().max()) < 4e-5
+    assert float((c2.cpu() - T(g["corr2"])).abs().max()) < 4e-5
+
+
+@pytest.mark.parametrize("C,h,w,B", [(128, 3, 304, 1), (64, 2, 40, 2), (192, 2, 72, 1), (256, 2, 152, 1), (384, 1, 608, 1), (128, 2, 8, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_ln_corr_vs_oracle_shapes(hip, C, h, w, B, dtype):
+    """Ragged strips/chunks (w not a multiple of 32/64/128), all supported channel counts, smallest legal width."""
+    from oracle import s2m2_oracle as O
+    g = torch.Generator().manual_seed(C + w)
+    feat = torch.randn(2 * B, C, h, w, generator=g) * 1.5 + 0.2
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.05 * torch.randn(C, generator=g)
+    if dtype == torch.float16:
+        feat = feat.half().float()
+    ref = O.ln_corr(feat, gamma, beta)
+    cv = hip.ln_corr(_nhwc(feat, dtype), gamma.cuda(), beta.cuda()).float().cpu()
+    scale = float(ref.abs().max())
+    err = float((cv - ref).abs().max())
+    assert err < (1e-5 * scale + 1e-4 if dtype == torch.float32 else 4e-3 * scale + 0.05), (err, scale)
+
+
+def test_ln_corr_swap_is_exact_transpose(hip):
+    """Size-independent property at the BASELINE size (S, 1216x1024: h=256, w=304, C=128): exchanging left and
+    right images transposes every row matrix bit-exactly (the k-order of the MFMA chain is symmetric)."""
+    g = torch.Generator().manual_seed(7)
+    feat = torch.randn(2, 256, 304, 128, generator=g).cuda().half()
+    gamma = (1 + 0.1 * torch.randn(128, generator=g)).cuda()
+    beta = (0.05 * torch.randn(128, generator=g)).cuda()
+    a = hip.ln_corr(feat, gamma, beta)
+    b = hip.ln_corr(feat.flip(0).contiguous(), gamma, beta)
+    assert torch.equal(a, b.transpose(2, 3))
+    # against fp32 math on the same fp16 inputs
+    f = torch.nn.functional.layer_norm(feat.float(), (128,), gamma, beta)
+    ref = torch.matmul(f[:1], f[1:].transpose(-1, -2))
+    assert float((a.float() - ref).abs().max()) < 0.3
+
+
+@pytest.mark.parametrize("pos", [True, False])
+def test_sinkhorn_full_size_vs_oracle_and_marginals(hip, pos):
+    """h=8 rows of the 1216-wide case (w=304) against the oracle, plus the transport-plan property: every
+    regular row of P has mass <= 1 (the rest went to the dustbin) and mass >= 0."""
+    from oracle import s2m2_oracle as O
+    g = torch.Generator().manual_seed(11)
+    w = 304
+    cv = torch.randn(1, 8, w, w, generator=g) * 3 + 110
+    idx = torch.randint(0, w, (8, w), generator=g)
+    cv[0, torch.arange(8)[:, None], torch.arange(w)[None, :], idx] += 12          # one strong match per left pixel
+    P = O.sinkhorn_prob(cv, pos)
+    rd, rc, ro, rind = O.regress(P)
+    disp, conf, occ, am = hip.sinkhorn_regress(cv.cuda(), pos, 3, want_argmax=True)
+    top = P.topk(2, 3).values
+    sure = (top[..., 0] - top[..., 1]) > 1e-4 * top[..., 0]
+    same = am.cpu() == rind.int()
+    assert bool(same[sure].all())
+    assert float((conf.cpu() - rc).abs()[:, 0][same].max()) < 5e-5
+    assert float((occ.cpu() - ro).abs().max()) < 5e-5
+    assert float((disp.cpu() - rd).abs()[:, 0][same].max()) < 2e-4
+    assert float(occ.max()) <= 1 + 1e-5 and float(occ.min()) >= 0
+
+
+def test_sinkhorn_fp16_input_matches_fp32_on_same_values(hip):
+    g = torch.Generator().manual_seed(5)
+    cv = (torch.randn(2, 4, 160, 160, generator=g) * 4 + 100).half()
+    a = hip.sinkhorn_regress(cv.cuda(), True, 3, want_argmax=True)
+    b = hip.sinkhorn_regress(cv.float().cuda(), True, 3, want_argmax=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
+def test_lookup_full_size_vs_oracle(hip):
+    from oracle import s2m2_oracle as O
+    g = torch.Generator().manual_seed(13)
+    B, h, w = 1, 6, 304
+    cv = torch.randn(B, h, w, w, generator=g) * 10 + 100
+    disp = torch.rand(B, 1, h, w, generator=g) * 200 - 10
+    r1, r2 = O.cv_lookup(cv, disp)
+    c1, c2 = hip.cv_lookup(cv.cuda(), disp.cuda(), 4)
+    assert float((c1.cpu() - r1).abs().max()) < 4e-5
+    assert float((c2.cpu() - r2).abs().max()) < 4e-5
+    # fp16 volume / fp16 output
+    c1h, _ = hip.cv_lookup(cv.half().cuda(), disp.cuda(), 4, True, torch.float16)
+    assert float((c1h.float().cpu().permute(0, 3, 1, 2) - r1).abs().max()) < 0.2
