@@ -1,0 +1,53 @@
+"""Multi-GPU path: stereo pairs are independent units (every op carries the batch dim independently), so
+pairs shard across ranks with NO data-path collective; the only exchange is the final gather of the three output maps
+(3 x H x W fp32 per pair) to one rank.  One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" in the CPU tests).  With RCCL, ``gather`` is a grouped send/recv: every peer writes straight to the root
+over its own xGMI link (no ring), which is the right shape for a fully connected 8-GPU node."""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+
+
+def shard_indices(n_pairs: int, rank: int, world: int) -> List[int]:
+    """Pair p runs on rank p % world (round robin keeps ranks within one pair of each other)."""
+    return list(range(rank, n_pairs, world))
+
+
+def gather_outputs(out: Sequence[torch.Tensor], dist, dst: int = 0, group=None) -> Optional[Tuple[torch.Tensor, ...]]:
+    """Gather same-shaped (disp, occ, conf) tuples from all ranks to ``dst``.
+
+    Returns on dst a tuple of tensors with the rank dimension folded into batch, rank-major: (world*B,1,H,W);
+    None elsewhere.  One collective per call (the three maps travel as one stacked buffer)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    buf = torch.stack([o.float() for o in out], 0).contiguous()              # (3,B,1,H,W)
+    bufs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    allb = torch.stack(bufs, 1)                                               # (3,world,B,1,H,W)
+    return tuple(allb[i].reshape(-1, *buf.shape[2:]) for i in range(len(out)))
+
+
+def run_sharded(forward: Callable[[torch.Tensor, torch.Tensor], Sequence[torch.Tensor]], left: torch.Tensor,
+                right: torch.Tensor, dist, dst: int = 0, group=None):
+    """Every rank holds (or can index) the full batch of pairs; it processes its shard and rank ``dst`` receives all
+    outputs in the original pair order.  Requires n_pairs % world == 0 (equal shards -> one fixed-size gather)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = left.shape[0]
+    if n % world:
+        raise ValueError(f"{n} pairs do not shard evenly over {world} ranks")
+    idx = shard_indices(n, rank, world)
+    out = forward(left[idx], right[idx])
+    g = gather_outputs(out, dist, dst, group)
+    if g is None:
+        return None
+    per = n // world
+    order = torch.tensor([p for r in range(world) for p in shard_indices(n, r, world)])
+    inv = torch.empty_like(order)
+    inv[order] = torch.arange(n)
+    assert per * world == n
+    return tuple(t[inv.to(t.device)] for t in g)

@@ -1,0 +1,79 @@
+"""End-to-end GPU parity of ``s2m2_amd.S2M2.forward`` (fp32 mode) against golden outputs of the reference's PyTorch
+CPU forward, plus batch independence and the fp16 deployment mode.
+
+Tolerance (north_star): 1e-3 px on the fp32 disparity.  The reference itself moves by up to 1.3e-2 px on 0.2 % of the
+pixels between 1 and 8 CPU threads when |disp| reaches hundreds of px with random weights (measured,
+tests/test_oracle_golden.py), so the bound is |d| <= 1e-3 + 1e-4*|disp| on >= 99.5 % of pixels, max < 5e-2,
+integer argmax bit exact wherever the reference's top-2 relative gap exceeds 1e-4."""
+import pytest
+import torch
+
+from conftest import T, load_golden
+from s2m2_amd.model import S2M2
+from s2m2_amd.weights import seeded_state_dict, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(C, ntr, pos, ri, up, seed):
+    m = S2M2(C, 1, ntr, use_positivity=bool(pos), output_upsample=bool(up), refine_iter=ri)
+    m.load_state_dict(seeded_state_dict(C, 1, ntr, seed), strict=True)
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_96x160_neg_r1_b2", "e2e_S_64x64_pos_r1_up"])
+def test_fp32_forward_vs_reference_golden(name):
+    g = load_golden(name + ".npz")
+    C, ntr, H, W, B, pos, ri, _, seed, up = [int(x) for x in g["cfg"]]
+    m = _model(C, ntr, pos, ri, up, seed)
+    cap = {}
+    d, o, c = m(T(g["left"]).cuda(), T(g["right"]).cuda(), capture=cap)
+    assert d.dtype == torch.float32 and tuple(d.shape) == g["disp"].shape
+    d, o, c = d.cpu(), o.cpu(), c.cpu()
+    assert float((cap["cv"].cpu() - T(g["cv"])).abs().max()) < 2e-3
+    top1, top2 = g["top2"][..., 0], g["top2"][..., 1]
+    sure = T((top1 - top2) > 1e-4 * top1)
+    same = cap["argmax"].cpu() == T(g["argmax"])
+    assert bool(same[sure].all())
+    ref = T(g["disp"])
+    err = (d - ref).abs()
+    frac = float((err <= 1e-3 + 1e-4 * ref.abs()).float().mean())
+    assert frac >= 0.995, (frac, float(err.max()))
+    assert float(err.max()) < 5e-2
+    assert float((o - T(g["occ"])).abs().max()) < 2e-4
+    assert float((c - T(g["conf"])).abs().max()) < 2e-4
+
+
+def test_batch_independence_and_determinism():
+    m = _model(128, 1, True, 1, False, 0)
+    l, r = synthetic_pair(64, 96, 2, 8, 5)
+    l, r = l.cuda(), r.cuda()
+    d2, o2, c2 = m(l, r)
+    d1a, _, _ = m(l[:1], r[:1])
+    d1b, _, _ = m(l[1:], r[1:])
+    assert float((d2 - torch.cat([d1a, d1b])).abs().max()) < 1e-3
+    d2b, _, _ = m(l, r)
+    assert torch.equal(d2, d2b)
+
+
+def test_fp16_autocast_mode_tracks_fp32():
+    """Deployment mode of the reference (autocast fp16, model_utils.py:76).  fp16 rounding of the cost volume legitimately
+    flips near-tie matches (16 % under default init), so this is a sanity bound, not a parity claim:
+    the median full-resolution disparity difference stays below 0.05 px and everything is finite."""
+    m = _model(128, 1, True, 2, False, 0)
+    l, r = synthetic_pair(128, 192, 1, 12, 9)
+    l, r = l.cuda(), r.cuda()
+    d32, o32, c32 = m(l, r)
+    with torch.autocast("cuda", dtype=torch.float16):
+        d16, o16, c16 = m(l, r)
+    assert d16.dtype == torch.float32
+    assert torch.isfinite(d16).all() and torch.isfinite(o16).all() and torch.isfinite(c16).all()
+    assert float((d16 - d32).abs().median()) < 0.05
+    assert float((c16 - c32).abs().median()) < 0.02
+
+
+def test_smallest_legal_image():
+    m = _model(128, 1, False, 1, False, 1)
+    l, r = synthetic_pair(32, 32, 1, 2, 3)
+    d, o, c = m(l.cuda(), r.cuda())
+    assert tuple(d.shape) == (1, 1, 32, 32) and torch.isfinite(d).all()

@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard pairs and gather the outputs to rank 0 in pair order."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from s2m2_amd.shard import gather_outputs, run_sharded, shard_indices
+
+
+def _fake_forward(l, r):
+    # deterministic per-pair "outputs": depends only on that pair's data (like the real forward)
+    d = (l - r).mean(dim=1, keepdim=True)
+    return d, d * 0.5, d.abs()
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    left = torch.rand(4, 3, 8, 16, generator=g)
+    right = torch.rand(4, 3, 8, 16, generator=g)
+    out = run_sharded(_fake_forward, left, right, dist, dst=0)
+    if rank == 0:
+        ref = _fake_forward(left, right)
+        q.put(all(torch.allclose(a, b) for a, b in zip(out, ref)))
+        one = gather_outputs(_fake_forward(left[:1] + rank, right[:1]), dist, 0)
+        q.put(tuple(one[0].shape) == (world, 1, 8, 16))
+    else:
+        assert out is None
+        gather_outputs(_fake_forward(left[:1] + rank, right[:1]), dist, 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_indices_cover_all_pairs():
+    for n, w in [(8, 8), (8, 2), (6, 3), (5, 2)]:
+        seen = sorted(p for r in range(w) for p in shard_indices(n, r, w))
+        assert seen == list(range(n))
+
+
+@pytest.mark.timeout(120)
+def test_world2_gloo_gather_in_pair_order():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90), q.get(timeout=90)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [True, True]
