@@ -3,189 +3,225 @@
 // Replaces DispInit.forward's  layer_norm -> chunk -> einsum('...hic,...hjc->...hij')
 // (/root/reference/src/s2m2/core/model/submodules.py:165,216-217).
 //
-// Decomposition (one image row (b,y) is an independent w x w x C contraction):
-//   block  = one strip of TI = 32*NW left pixels of one image row  x  all w right pixels
-//   wave   = 32 left pixels; its normalised A operand lives in registers for the whole block
-//   loop   = chunks of TJ right pixels: raw tokens are fetched with 16-B coalesced loads (8 lanes per token),
-//            LayerNorm'ed in fp32 (two-pass mean/var, 8-lane butterfly), rounded to T and staged in LDS
-//            (row stride padded by 16 B -> conflict-free ds_read_b128 for the MFMA fragments), double buffered
-//            so the HBM/L2 latency of chunk c+1 hides under the MFMAs and stores of chunk c;
-//   store  = accumulators go through a wave-private LDS tile so that every lane writes 16 contiguous bytes
-//            of one cost-volume row (a 32 x TJ tile = 32 segments of >= 128 B).
-// Blocks of the same image row are made neighbours on one XCD (xcd_remap) so the right-image tokens, which
-// every strip re-reads, are served by that XCD's L2.
-//
+// One image row (b,y) is an independent  w x w x C  contraction  S = LN(L) . LN(R)^T  (L, R: w tokens of C channels).
+//   block  = NW waves = one image row (or a strip of NW*32 left pixels of it); NW is a launch parameter.
+//   wave   = 32 left pixels AND 32 right pixels per chunk: at kernel entry it puts both token sets in flight with 16-B
+//            coalesced loads (8 lanes per token) -- for w <= 32*NW that is the block's entire input, 2*w*C*sizeof(T)
+//            bytes in flight per CU at once.  Tokens are LayerNorm'ed in fp32 (two-pass mean/var, 8-lane butterfly),
+//            rounded to T and written to LDS rows padded by 16 B (conflict-free ds_read_b128 fragment reads).
+//            The wave's own left tokens bounce through its LDS slice into MFMA fragments that stay in registers.
+//   sync   = ONE block barrier per chunk of NW*32 right pixels (one per row when it fits); after it every wave
+//            sweeps the column tiles on its own (staggered start), no further block-level synchronisation.
+//   MFMA   = roles swapped on purpose: D = R_tile . L_wave^T, so a lane ends up with 4 CONSECUTIVE j of one row i
+//            per register quad -> the accumulators go to a wave-private LDS tile with 4 wide writes per 32x32
+//            tile (instead of 32 two-byte writes), come back as 16-B pieces of whole rows, and every global store
+//            instruction writes 8 rows x 128 contiguous bytes of the cost volume.
+// Every feature token is read from HBM once and normalised once per strip; the cost volume is written once.
 // Algorithmic traffic per pair: 2*h*w*C*sizeof(T) read + h*w*w*sizeof(TO) written.
 #include "common.h"
+#include <stdlib.h>
 
 namespace s2m2 {
 
-template <typename T, typename TO, int C_, int NW_, int TJ_, int NBUF_>
+template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_>
 struct LnCorrCfg {
-    static constexpr int C = C_, NW = NW_, TJ = TJ_, NBUF = NBUF_;
+    static constexpr int C = C_;
+    static constexpr int RIF = RIF_;                    // token rounds (8 tokens per wave each) kept in flight in registers
+    static constexpr bool EARLY_B = EARLY_B_;           // right tokens of chunk 0 are requested together with the left ones
     static constexpr int VEC = 16 / sizeof(T);          // elements per 16-B piece
     static constexpr int PIECES = C / VEC;              // pieces per token
     static constexpr int LPT = 8;                       // lanes per token
     static constexpr int PPL = PIECES / LPT;            // pieces per lane per token
-    static constexpr int TPR = NW * 64 / LPT;           // tokens per block-wide load round
-    static constexpr int TI = NW * 32;                  // left pixels per block
-    static constexpr int A_ROUNDS = TI / TPR;           // = 4
-    static constexpr int B_ROUNDS = TJ / TPR;
     static constexpr int RS = C + VEC;                  // LDS row stride (elements): +16 B pad
     static constexpr int VECO = 16 / sizeof(TO);
-    static constexpr int CRS = TJ + VECO;               // staging row stride (elements of TO)
+    static constexpr int CRS = 64 + VECO;               // staging row stride (elements of TO): 2 tiles + 16 B pad
     static constexpr int KSTEPS = C / 16;
-    static constexpr int CT = TJ / 32;                  // 32-wide column tiles per chunk
     static constexpr size_t GB_BYTES = 2 * C * sizeof(float);
-    static constexpr size_t B_BYTES = (size_t)NBUF * TJ * RS * sizeof(T);
-    static constexpr size_t A_BYTES = (size_t)TI * RS * sizeof(T);
-    static constexpr size_t CS_BYTES = (size_t)NW * 32 * CRS * sizeof(TO);
-    static constexpr size_t AC_BYTES = A_BYTES > CS_BYTES ? A_BYTES : CS_BYTES;   // Cs aliases As (A is in registers)
-    static constexpr size_t LDS_BYTES = GB_BYTES + B_BYTES + AC_BYTES;
+    static constexpr size_t WB_BYTES = (size_t)32 * RS * sizeof(T);      // per wave: its 32 normalised tokens
+    static constexpr size_t WC_BYTES = (size_t)32 * CRS * sizeof(TO);    // per wave: 32 x 64 output staging
+    static constexpr size_t lds_bytes(int nw) { return GB_BYTES + (size_t)nw * (WB_BYTES + WC_BYTES); }
+    static constexpr int NWLDS = (int)((160 * 1024 - GB_BYTES) / (WB_BYTES + WC_BYTES));
+    static constexpr int NWMAX = NWLDS < NWCAP_ ? NWLDS : NWCAP_;      // waves per block: LDS bound, register bound
     static_assert(PIECES % LPT == 0, "C must be a multiple of 8 pieces");
-    static_assert(B_ROUNDS >= 1 && TJ % TPR == 0, "TJ must be a multiple of tokens-per-round");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(NWMAX >= 1, "LDS budget");
 };
 
-template <typename CFG, typename T, int ROUNDS> struct RawTile { Vec16<T> p[ROUNDS][CFG::PPL]; };
-
-// issue the 16-B loads of ROUNDS*TPR consecutive tokens starting at token t0 (clamped to the row)
-template <typename CFG, typename T, int ROUNDS>
-__device__ __forceinline__ void load_raw(RawTile<CFG, T, ROUNDS>& raw, const T* __restrict__ src, int t0, int w, int tid) {
-    const int sub = tid & (CFG::LPT - 1);
-    const int trow = tid / CFG::LPT;
+// LayerNorm (eps 1e-5, biased variance, affine) one token spread over 8 lanes (PPL 16-B pieces per lane) in fp32 and
+// write it, rounded to T, to its LDS row.  Contraction is pinned (explicit fmaf, contract off) so that left and right
+// tokens round identically: swapping the two images then transposes the cost volume bit-exactly (tests rely on it).
+#pragma clang fp contract(off)
+template <typename CFG, typename T>
+__device__ __forceinline__ void normalize_store(const Vec16<T> (&p)[CFG::PPL], T* __restrict__ drow,
+                                                const float* __restrict__ gb, int sub) {
+    constexpr float inv_c = 1.0f / CFG::C;
+    float x[CFG::PPL][CFG::VEC];
+    float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        int tok = t0 + r * CFG::TPR + trow;
-        tok = tok < w ? tok : w - 1;
-        const T* p = src + (size_t)tok * CFG::C;
+    for (int q = 0; q < CFG::PPL; ++q)
 #pragma unroll
-        for (int q = 0; q < CFG::PPL; ++q)
-            raw.p[r][q] = *reinterpret_cast<const Vec16<T>*>(p + (sub + CFG::LPT * q) * CFG::VEC);
+        for (int e = 0; e < CFG::VEC; ++e) { x[q][e] = to_f32(p[q].v[e]); s += x[q][e]; }
+    const float mean = group_sum<CFG::LPT>(s) * inv_c;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < CFG::PPL; ++q)
+#pragma unroll
+        for (int e = 0; e < CFG::VEC; ++e) { x[q][e] -= mean; ss = __builtin_fmaf(x[q][e], x[q][e], ss); }
+    const float rstd = rsqrtf(group_sum<CFG::LPT>(ss) * inv_c + 1e-5f);
+#pragma unroll
+    for (int q = 0; q < CFG::PPL; ++q) {
+        const int c0 = (sub + CFG::LPT * q) * CFG::VEC;
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < CFG::VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[q][e] * rstd, gb[c0 + e], gb[CFG::C + c0 + e]));
+        *reinterpret_cast<Vec16<T>*>(drow + c0) = o;
     }
 }
 
-// LayerNorm (eps 1e-5, biased variance, affine) each token in fp32 and write it, rounded to T, to dst[token][RS]
-template <typename CFG, typename T, int ROUNDS>
-__device__ __forceinline__ void normalize_store(const RawTile<CFG, T, ROUNDS>& raw, T* __restrict__ dst,
-                                                const float* __restrict__ gb, int tid) {
-    const int sub = tid & (CFG::LPT - 1);
-    const int trow = tid / CFG::LPT;
-    constexpr float inv_c = 1.0f / CFG::C;
+template <typename CFG, typename T>
+__device__ __forceinline__ void load_token(Vec16<T> (&p)[CFG::PPL], const T* __restrict__ src, int tok, int w, int sub) {
+    tok = tok < w ? tok : w - 1;                                   // ragged tail: duplicates, never stored
+    const T* q0 = src + (size_t)tok * CFG::C + sub * CFG::VEC;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        float x[CFG::PPL][CFG::VEC];
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < CFG::PPL; ++q)
-#pragma unroll
-            for (int e = 0; e < CFG::VEC; ++e) { x[q][e] = to_f32(raw.p[r][q].v[e]); s += x[q][e]; }
-        const float mean = group_sum<CFG::LPT>(s) * inv_c;
-        float ss = 0.f;
-#pragma unroll
-        for (int q = 0; q < CFG::PPL; ++q)
-#pragma unroll
-            for (int e = 0; e < CFG::VEC; ++e) { x[q][e] -= mean; ss += x[q][e] * x[q][e]; }
-        const float rstd = rsqrtf(group_sum<CFG::LPT>(ss) * inv_c + 1e-5f);
-        T* drow = dst + (size_t)(r * CFG::TPR + trow) * CFG::RS;
-#pragma unroll
-        for (int q = 0; q < CFG::PPL; ++q) {
-            const int c0 = (sub + CFG::LPT * q) * CFG::VEC;
-            Vec16<T> o;
-#pragma unroll
-            for (int e = 0; e < CFG::VEC; ++e) o.v[e] = from_f32<T>(x[q][e] * rstd * gb[c0 + e] + gb[CFG::C + c0 + e]);
-            *reinterpret_cast<Vec16<T>*>(drow + c0) = o;
-        }
-    }
+    for (int q = 0; q < CFG::PPL; ++q) p[q] = *reinterpret_cast<const Vec16<T>*>(q0 + CFG::LPT * q * CFG::VEC);
+}
+
+template <typename TO> __device__ __forceinline__ void store_quad(TO* dst, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store_quad<half_t>(half_t* dst, float a, float b, float c, float d) {
+    half4_t v = {(half_t)a, (half_t)b, (half_t)c, (half_t)d};
+    *reinterpret_cast<half4_t*>(dst) = v;
+}
+template <> __device__ __forceinline__ void store_quad<float>(float* dst, float a, float b, float c, float d) {
+    float4_t v = {a, b, c, d};
+    *reinterpret_cast<float4_t*>(dst) = v;
 }
 
 template <typename CFG, typename T, typename TO>
-__global__ __launch_bounds__(CFG::NW * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, TO* __restrict__ cv,
-                                                              int B, int h, int w, int nstrip) {
+__global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, TO* __restrict__ cv,
+                                                                 int B, int h, int w, int nstrip) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
-    T* Bs = reinterpret_cast<T*>(smem + CFG::GB_BYTES);
-    T* As = reinterpret_cast<T*>(smem + CFG::GB_BYTES + CFG::B_BYTES);
-    TO* Cs = reinterpret_cast<TO*>(smem + CFG::GB_BYTES + CFG::B_BYTES);
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = tid >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NW = blockDim.x >> 6;
+    T* Bs = reinterpret_cast<T*>(smem + CFG::GB_BYTES);                               // [NW*32][RS] normalised right tokens
+    T* Wb = Bs + (size_t)wv * 32 * CFG::RS;                                           // this wave's 32 rows of it
+    TO* Wc = reinterpret_cast<TO*>(smem + CFG::GB_BYTES + (size_t)NW * CFG::WB_BYTES + (size_t)wv * CFG::WC_BYTES);
+
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int row = bid / nstrip;            // (b, y)
+    const int row = bid / nstrip;                       // (b, y)
     const int strip = bid - row * nstrip;
     const int b = row / h, y = row - b * h;
-    const int i0 = strip * CFG::TI;
+    const int i0 = (strip * NW + wv) * 32;              // first left pixel of this wave
+    const bool wave_active = i0 < w;
     const T* left = feat + ((size_t)(b * h + y) * w) * CFG::C;
     const T* right = feat + ((size_t)((B + b) * h + y) * w) * CFG::C;
     TO* cvrow = cv + (size_t)row * w * w;
+    const int sub = lane & 7, trow = lane >> 3;
+    const int TJ = NW * 32;                             // right pixels per chunk (the whole row when w <= TJ)
+    const int nchunks = (w + TJ - 1) / TJ;
 
-    RawTile<CFG, T, CFG::A_ROUNDS> rawA;
-    RawTile<CFG, T, CFG::B_ROUNDS> rawB;
-    load_raw<CFG, T, CFG::A_ROUNDS>(rawA, left, i0, w, tid);
-    load_raw<CFG, T, CFG::B_ROUNDS>(rawB, right, 0, w, tid);
-    for (int c = tid; c < CFG::C; c += CFG::NW * 64) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
-    __syncthreads();
-    normalize_store<CFG, T, CFG::A_ROUNDS>(rawA, As, gb, tid);
-    __syncthreads();
-
-    // this wave's A operand: rows i0 + 32*wv + (lane&31), all C channels, as KSTEPS k16-fragments
+    // ---- everything this wave needs first is put in flight at once: 32 left tokens (+ 32 right tokens of chunk 0)
+    static_assert(!CFG::EARLY_B || CFG::RIF == 4, "EARLY_B needs all four rounds in registers");
+    Vec16<T> rawB[CFG::RIF][CFG::PPL];
     Frag<T> afrag[CFG::KSTEPS];
     {
-        const T* ap = As + (size_t)(wv * 32 + (lane & 31)) * CFG::RS + (lane >> 5) * 8;
+        Vec16<T> rawA[CFG::RIF][CFG::PPL];
+        if (wave_active) {
 #pragma unroll
-        for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
+            for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawA[r], left, i0 + r * 8 + trow, w, sub);
+        }
+        if (CFG::EARLY_B) {
+#pragma unroll
+            for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, wv * 32 + r * 8 + trow, w, sub);
+        }
+        for (int c = tid; c < CFG::C; c += blockDim.x) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
+        __syncthreads();
+        // left operand: normalise -> (this wave's slice of Bs as scratch) -> k16 fragments in registers
+        if (wave_active) {
+#pragma unroll
+            for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
+                if (r0 > 0) {
+#pragma unroll
+                    for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawA[r], left, i0 + (r0 + r) * 8 + trow, w, sub);
+                }
+#pragma unroll
+                for (int r = 0; r < CFG::RIF; ++r)
+                    normalize_store<CFG, T>(rawA[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub);
+            }
+            __builtin_amdgcn_wave_barrier();
+            const T* ap = Wb + (size_t)(lane & 31) * CFG::RS + (lane >> 5) * 8;
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    __syncthreads();                          // As is dead from here on; its space becomes the store staging Cs
-
-    const bool wave_active = (i0 + wv * 32) < w;
-    const int nchunks = (w + CFG::TJ - 1) / CFG::TJ;
-    TO* cs = Cs + (size_t)wv * 32 * CFG::CRS;
 
     for (int c = 0; c < nchunks; ++c) {
-        T* bs = Bs + (size_t)(CFG::NBUF == 2 ? (c & 1) : 0) * CFG::TJ * CFG::RS;
-        if (CFG::NBUF == 1 && c > 0) __syncthreads();            // previous chunk's readers are done
-        normalize_store<CFG, T, CFG::B_ROUNDS>(rawB, bs, gb, tid);
-        if (c + 1 < nchunks) load_raw<CFG, T, CFG::B_ROUNDS>(rawB, right, (c + 1) * CFG::TJ, w, tid);
+        // right tokens of this chunk: each wave normalises its 32 into its slice, then prefetches its share of the next chunk
+        const int t0 = c * TJ + wv * 32;
+#pragma unroll
+        for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
+            if (!(CFG::RIF == 4 && (c > 0 || CFG::EARLY_B))) {
+#pragma unroll
+                for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, t0 + (r0 + r) * 8 + trow, w, sub);
+            }
+#pragma unroll
+            for (int r = 0; r < CFG::RIF; ++r)
+                normalize_store<CFG, T>(rawB[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub);
+        }
+        if (CFG::RIF == 4 && c + 1 < nchunks) {
+#pragma unroll
+            for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, t0 + TJ + r * 8 + trow, w, sub);
+        }
         __syncthreads();
-        if (!wave_active) continue;
-
-        float16_t acc[CFG::CT];
+        if (wave_active) {
+            const int jbase = c * TJ;
+            int ntile = (w - jbase + 31) / 32;                    // 32-wide column tiles with data in this chunk
+            ntile = ntile < NW ? ntile : NW;
+            const int npair = (ntile + 1) >> 1;
+            for (int pp = 0; pp < npair; ++pp) {
+                int pr = pp + wv;                                 // stagger the waves over the column tiles
+                pr = pr >= npair ? pr - npair : pr;
+                pr = pr >= npair ? pr % npair : pr;
 #pragma unroll
-        for (int ct = 0; ct < CFG::CT; ++ct)
+                for (int half = 0; half < 2; ++half) {
+                    const int ct = pr * 2 + half;
+                    if (ct < ntile) {
+                        float16_t acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-        const T* bp = bs + (size_t)(lane & 31) * CFG::RS + (lane >> 5) * 8;
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        const T* bp = Bs + (size_t)(ct * 32 + (lane & 31)) * CFG::RS + (lane >> 5) * 8;
 #pragma unroll
-        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                            Frag<T> bf;
+                            load_frag(bf, bp + kk * 16);
+                            mma32(acc, bf, afrag[kk]);            // D[j][i]: lane = left pixel i, registers = right pixels j
+                        }
+                        TO* wrow = Wc + (size_t)(lane & 31) * CFG::CRS + half * 32 + 4 * (lane >> 5);
 #pragma unroll
-            for (int ct = 0; ct < CFG::CT; ++ct) {
-                Frag<T> bf;
-                load_frag(bf, bp + (size_t)ct * 32 * CFG::RS + kk * 16);
-                mma32(acc[ct], afrag[kk], bf);
+                        for (int g = 0; g < 4; ++g)
+                            store_quad<TO>(wrow + 8 * g, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                constexpr int PPR = 64 / CFG::VECO;               // 16-B pieces per staged row (64 columns)
+                constexpr int ITERS = 32 * PPR / 64;
+                const int j0 = jbase + pr * 64;
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    const int q = it * 64 + lane;
+                    const int rr = q / PPR, pc = q - rr * PPR;
+                    const int i = i0 + rr;
+                    const int j = j0 + pc * CFG::VECO;
+                    const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
+                    if (i < w && j < w) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        // accumulators -> wave-private LDS tile -> 16-B row-contiguous global stores
-#pragma unroll
-        for (int ct = 0; ct < CFG::CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                cs[acc_row(r, lane) * CFG::CRS + ct * 32 + (lane & 31)] = from_f32<TO>(acc[ct][r]);
-        __builtin_amdgcn_wave_barrier();
-        constexpr int PPR = CFG::TJ / CFG::VECO;          // 16-B pieces per staged row
-        constexpr int ITERS = 32 * PPR / 64;
-        const int j0 = c * CFG::TJ;
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int q = it * 64 + lane;
-            const int rr = q / PPR, pc = q - rr * PPR;
-            const int i = i0 + wv * 32 + rr;
-            const int j = j0 + pc * CFG::VECO;
-            const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(cs + rr * CFG::CRS + pc * CFG::VECO);
-            if (i < w && j < w) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
-        }
-        __builtin_amdgcn_wave_barrier();
+        if (c + 1 < nchunks) __syncthreads();                     // all readers done before Bs is overwritten
     }
 }
 
@@ -198,29 +234,36 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     static bool attr_done = false;                       // per instantiation
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)CFG::LDS_BYTES) != hipSuccess)
-            return set_error("ln_corr: cannot reserve %zu bytes of LDS", (size_t)CFG::LDS_BYTES);
+                                (int)CFG::lds_bytes(CFG::NWMAX)) != hipSuccess)
+            return set_error("ln_corr: cannot reserve %zu bytes of LDS", CFG::lds_bytes(CFG::NWMAX));
         attr_done = true;
     }
-    const int nstrip = (w + CFG::TI - 1) / CFG::TI;
+    const int tiles = (w + 31) / 32;                     // 32-pixel row tiles = waves needed per image row
+    int nstrip = (tiles + CFG::NWMAX - 1) / CFG::NWMAX;
+    // small problems: split rows into strips until the grid covers the chip (each strip re-normalises the right row)
+    while (B * h * nstrip < 200 && nstrip < tiles && (tiles + nstrip) / (nstrip + 1) >= 2) ++nstrip;
+    static const int force_nstrip = getenv("S2M2_LNCORR_NSTRIP") ? atoi(getenv("S2M2_LNCORR_NSTRIP")) : 0;   // tuning knob
+    if (force_nstrip > 0 && (tiles + force_nstrip - 1) / force_nstrip <= CFG::NWMAX) nstrip = force_nstrip;
+    const int nw = (tiles + nstrip - 1) / nstrip;
     const int nblocks = B * h * nstrip;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(CFG::NW * 64), CFG::LDS_BYTES, st,
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
                        static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip);
     return check_launch("ln_corr");
 }
 
-// tile configuration per (dtype, C): NW waves (32 left pixels each), TJ right pixels per chunk, NBUF LDS buffers
+// per (dtype, C): cap on waves per block from the registers the resident left-operand fragments need (the LDS bound --
+// 32 normalised tokens + a 32x64 staging tile per wave -- is computed in LnCorrCfg)
 template <typename T, int C> struct LnCorrPick;
-template <> struct LnCorrPick<half_t, 64>  { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 64, 4, 64, 2>; };
-template <> struct LnCorrPick<half_t, 128> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 128, 4, 64, 2>; };
-template <> struct LnCorrPick<half_t, 192> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 192, 4, 64, 2>; };
-template <> struct LnCorrPick<half_t, 256> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 256, 4, 64, 2>; };
-template <> struct LnCorrPick<half_t, 384> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 384, 4, 32, 2>; };
-template <> struct LnCorrPick<float, 64>   { template <typename TO> using cfg = LnCorrCfg<float, TO, 64, 4, 32, 2>; };
-template <> struct LnCorrPick<float, 128>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 128, 4, 32, 2>; };
-template <> struct LnCorrPick<float, 192>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 192, 4, 32, 2>; };
-template <> struct LnCorrPick<float, 256>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 256, 2, 32, 2>; };
-template <> struct LnCorrPick<float, 384>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 384, 2, 32, 1>; };
+template <> struct LnCorrPick<half_t, 64>  { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 64, 12, 4, true>; };
+template <> struct LnCorrPick<half_t, 128> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 128, 11, 4, true>; };
+template <> struct LnCorrPick<half_t, 192> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 192, 8, 4, false>; };
+template <> struct LnCorrPick<half_t, 256> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 256, 8, 2, false>; };
+template <> struct LnCorrPick<half_t, 384> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 384, 4, 2, false>; };
+template <> struct LnCorrPick<float, 64>   { template <typename TO> using cfg = LnCorrCfg<float, TO, 64, 12, 4, true>; };
+template <> struct LnCorrPick<float, 128>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 128, 8, 4, false>; };
+template <> struct LnCorrPick<float, 192>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 192, 8, 2, false>; };
+template <> struct LnCorrPick<float, 256>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 256, 4, 2, false>; };
+template <> struct LnCorrPick<float, 384>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 384, 4, 1, false>; };
 
 template <typename T, typename TO>
 static int dispatch_c(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, int C, hipStream_t st) {
