@@ -16,7 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
-LIB = os.path.join(LIBDIR, "libs2m2_hip.so")
+SUFFIX = os.environ.get("S2M2_LIB_SUFFIX", "")          # experiment builds: extra -D flags -> libs2m2_hip<suffix>.so
+DEFINES = os.environ.get("S2M2_BUILD_DEFINES", "").split()
+LIB = os.path.join(LIBDIR, f"libs2m2_hip{SUFFIX}.so")
+if SUFFIX:
+    OBJ = os.path.join(CSRC, "_obj" + SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on", "-fno-fast-math"]
@@ -41,7 +45,7 @@ def _compile(src: str, force: bool, hdr_mtime: float) -> str:
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
             and os.path.getmtime(obj) > hdr_mtime):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", spath, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *DEFINES, "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")

@@ -85,6 +85,17 @@ template <int WIDTH> __device__ __forceinline__ float group_sum(float x) {
     for (int o = WIDTH / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
 }
+// DPP cross-lane moves (VALU data path, no LDS round trip -- __shfl_xor lowers to ds_bpermute, ~100+ cycles each)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum over aligned groups of 8 lanes, result in all 8: quad_perm[1,0,3,2], quad_perm[2,3,0,1], row_half_mirror
+__device__ __forceinline__ float group8_sum(float x) {
+    x += dpp_mov<0xB1>(x);
+    x += dpp_mov<0x4E>(x);
+    x += dpp_mov<0x141>(x);
+    return x;
+}
 __device__ __forceinline__ float wave_sum(float x) { return group_sum<64>(x); }
 __device__ __forceinline__ float wave_max(float x) {
 #pragma unroll

@@ -21,6 +21,12 @@
 #include "common.h"
 #include <stdlib.h>
 
+// compile-time ablation switches for tools/k1_ablate.py (never set in the shipped library):
+// 1 no global stores, 2 no MFMA, 4 no LayerNorm arithmetic, 8 no multiply/store phase at all
+#ifndef S2M2_LNCORR_DBG
+#define S2M2_LNCORR_DBG 0
+#endif
+
 namespace s2m2 {
 
 template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_>
@@ -42,7 +48,7 @@ struct LnCorrCfg {
     static constexpr size_t lds_bytes(int nw) { return GB_BYTES + (size_t)nw * (WB_BYTES + WC_BYTES); }
     static constexpr int NWLDS = (int)((160 * 1024 - GB_BYTES) / (WB_BYTES + WC_BYTES));
     static constexpr int NWMAX = NWLDS < NWCAP_ ? NWLDS : NWCAP_;      // waves per block: LDS bound, register bound
-    static_assert(PIECES % LPT == 0, "C must be a multiple of 8 pieces");
+    static_assert(PIECES % LPT == 0 && LPT == 8, "C must be a multiple of 8 pieces; group8_sum assumes 8 lanes per token");
     static_assert(NWMAX >= 1, "LDS budget");
 };
 
@@ -52,21 +58,26 @@ struct LnCorrCfg {
 #pragma clang fp contract(off)
 template <typename CFG, typename T>
 __device__ __forceinline__ void normalize_store(const Vec16<T> (&p)[CFG::PPL], T* __restrict__ drow,
-                                                const float* __restrict__ gb, int sub) {
+                                                const float* __restrict__ gb, int sub, int dbg = 0) {
     constexpr float inv_c = 1.0f / CFG::C;
+    if (dbg & 4) {                                       // ablation: no LayerNorm arithmetic, plain copy
+#pragma unroll
+        for (int q = 0; q < CFG::PPL; ++q) *reinterpret_cast<Vec16<T>*>(drow + (sub + CFG::LPT * q) * CFG::VEC) = p[q];
+        return;
+    }
     float x[CFG::PPL][CFG::VEC];
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < CFG::PPL; ++q)
 #pragma unroll
         for (int e = 0; e < CFG::VEC; ++e) { x[q][e] = to_f32(p[q].v[e]); s += x[q][e]; }
-    const float mean = group_sum<CFG::LPT>(s) * inv_c;
+    const float mean = group8_sum(s) * inv_c;
     float ss = 0.f;
 #pragma unroll
     for (int q = 0; q < CFG::PPL; ++q)
 #pragma unroll
         for (int e = 0; e < CFG::VEC; ++e) { x[q][e] -= mean; ss = __builtin_fmaf(x[q][e], x[q][e], ss); }
-    const float rstd = rsqrtf(group_sum<CFG::LPT>(ss) * inv_c + 1e-5f);
+    const float rstd = rsqrtf(group8_sum(ss) * inv_c + 1e-5f);
 #pragma unroll
     for (int q = 0; q < CFG::PPL; ++q) {
         const int c0 = (sub + CFG::LPT * q) * CFG::VEC;
@@ -99,6 +110,7 @@ template <typename CFG, typename T, typename TO>
 __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, TO* __restrict__ cv,
                                                                  int B, int h, int w, int nstrip) {
+    constexpr int dbg = S2M2_LNCORR_DBG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x;
@@ -124,6 +136,9 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 
     // ---- everything this wave needs first is put in flight at once: 32 left tokens (+ 32 right tokens of chunk 0)
     static_assert(!CFG::EARLY_B || CFG::RIF == 4, "EARLY_B needs all four rounds in registers");
+    // (the LayerNorm affine goes to LDS first: __syncthreads() drains vmcnt, so no token load may be pending across it)
+    for (int c = tid; c < CFG::C; c += blockDim.x) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
+    __syncthreads();
     Vec16<T> rawB[CFG::RIF][CFG::PPL];
     Frag<T> afrag[CFG::KSTEPS];
     {
@@ -136,8 +151,6 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, wv * 32 + r * 8 + trow, w, sub);
         }
-        for (int c = tid; c < CFG::C; c += blockDim.x) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
-        __syncthreads();
         // left operand: normalise -> (this wave's slice of Bs as scratch) -> k16 fragments in registers
         if (wave_active) {
 #pragma unroll
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                 }
 #pragma unroll
                 for (int r = 0; r < CFG::RIF; ++r)
-                    normalize_store<CFG, T>(rawA[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub);
+                    normalize_store<CFG, T>(rawA[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub, dbg);
             }
             __builtin_amdgcn_wave_barrier();
             const T* ap = Wb + (size_t)(lane & 31) * CFG::RS + (lane >> 5) * 8;
@@ -169,43 +182,53 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
             }
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r)
-                normalize_store<CFG, T>(rawB[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub);
+                normalize_store<CFG, T>(rawB[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub, dbg);
         }
         if (CFG::RIF == 4 && c + 1 < nchunks) {
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, t0 + TJ + r * 8 + trow, w, sub);
         }
         __syncthreads();
-        if (wave_active) {
+        if (wave_active && !(dbg & 8)) {
             const int jbase = c * TJ;
             int ntile = (w - jbase + 31) / 32;                    // 32-wide column tiles with data in this chunk
             ntile = ntile < NW ? ntile : NW;
             const int npair = (ntile + 1) >> 1;
-            for (int pp = 0; pp < npair; ++pp) {
-                int pr = pp + wv;                                 // stagger the waves over the column tiles
-                pr = pr >= npair ? pr - npair : pr;
-                pr = pr >= npair ? pr % npair : pr;
+            // The column tiles are taken two at a time (64 columns = 128-B row segments in the stores), starting at a
+            // different pair per wave.  Software pipeline: the 16 MFMAs of pair p+1 (two independent accumulators,
+            // interleaved) are issued BEFORE pair p is read back from the staging tile and stored, so the matrix
+            // pipe works while this wave sits in the (HBM-bound) store queue.
+            float16_t acc0, acc1;
+            auto pair_of = [&](int pp) { int pr = pp + wv; pr = pr >= npair ? pr - npair : pr; return pr >= npair ? pr % npair : pr; };
+            auto mma_pair = [&](int pr) {
+                const int ct0 = pr * 2;
+                const bool two = ct0 + 1 < ntile;
+                const T* bp0 = Bs + (size_t)(ct0 * 32 + (lane & 31)) * CFG::RS + (lane >> 5) * 8;
+                const T* bp1 = two ? bp0 + 32 * CFG::RS : bp0;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int ct = pr * 2 + half;
-                    if (ct < ntile) {
-                        float16_t acc;
+                for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+                if (!(dbg & 2)) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                        const T* bp = Bs + (size_t)(ct * 32 + (lane & 31)) * CFG::RS + (lane >> 5) * 8;
-#pragma unroll
-                        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-                            Frag<T> bf;
-                            load_frag(bf, bp + kk * 16);
-                            mma32(acc, bf, afrag[kk]);            // D[j][i]: lane = left pixel i, registers = right pixels j
-                        }
-                        TO* wrow = Wc + (size_t)(lane & 31) * CFG::CRS + half * 32 + 4 * (lane >> 5);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            store_quad<TO>(wrow + 8 * g, acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+                    for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                        Frag<T> b0, b1;
+                        load_frag(b0, bp0 + kk * 16);
+                        load_frag(b1, bp1 + kk * 16);
+                        mma32(acc0, b0, afrag[kk]);               // D[j][i]: lane = left pixel i, registers = right pixels j
+                        mma32(acc1, b1, afrag[kk]);
                     }
                 }
+            };
+            mma_pair(pair_of(0));
+            for (int pp = 0; pp < npair; ++pp) {
+                const int pr = pair_of(pp);
+                TO* wrow = Wc + (size_t)(lane & 31) * CFG::CRS + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    store_quad<TO>(wrow + 8 * g, acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+                    store_quad<TO>(wrow + 32 + 8 * g, acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+                }
                 __builtin_amdgcn_wave_barrier();
+                if (pp + 1 < npair) mma_pair(pair_of(pp + 1));
                 constexpr int PPR = 64 / CFG::VECO;               // 16-B pieces per staged row (64 columns)
                 constexpr int ITERS = 32 * PPR / 64;
                 const int j0 = jbase + pr * 64;
@@ -216,7 +239,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                     const int i = i0 + rr;
                     const int j = j0 + pc * CFG::VECO;
                     const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                    if (i < w && j < w) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
+                    if (i < w && j < w && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
             }

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libs2m2_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libs2m2_hip%s.so" % os.environ.get("S2M2_LIB_SUFFIX", ""))   # suffix: experiment builds only
 
 F32, F16 = 0, 1
 _DT = {torch.float32: F32, torch.float16: F16}
