@@ -61,6 +61,21 @@ def cpu_baseline(model_type, H, W, refine_iter):
             "sample": f"1 pair {W}x{H} {model_type}-model fp32 refine_iter={refine_iter}, oracle/s2m2_oracle.py (torch CPU ops), 1 timed run after a 96x64 warm-up"}
 
 
+def pmc_traffic(model_type, H, W, use_fp16, B):
+    """HBM bytes per K1 launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of
+    tools/k1_only.py, corrected as MI355X_MICROARCH.md prescribes -> profiles/rNN/k1_<case>_<dtype>_pmc.json).  PMC collection
+    serialises kernels and cannot run inside the timed bench, so the newest committed summary for this exact K1 shape is quoted."""
+    import glob
+    case = {("S", 1024, 1216): "c3", ("S", 480, 640): "c2", ("L", 1024, 1216): "c4", ("XL", 2048, 2432): "c5"}.get((model_type, H, W))
+    if case is None or B != 1:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"k1_{case}_{'fp16' if use_fp16 else 'fp32'}_pmc.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("traffic_bytes"), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -123,6 +138,7 @@ def main():
         k1_us = 1e3 * sum(k1_ms) / max(1, len(k1_ms))
         achieved = k1_bytes / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
         pairs = a.steps * B * world
+        traffic, traffic_src = pmc_traffic(a.model, a.height, a.width, use_fp16, B)
         line = {
             "metric": "stereo pairs/sec, S-model 1216x1024 fp16 refine_iter=3 (ms/pair = 1000*n_gpus/value)",
             "value": pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -134,7 +150,7 @@ def main():
                        "pairs_per_gpu": B, "parallelism": f"dp{world} (pairs sharded, RCCL gather of outputs to rank 0)"},
             "roofline": {"kernel": "ln_corr_kernel (K1: LayerNorm + all-pairs correlation -> cost volume)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": k1_us,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": k1_us,
                          "launches_timed": len(k1_ms)},
         }
         if world == 1 and not a.no_cpu_baseline:
