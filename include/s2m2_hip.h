@@ -74,6 +74,74 @@ int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2,
                    int B, int h, int w, int radius, int cv_dtype, int out_dtype,
                    long long batch_stride, long long pix_stride, long long tap_stride, void* stream);
 
+/*
+ * [A2,A3,A7,A8,A11,A12,A14,A15] implicit-GEMM convolution / linear layer with fused concatenation and epilogues.
+ *   Replaces the stride-1 nn.Conv2d / nn.ConvTranspose2d / nn.Linear call sites outside the CNN backbone
+ *   (refinenet.py:14-20,47-57,87-122; attentions.py:24-28,71-74,239-241,269-275; feature_fusion.py:15-21;
+ *   stacked_MRT.py:22-34; unet.py:25-37; submodules.py:104-108,127-135; s2m2.py:65-67) and the elementwise kernels
+ *   PyTorch launches around them: torch.cat of the inputs, bias, GELU/ReLU/sigmoid/tanh, residual add, the ConvGRU gate
+ *   arithmetic (refinenet.py:24-34), the FeatureFusion gate mix (feature_fusion.py:24-31).
+ *
+ *   out[n,y,x,co] = epi( out_scale * act( bias[co] + sum_{ky,kx,ci} in[n, y+ky-KH/2, x+kx-KW/2, ci] * weight[co,ky,kx,ci] ) )
+ *   in  = channel concatenation of src[0..nsrc) (NHWC, src_c[s] channels each, pixel stride src_stride[s]; zero padding)
+ *   weight  packed (Cout, KH*KW, Cin), Cin = sum(src_c), same dtype as the activations; bias fp32 (Cout) or NULL
+ *   out NHWC with pixel stride out_stride (write into a channel slice of a wider tensor by offsetting `out`)
+ *   every channel count / stride is a multiple of 8 (callers zero-pad: weights of padded channels are zero)
+ *   epi: ADD  v + aux0 | MUL  v * aux0 | GRU  (1-aux0)*aux1 + aux0*v  (aux0 = z, aux1 = h, v = q)
+ *        GATEMIX  g = clamp(v, .01, .99); g*aux0 + (1-g)*aux1          (aux tensors NHWC at the output pixel/channel)
+ *   shuffle2 = C' > 0: the conv is the GEMM of a ConvTranspose2d(kernel 2, stride 2): KH = KW = 1, Cout = 4*C' ordered
+ *        (dy, dx, c'), result stored to (N, 2H, 2W, C') with pixel stride out_stride.
+ *   tile: 0 = automatic, 1..4 force a block tile (128x128, 64x64, 128x32, 128x64) -- tests and tuning only.
+ */
+enum { S2M2_ACT_NONE = 0, S2M2_ACT_GELU = 1, S2M2_ACT_RELU = 2, S2M2_ACT_SIGMOID = 3, S2M2_ACT_TANH = 4 };
+enum { S2M2_EPI_NONE = 0, S2M2_EPI_ADD = 1, S2M2_EPI_MUL = 2, S2M2_EPI_GRU = 3, S2M2_EPI_GATEMIX = 4 };
+typedef struct s2m2_conv_desc {
+    const void* src[4];
+    int src_c[4];
+    int src_stride[4];
+    int nsrc;
+    const void* weight;
+    const float* bias;
+    void* out;
+    int out_stride;
+    int N, H, W, KH, KW, Cout;
+    int act, epi;
+    const void* aux0;
+    const void* aux1;
+    int aux0_stride, aux1_stride;
+    float out_scale;
+    int shuffle2;
+    int tile;
+    int dtype;
+} s2m2_conv_desc;
+int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
+
+/*
+ * [A2,A3] pre-norm LayerNorm without affine over the channel axis (attentions.py:117,148,182,213,243; eps 1e-5, biased var).
+ *   x, y: `rows` token rows of C channels, row strides x_stride / y_stride elements (multiples of 8); fp32 arithmetic.
+ */
+int s2m2_layernorm(const void* x, void* y, long long rows, int C, long long x_stride, long long y_stride, int dtype, void* stream);
+
+/*
+ * [A1] nn.GroupNorm(G, C) with affine on an NHWC activation (CNNEncoder, submodules.py:80,90).  x, y: (N, HW, C);
+ *   gamma, beta fp32 (C); workspace >= s2m2_groupnorm_workspace_bytes(N, G) bytes (zeroed inside, on the stream).
+ *   Statistics are accumulated in fp64, the normalisation runs in fp32.
+ */
+size_t s2m2_groupnorm_workspace_bytes(int N, int G);
+int s2m2_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* workspace, int N, long long HW,
+                        int C, int G, float eps, int dtype, void* stream);
+
+/*
+ * [A14,A15 tails] convex upsampling (S2M2.upsample4x / upsample1x, s2m2.py:101-133; custom_unfold utils.py:9-20):
+ *   out[m][b,Y,X] = scale[m] * sum_{n<9} softmax_n(logits[b,Y,X,0:9]) * x[m][b, clamp(Y/factor + n/3 - 1), clamp(X/factor + n%3 - 1)]
+ *   x[m]   (B, hs, ws) fp32, m < nmaps <= 3 (host array of device pointers);  out[m] (B, hs*factor, ws*factor) fp32
+ *   logits NHWC at the OUTPUT resolution, 9 used channels, rows padded to logit_stride >= 16 elements, dtype `dtype`;
+ *   logit_up2 = 1 (output_upsample, s2m2.py:123-127): logits are (B, hs, ws, .) and bilinearly upsampled x2
+ *   (align_corners=False, rounded to `dtype`) on the fly; factor must be 2.
+ */
+int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
+                         int logit_stride, int B, int hs, int ws, int factor, int logit_up2, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

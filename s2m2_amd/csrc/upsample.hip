@@ -1,0 +1,113 @@
+// K7 -- convex upsampling: 9-way softmax of the mask logits + weighted sum of the 3x3 replicate-padded neighbourhood.
+//
+// Replaces S2M2.upsample4x / upsample1x (reference s2m2.py:101-133: custom_unfold (utils.py:9-20) -> F.interpolate(nearest)
+// -> softmax(dim=1) -> multiply -> sum; with output_upsample also a bilinear x2 of the logits) for all three maps
+// (disparity, occlusion, confidence) in one pass: the reference materialises three (B,9,H,W) unfolded tensors and a
+// (B,9,H,W) softmax; here each output pixel reads its 9 logits once (NHWC, channels 0..8 of a 16-channel-padded row) and
+// gathers the 9 low-resolution neighbours from cache.  HBM-bound: ~(logit row + 3*4 B) per output pixel.
+//   out[m][b,Y,X] = scale_m * sum_n softmax_n(logit[b,Y,X,:9]) * x[m][b, clamp(Y/f + n/3 - 1), clamp(X/f + n%3 - 1)]
+#include "common.h"
+
+namespace s2m2 {
+
+struct UpArgs {
+    const float* x[3];
+    float* out[3];
+    float scale[3];
+    const void* logits;
+    int nmaps, logit_stride, B, hs, ws, factor, logit_up2;
+};
+
+template <typename T>
+__device__ __forceinline__ void load9(const T* p, float (&l)[9]) {
+    constexpr int VEC = 16 / sizeof(T);
+    constexpr int NP = (9 + VEC - 1) / VEC;
+    Vec16<T> v[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) v[q] = *reinterpret_cast<const Vec16<T>*>(p + q * VEC);
+#pragma unroll
+    for (int n = 0; n < 9; ++n) l[n] = to_f32(v[n / VEC].v[n % VEC]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convex_upsample_kernel(UpArgs a) {
+    const int Ho = a.hs * a.factor, Wo = a.ws * a.factor;
+    const long long total = (long long)a.B * Ho * Wo;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int X = (int)(gid % Wo);
+    const long long t = gid / Wo;
+    const int Y = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const T* lg = static_cast<const T*>(a.logits);
+    float l[9];
+    if (!a.logit_up2) {
+        load9<T>(lg + gid * a.logit_stride, l);
+    } else {
+        // bilinear x2, align_corners=False (ATen upsample_bilinear2d: src = max((dst + 0.5) * 0.5 - 0.5, 0)), rounded to T
+        const float sy = fmaxf(((float)Y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf(((float)X + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < a.hs - 1), x1 = x0 + (x0 < a.ws - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        float l00[9], l01[9], l10[9], l11[9];
+        const long long base = (long long)b * a.hs * a.ws;
+        load9<T>(lg + (base + (long long)y0 * a.ws + x0) * a.logit_stride, l00);
+        load9<T>(lg + (base + (long long)y0 * a.ws + x1) * a.logit_stride, l01);
+        load9<T>(lg + (base + (long long)y1 * a.ws + x0) * a.logit_stride, l10);
+        load9<T>(lg + (base + (long long)y1 * a.ws + x1) * a.logit_stride, l11);
+#pragma unroll
+        for (int n = 0; n < 9; ++n) {
+            const float v = (1.f - ly) * ((1.f - lx) * l00[n] + lx * l01[n]) + ly * ((1.f - lx) * l10[n] + lx * l11[n]);
+            l[n] = to_f32(from_f32<T>(v));
+        }
+    }
+    float mx = l[0];
+#pragma unroll
+    for (int n = 1; n < 9; ++n) mx = fmaxf(mx, l[n]);
+    float den = 0.f;
+#pragma unroll
+    for (int n = 0; n < 9; ++n) { l[n] = expf(l[n] - mx); den += l[n]; }
+    const float inv = 1.0f / den;
+    const int yc = Y / a.factor, xc = X / a.factor;
+    int yy[3], xx[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int v = yc + d - 1; yy[d] = v < 0 ? 0 : (v > a.hs - 1 ? a.hs - 1 : v);
+        v = xc + d - 1;     xx[d] = v < 0 ? 0 : (v > a.ws - 1 ? a.ws - 1 : v);
+    }
+    for (int m = 0; m < a.nmaps; ++m) {
+        const float* xm = a.x[m] + (long long)b * a.hs * a.ws;
+        float acc = 0.f;
+#pragma unroll
+        for (int n = 0; n < 9; ++n) acc += xm[(long long)yy[n / 3] * a.ws + xx[n % 3]] * (l[n] * inv);
+        a.out[m][gid] = acc * a.scale[m];
+    }
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
+                                    int logit_stride, int B, int hs, int ws, int factor, int logit_up2, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(x && out && logits && scale, "convex_upsample: null pointer");
+    S2M2_REQUIRE(nmaps >= 1 && nmaps <= 3, "convex_upsample: nmaps=%d (1..3)", nmaps);
+    S2M2_REQUIRE(B > 0 && hs > 0 && ws > 0 && factor >= 1, "convex_upsample: bad shape");
+    S2M2_REQUIRE(logit_stride >= 16 && logit_stride % 8 == 0, "convex_upsample: logit rows must be padded to >= 16 channels (stride %d)", logit_stride);
+    S2M2_REQUIRE(!logit_up2 || factor == 2, "convex_upsample: logit_up2 needs factor 2");
+    UpArgs a;
+    for (int m = 0; m < 3; ++m) {
+        a.x[m] = m < nmaps ? x[m] : nullptr;
+        a.out[m] = m < nmaps ? out[m] : nullptr;
+        a.scale[m] = m < nmaps ? scale[m] : 0.f;
+        if (m < nmaps) S2M2_REQUIRE(x[m] && out[m], "convex_upsample: map %d is null", m);
+    }
+    a.logits = logits; a.nmaps = nmaps; a.logit_stride = logit_stride; a.B = B; a.hs = hs; a.ws = ws; a.factor = factor;
+    a.logit_up2 = logit_up2;
+    const long long total = (long long)B * hs * factor * ws * factor;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == S2M2_F16) hipLaunchKernelGGL((convex_upsample_kernel<half_t>), grid, dim3(256), 0, st, a);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((convex_upsample_kernel<float>), grid, dim3(256), 0, st, a);
+    else return set_error("convex_upsample: unsupported dtype %d", dtype);
+    return check_launch("convex_upsample");
+}

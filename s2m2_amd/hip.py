@@ -22,6 +22,18 @@ _lib: Optional[ctypes.CDLL] = None
 
 _vp, _i, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
 
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_ADD, EPI_MUL, EPI_GRU, EPI_GATEMIX = 0, 1, 2, 3, 4
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of s2m2_conv_desc (include/s2m2_hip.h)"""
+    _fields_ = [("src", _vp * 4), ("src_c", _i * 4), ("src_stride", _i * 4), ("nsrc", _i), ("weight", _vp), ("bias", _vp),
+                ("out", _vp), ("out_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Cout", _i),
+                ("act", _i), ("epi", _i), ("aux0", _vp), ("aux1", _vp), ("aux0_stride", _i), ("aux1_stride", _i),
+                ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
 SIGNATURES = {
     "s2m2_version": (_i, []),
@@ -31,6 +43,11 @@ SIGNATURES = {
     "s2m2_sinkhorn_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
+    "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "s2m2_layernorm": (_i, [_vp, _vp, _ll, _i, _ll, _ll, _i, _vp]),
+    "s2m2_groupnorm_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
+    "s2m2_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, ctypes.c_float, _i, _vp]),
 }
 
 
@@ -106,3 +123,111 @@ def cv_lookup(cv: torch.Tensor, disp: torch.Tensor, radius: int = 4, channels_la
     _check(load().s2m2_cv_lookup(cv.data_ptr(), disp.float().data_ptr(), c1.data_ptr(), c2.data_ptr(), B, h, w, radius,
                                  _DT[cv.dtype], _DT[out_dtype], bs, ps, ts, _stream()), "s2m2_cv_lookup")
     return c1, c2
+
+
+def _nhwc(t: torch.Tensor):
+    """(N,H,W,C) view, channels contiguous, pixels dense with a common pixel stride (a channel slice of a wider tensor is fine)."""
+    if t.dim() != 4 or not t.is_cuda or t.stride(3) != 1:
+        raise ValueError(f"s2m2_amd.hip: expected an (N,H,W,C) device tensor with contiguous channels, got {tuple(t.shape)} {t.stride()}")
+    n, h, w, c = t.shape
+    ps = t.stride(2)
+    if (h > 1 and t.stride(1) != w * ps) or (n > 1 and t.stride(0) != h * w * ps):
+        raise ValueError(f"s2m2_amd.hip: pixels are not dense: shape {tuple(t.shape)} strides {t.stride()}")
+    return ps
+
+
+def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, act: int = ACT_NONE,
+           epi: int = EPI_NONE, aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0) -> torch.Tensor:
+    """Implicit-GEMM convolution / linear layer (s2m2_conv2d).  srcs: list of (N,H,W,Cs) tensors, concatenated along C;
+    weight: packed (Cout, KH*KW*sum(Cs)) (see s2m2_amd.pack); bias fp32 (Cout) or None.  Returns (N,H,W,Cout), or
+    (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    d = ConvDesc()
+    x0 = srcs[0]
+    n, h, w, _ = x0.shape
+    dt = x0.dtype
+    cin = 0
+    for i, t in enumerate(srcs):
+        if t.dtype != dt or tuple(t.shape[:3]) != (n, h, w):
+            raise ValueError("conv2d: sources must share dtype and (N,H,W)")
+        d.src[i] = t.data_ptr()
+        d.src_c[i] = t.shape[3]
+        d.src_stride[i] = _nhwc(t)
+        cin += t.shape[3]
+    if weight.dtype != dt or not weight.is_contiguous() or tuple(weight.shape) != (Cout, KH * KW * cin):
+        raise ValueError(f"conv2d: packed weight must be {(Cout, KH * KW * cin)} {dt}, got {tuple(weight.shape)} {weight.dtype}")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cout or not bias.is_contiguous()):
+        raise ValueError("conv2d: bias must be fp32 (Cout)")
+    if out is None:
+        out = torch.empty((n, 2 * h, 2 * w, shuffle2) if shuffle2 else (n, h, w, Cout), device=x0.device, dtype=dt)
+    exp_shape = (n, 2 * h, 2 * w, shuffle2) if shuffle2 else (n, h, w, Cout)
+    if tuple(out.shape) != exp_shape or out.dtype != dt:
+        raise ValueError(f"conv2d: out must be {exp_shape} {dt}, got {tuple(out.shape)} {out.dtype}")
+    d.nsrc = len(srcs)
+    d.weight = weight.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.out = out.data_ptr()
+    d.out_stride = _nhwc(out)
+    d.N, d.H, d.W, d.KH, d.KW, d.Cout = n, h, w, KH, KW, Cout
+    d.act, d.epi = act, epi
+    for name, a in (("aux0", aux0), ("aux1", aux1)):
+        if a is not None:
+            if a.dtype != dt or tuple(a.shape) != (n, h, w, Cout):
+                raise ValueError(f"conv2d: {name} must be {(n, h, w, Cout)} {dt}")
+            setattr(d, name, a.data_ptr())
+            setattr(d, name + "_stride", _nhwc(a))
+    d.out_scale = out_scale
+    d.shuffle2 = shuffle2
+    d.tile = tile
+    d.dtype = _DT[dt]
+    _check(load().s2m2_conv2d(ctypes.byref(d), _stream()), "s2m2_conv2d")
+    return out
+
+
+def layernorm(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """LayerNorm without affine over the last axis of a (..., C) tensor with contiguous channels and a uniform row stride."""
+    C = x.shape[-1]
+    if x.stride(-1) != 1:
+        raise ValueError("layernorm: channels must be contiguous")
+    rows = x.numel() // C
+    xs = x.stride(-2) if x.dim() > 1 else C
+    for d in range(x.dim() - 2):
+        if x.shape[d] > 1 and x.stride(d) != x.stride(d + 1) * x.shape[d + 1]:
+            raise ValueError("layernorm: rows must have a uniform stride")
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    _check(load().s2m2_layernorm(x.data_ptr(), out.data_ptr(), rows, C, xs, C, _DT[x.dtype], _stream()), "s2m2_layernorm")
+    return out
+
+
+def groupnorm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """nn.GroupNorm on a contiguous (N,H,W,C) tensor; gamma/beta fp32."""
+    _dev(x, gamma, beta)
+    n, h, w, c = x.shape
+    ws = torch.empty(load().s2m2_groupnorm_workspace_bytes(n, groups) // 8, device=x.device, dtype=torch.float64)
+    out = torch.empty_like(x)
+    _check(load().s2m2_groupnorm_nhwc(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), n, h * w, c,
+                                      groups, eps, _DT[x.dtype], _stream()), "s2m2_groupnorm_nhwc")
+    return out
+
+
+def convex_upsample(maps, logits: torch.Tensor, factor: int, scales=None, logit_up2: bool = False):
+    """maps: list of (B,1,hs,ws) or (B,hs,ws) fp32 tensors; logits (B,Ho,Wo,>=16) NHWC (9 used).  -> list of (B,1,Ho,Wo) fp32."""
+    B, hs, ws = maps[0].shape[0], maps[0].shape[-2], maps[0].shape[-1]
+    n = len(maps)
+    maps = [m.float().contiguous() for m in maps]
+    _dev(*maps)
+    ls = _nhwc(logits)
+    Ho, Wo = hs * factor, ws * factor
+    exp_l = (B, hs, ws) if logit_up2 else (B, Ho, Wo)
+    if tuple(logits.shape[:3]) != exp_l:
+        raise ValueError(f"convex_upsample: logits must be {exp_l + ('>=16',)}, got {tuple(logits.shape)}")
+    outs = [torch.empty((B, 1, Ho, Wo), device=logits.device, dtype=torch.float32) for _ in range(n)]
+    xp = (_vp * n)(*[m.data_ptr() for m in maps])
+    op = (_vp * n)(*[o.data_ptr() for o in outs])
+    sc = (ctypes.c_float * n)(*[float(v) for v in (scales or [1.0] * n)])
+    _check(load().s2m2_convex_upsample(xp, op, sc, n, logits.data_ptr(), ls, B, hs, ws, factor, int(logit_up2),
+                                       _DT[logits.dtype], _stream()), "s2m2_convex_upsample")
+    return outs

@@ -1,0 +1,155 @@
+"""GPU parity of K5 (implicit-GEMM conv / linear with fused concat + epilogues, s2m2_conv2d through the C ABI) against plain
+PyTorch fp32 references of the same ops (F.conv2d / F.conv_transpose2d / F.linear + the elementwise tail), on the operand
+values the kernel sees (fp16 mode: operands rounded to fp16 first, fp32 accumulate).
+
+Tolerances: fp32 mode -- exact-fp32 MFMA chain vs the vendor's summation order: 2e-5 * sqrt(K) * scale absolute.
+fp16 mode -- output rounded to fp16 (rel 2^-11) plus accumulate-order noise: 2e-3 * scale."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from s2m2_amd import pack
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from s2m2_amd import hip as h
+    h.load()
+    return h
+
+
+def _act(x, a):
+    return [lambda t: t, lambda t: F.gelu(t), F.relu, torch.sigmoid, torch.tanh][a](x)
+
+
+def _ref_conv(srcs, w, b, act, scale=1.0):
+    x = torch.cat([s.float() for s in srcs], -1).permute(0, 3, 1, 2)
+    kh, kw = w.shape[2:]
+    y = F.conv2d(x, w.float(), None if b is None else b.float(), padding=(kh // 2, kw // 2))
+    return (_act(y, act) * scale).permute(0, 2, 3, 1)
+
+
+def _tol(dtype, K, scale):
+    return (2e-5 * math.sqrt(K) if dtype == torch.float32 else 2.5e-3) * scale
+
+
+CASES = [
+    # N, H, W, [src channels (real)], Cout, KH, KW, act, tile
+    (1, 17, 23, [128], 128, 3, 3, 1, 0),
+    (2, 16, 24, [128], 128, 1, 1, 0, 1),
+    (1, 33, 19, [128, 128], 128, 3, 1, 3, 2),
+    (1, 19, 33, [128, 128], 128, 1, 3, 4, 0),
+    (1, 24, 40, [96, 64, 64, 160], 256, 1, 1, 1, 0),
+    (1, 20, 28, [1], 96, 3, 3, 1, 0),
+    (1, 20, 28, [9], 96, 1, 1, 1, 4),
+    (1, 20, 28, [2, 128], 128, 3, 3, 1, 0),
+    (1, 40, 56, [128], 1, 3, 3, 0, 0),
+    (1, 40, 56, [48], 9, 1, 1, 0, 3),
+    (1, 12, 20, [256], 256, 3, 3, 2, 0),
+    (1, 9, 13, [512], 512, 1, 1, 1, 0),
+    (3, 8, 8, [64], 32, 1, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", CASES)
+def test_conv_vs_torch(hip, case, dtype):
+    N, H, W, cs, Cout, KH, KW, act, tile = case
+    g = torch.Generator(device="cuda").manual_seed(CASES.index(case))
+    srcs_real = [torch.randn(N, H, W, c, device="cuda", generator=g).to(dtype) for c in cs]
+    cin = sum(cs)
+    w = (torch.randn(Cout, cin, KH, KW, device="cuda", generator=g) / math.sqrt(cin * KH * KW)).to(dtype)
+    b = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    ref = _ref_conv(srcs_real, w, b, act, 0.5)
+    srcs = []
+    for t in srcs_real:                                    # zero-pad every source to a multiple of 8 channels
+        cp = pack.pad8(t.shape[-1])
+        buf = torch.zeros(N, H, W, cp, device="cuda", dtype=dtype)
+        buf[..., :t.shape[-1]] = t
+        srcs.append(buf)
+    wp = pack.pack_conv(w, dtype, [(c, pack.pad8(c)) for c in cs])
+    bp = pack.pack_bias(b, Cout)
+    out = hip.conv2d(srcs, wp, bp, KH, KW, wp.shape[0], act=act, out_scale=0.5, tile=tile)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (N, H, W, pack.pad8(Cout))
+    err = float((out[..., :Cout].float() - ref).abs().max())
+    assert err < _tol(dtype, cin * KH * KW, max(1.0, float(ref.abs().max()))), err
+    if pack.pad8(Cout) > Cout:                              # padded output channels: act(0) * scale
+        pad = out[..., Cout:].float()
+        assert float((pad - _act(torch.zeros(()), act) * 0.5).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("epi", [1, 2, 3, 4])
+def test_conv_epilogues(hip, dtype, epi):
+    N, H, W, C = 1, 18, 26, 128
+    g = torch.Generator(device="cuda").manual_seed(epi)
+    x = torch.randn(N, H, W, 2 * C, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(C, 2 * C, 3, 3, device="cuda", generator=g) / math.sqrt(18 * C)).to(dtype)
+    a0 = torch.rand(N, H, W, C, device="cuda", generator=g).to(dtype)
+    a1 = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
+    act = {1: 0, 2: 3, 3: 4, 4: 3}[epi]
+    v = _ref_conv([x], w, None, act)
+    v = v.to(dtype).float()                                  # the kernel stages the activated value in the I/O dtype
+    if epi == 1:
+        ref = v + a0.float()
+    elif epi == 2:
+        ref = v * a0.float()
+    elif epi == 3:
+        ref = (1 - a0.float()) * a1.float() + a0.float() * v
+    else:
+        gt = v.clamp(0.01, 0.99)
+        ref = gt * a0.float() + (1 - gt) * a1.float()
+    # sources given as two channel-slice views of one wider tensor (exercises pixel strides)
+    out = hip.conv2d([x[..., :C], x[..., C:]], pack.pack_conv(w, dtype), None, 3, 3, C, act=act, epi=epi, aux0=a0, aux1=a1)
+    err = float((out.float() - ref).abs().max())
+    assert err < _tol(dtype, 18 * C, 4.0), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("cout", [64, 9, 16])
+def test_convT_2x2_stride2(hip, dtype, cout):
+    N, H, W, C = 2, 13, 21, 128
+    g = torch.Generator(device="cuda").manual_seed(cout)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(C, cout, 2, 2, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    ref = F.conv_transpose2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=2).permute(0, 2, 3, 1)
+    wp, cp = pack.pack_convT_2x2s2(w, dtype)
+    out = hip.conv2d([x], wp, pack.pack_bias_shuffle(b, cout), 1, 1, 4 * cp, shuffle2=cp)
+    assert tuple(out.shape) == (N, 2 * H, 2 * W, cp)
+    err = float((out[..., :cout].float() - ref).abs().max())
+    assert err < _tol(dtype, C, 4.0), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_convT_3x3_stride1_and_output_slice(hip, dtype):
+    N, H, W = 1, 22, 30
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, H, W, 3, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(3, 16, 3, 3, device="cuda", generator=g) / 5).to(dtype)
+    b = torch.randn(16, device="cuda", generator=g) * 0.1
+    ref = F.relu(F.conv_transpose2d(x.float().permute(0, 3, 1, 2), w.float(), b, padding=1)).permute(0, 2, 3, 1)
+    xp = torch.zeros(N, H, W, 8, device="cuda", dtype=dtype)
+    xp[..., :3] = x
+    wide = torch.full((N, H, W, 48), 7.0, device="cuda", dtype=dtype)          # write into channels 16..31 of a wider tensor
+    hip.conv2d([xp], pack.pack_conv(pack.convT_s1_as_conv(w), dtype, [(3, 8)]), pack.pack_bias(b, 16), 3, 3, 16, act=2,
+               out=wide[..., 16:32])
+    assert float((wide[..., 16:32].float() - ref).abs().max()) < _tol(dtype, 27, 4.0)
+    assert float((wide[..., :16].float() - 7).abs().max()) == 0 and float((wide[..., 32:].float() - 7).abs().max()) == 0
+
+
+def test_linear_tokens_big(hip):
+    """nn.Linear on (tokens, C) = 1x1 conv on a (1, 1, tokens, C) image; BASELINE-sized token count, fp16."""
+    T, C = 2 * 256 * 304, 128
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(1, 1, T, C, device="cuda", generator=g).half()
+    w = (torch.randn(3 * C, C, device="cuda", generator=g) / math.sqrt(C)).half()
+    b = torch.randn(3 * C, device="cuda", generator=g)
+    out = hip.conv2d([x], pack.pack_conv(w, torch.float16), pack.pack_bias(b, 3 * C), 1, 1, 3 * C)
+    ref = F.linear(x.float(), w.float(), b)
+    assert float((out.float() - ref).abs().max()) < 2.5e-3 * float(ref.abs().max())

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Time s2m2_conv2d against PyTorch-ROCm (MIOpen / hipBLASLt) on the hot-path conv shapes (fp16, channels-last).
+    python tools/convbench.py [--iters 30]"""
+import argparse
+import math
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from s2m2_amd import hip, pack  # noqa: E402
+from tools.kbench import timeit  # noqa: E402
+
+SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
+    ("1/4 3x3 128->128", 1, 256, 304, 128, 128, 3, 3),
+    ("1/4 3x3 128->128 x2", 2, 256, 304, 128, 128, 3, 3),
+    ("1/4 1x1 128->128", 1, 256, 304, 128, 128, 1, 1),
+    ("1/4 1x1 256->256", 1, 256, 304, 256, 256, 1, 1),
+    ("1/4 1x1 384->256", 1, 256, 304, 384, 256, 1, 1),
+    ("1/4 3x3 256->128", 1, 256, 304, 256, 128, 3, 3),
+    ("1/4 3x1 256->128", 1, 256, 304, 256, 128, 3, 1),
+    ("1/4 lin 128->384 x2", 2, 256, 304, 128, 384, 1, 1),
+    ("1/8 3x3 128->128", 1, 128, 152, 128, 128, 3, 3),
+    ("1/16 3x3 256->256", 1, 64, 76, 256, 256, 3, 3),
+    ("1/32 1x1 256->256", 1, 32, 38, 256, 256, 1, 1),
+    ("1/2 3x3 128->128", 1, 512, 608, 128, 128, 3, 3),
+    ("1/2 3x3 128->64", 1, 512, 608, 128, 64, 3, 3),
+    ("1/1 3x3 48->48", 1, 1024, 1216, 48, 48, 3, 3),
+    ("1/4 3x3 128->8", 1, 256, 304, 128, 8, 3, 3),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=30)
+    a = ap.parse_args()
+    for name, N, H, W, ci, co, kh, kw in SHAPES:
+        x = torch.randn(N, H, W, ci, device="cuda").half()
+        w = (torch.randn(co, ci, kh, kw, device="cuda") / math.sqrt(ci * kh * kw)).half()
+        b = torch.randn(co, device="cuda")
+        wp, bp = pack.pack_conv(w, torch.float16), pack.pack_bias(b, co)
+        xn = x.permute(0, 3, 1, 2)
+        wcl = w.contiguous(memory_format=torch.channels_last)
+        bh = b.half()
+        fl = 2.0 * N * H * W * ci * co * kh * kw
+        t_ref = timeit(lambda: F.gelu(F.conv2d(xn, wcl, bh, padding=(kh // 2, kw // 2))), a.iters)
+        line = f"{name:24s} torch conv+gelu {t_ref:8.1f} us ({fl / t_ref / 1e6:6.1f} TF/s) |"
+        for tile in (0, 1, 2, 4):
+            if tile == 1 and co < 128:
+                continue
+            t = timeit(lambda: hip.conv2d([x], wp, bp, kh, kw, wp.shape[0], act=hip.ACT_GELU, tile=tile), a.iters)
+            line += f" t{tile} {t:8.1f} us ({fl / t / 1e6:6.1f})"
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
