@@ -82,7 +82,7 @@ int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2,
  *   PyTorch launches around them: torch.cat of the inputs, bias, GELU/ReLU/sigmoid/tanh, residual add, the ConvGRU gate
  *   arithmetic (refinenet.py:24-34), the FeatureFusion gate mix (feature_fusion.py:24-31).
  *
- *   out[n,y,x,co] = epi( out_scale * act( bias[co] + sum_{ky,kx,ci} in[n, y+ky-KH/2, x+kx-KW/2, ci] * weight[co,ky,kx,ci] ) )
+ *   out[n,y,x,co] = epi( out_scale * act( bias[co] + sum_{ky,kx,ci} in[n, y*stride+ky-KH/2, x*stride+kx-KW/2, ci] * weight[co,ky,kx,ci] ) )
  *   in  = channel concatenation of src[0..nsrc) (NHWC, src_c[s] channels each, pixel stride src_stride[s]; zero padding)
  *   weight  packed (Cout, KH*KW, Cin), Cin = sum(src_c), same dtype as the activations; bias fp32 (Cout) or NULL
  *   out NHWC with pixel stride out_stride (write into a channel slice of a wider tensor by offsetting `out`)
@@ -113,6 +113,7 @@ typedef struct s2m2_conv_desc {
     int shuffle2;
     int tile;
     int dtype;
+    int stride;             /* 1 or 2: out[y,x] is centred on in[y*stride, x*stride]; output (N, ceil(H/stride), ceil(W/stride), Cout) */
 } s2m2_conv_desc;
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
 
@@ -141,6 +142,29 @@ int s2m2_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float*
  */
 int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
                          int logit_stride, int B, int hs, int ws, int factor, int logit_up2, int dtype, void* stream);
+
+/*
+ * [A2,A3] multi-head attention softmax(Q K^T * scale) V, flash style (no score matrix in memory).  Replaces
+ *   F.scaled_dot_product_attention and the explicit attention + positional-encoding einsums (attentions.py:42-50, :83-91).
+ *   q, k, v, out: token rows; element (batch b, token n, head hd, e) at base + (b*N + n)*stride + hd*D + e  (so the fused
+ *   QKV projection is read in place and the output is (tokens, heads*D)).  D multiple of 8, <= 256 (<= 128 with PE).
+ *   swap_halves = 1: keys/values of batch b come from batch (b + nb/2) % nb (symmetric cross attention, CrossAttn).
+ *   pe_x != NULL selects SelfAttn(use_pe=True): tokens form a grid_h x grid_w grid (row major), pe_x (2*grid_w-1, 16) and
+ *   pe_y (2*grid_h-1, 16) fp32 are the separable sinc tables of get_pe (utils.py:32-60) indexed by xq-xk+grid_w-1 /
+ *   yq-yk+grid_h-1, and pe_out (tokens, heads*32) receives sum_k P[q,k] * 0.5*[pe_x[..], pe_y[..]]  (the input of pe_proj).
+ */
+int s2m2_attention(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
+                   long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
+                   int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
+                   int grid_w, int grid_h, int dtype, void* stream);
+
+/*
+ * [A2,A3] 2x resampling of an NHWC activation: mode 0 = nn.AvgPool2d(2) (unet.py:25-30, stacked_MRT.py:22-27), mode 1 =
+ *   bilinear x2 with align_corners=False (unet.py:32-37, stacked_MRT.py:29-34).  x (N,H,W,C) -> y (N,H/2,W/2,C) or (N,2H,2W,C),
+ *   pixel strides x_stride / y_stride elements; fp32 arithmetic.
+ */
+int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int C, long long x_stride, long long y_stride, int mode,
+                    int dtype, void* stream);
 
 #ifdef __cplusplus
 }

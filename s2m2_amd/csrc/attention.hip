@@ -1,0 +1,397 @@
+// K4 -- flash-style multi-head attention on MFMA: softmax(Q K^T * scale) V without materialising the score matrix.
+//
+// Replaces every F.scaled_dot_product_attention call and the explicit attention + positional-encoding einsums of the
+// reference (attentions.py:42-50 SelfAttn, :83-91 CrossAttn; used by the 1-D epipolar blocks at 1/4, 1/8, 1/16 and the
+// 2-D global blocks at 1/32 of stacked_MRT.py / unet.py).
+//
+// Layout: q, k, v, out are token rows (channels contiguous); element (batch b, token n, head hd, e) lives at
+//   base + (b*N + n)*row_stride + hd*D + e, so the kernel reads the fused QKV projection in place and writes (tokens, C).
+// Cross attention ("swap" = 1): keys/values of batch b come from batch (b + nb/2) % nb -- the symmetric left<->right
+// attention of CrossAttn (shared weights, both directions in one launch).
+//
+//   block = NW waves = NW consecutive 32-query tiles of one (batch, head); K and V stream through LDS in tiles of 32 keys,
+//           loaded by all waves (global -> registers before the MFMAs of the current tile, registers -> LDS after them).
+//   S^T   = K_tile . Q^T  (v_mfma 32x32: a lane owns ONE query column and 16 of the 32 keys; the other 16 sit in lane^32),
+//           so the online-softmax row maximum / sum are in-lane reductions plus one cross-half exchange.
+//   O^T  += V_tile^T . P^T: the probabilities go straight from the S accumulators into the B operand (the k-slot -> key
+//           map of a register octet is {16s+4hi+0..3, 16s+8+4hi+0..3}); V is staged TRANSPOSED in LDS (Vt[d][key]) so the
+//           matching A operand is two 4-element reads per lane.  No permutes, no P round trip through LDS.
+//   PE    = (template) contextual relative positional encoding of SelfAttn(use_pe): pe_sum[q,:] = sum_k P[q,k] pe[q,k,:]
+//           with pe[q,k] = 0.5*[px[xq-xk+w-1], py[yq-yk+h-1]] evaluated from the two separable sinc tables (utils.py:32-60)
+//           kept in LDS -- the (N,N,32) tensor of the reference (95 MB at 1216x1024, 1.5 GB for XL) is never built.
+// fp16: v_mfma_f32_32x32x16_f16 with fp32 softmax/accumulators;  fp32 (parity mode): exact v_mfma_f32_32x32x2_f32.
+#include "common.h"
+
+namespace s2m2 {
+
+struct AttnArgs {
+    const void* q; const void* k; const void* v; void* out;
+    long long sq, sk, sv, so;           // row strides (elements)
+    int nb, heads, Nq, Nk, D, swap;
+    float scale;
+    // positional encoding (PE variant only)
+    const float* px; const float* py; void* pe_out; long long spe; int gw, gh;
+};
+
+template <typename T, int DP_, bool PE_>
+struct AttnCfg {
+    static constexpr int DP = DP_;                       // head dim rounded up to a multiple of 16
+    static constexpr bool PE = PE_;
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int KSTEPS = DP / 16;
+    static constexpr int ND = (DP + 31) / 32;            // 32-wide output d tiles
+    static constexpr int KRS = DP + VEC;                 // K tile row stride (elements)
+    static constexpr int VRS = 32 + 4;                   // Vt row stride (elements): 32 keys + pad
+    static constexpr int VROWS = ND * 32;
+    static constexpr size_t K_BYTES = (size_t)32 * KRS * sizeof(T);
+    static constexpr size_t V_BYTES = (size_t)VROWS * VRS * sizeof(T);
+    static constexpr int KP = DP / VEC;                  // 16-byte pieces per K/V row
+    static constexpr int MAXW = (DP * sizeof(T) >= 384) ? 4 : 8;   // waves per block: 512 registers per lane for the wide heads
+};
+
+template <typename T> struct Quad;                                     // 4 consecutive elements
+template <> struct alignas(8) Quad<half_t> { half_t v[4]; };
+template <> struct alignas(16) Quad<float> { float v[4]; };
+
+template <typename T> __device__ __forceinline__ void make_pfrag(Frag<T>& f, const float* p);
+template <> __device__ __forceinline__ void make_pfrag<half_t>(Frag<half_t>& f, const float* p) {
+    half8_t h = {(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3], (half_t)p[4], (half_t)p[5], (half_t)p[6], (half_t)p[7]};
+    f.v = h;
+}
+template <> __device__ __forceinline__ void make_pfrag<float>(Frag<float>& f, const float* p) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = p[e];
+}
+template <typename T> __device__ __forceinline__ void load_vfrag(Frag<T>& f, const T* lo, const T* hi4);
+template <> __device__ __forceinline__ void load_vfrag<half_t>(Frag<half_t>& f, const half_t* a, const half_t* b) {
+    const half4_t x = *reinterpret_cast<const half4_t*>(a);
+    const half4_t y = *reinterpret_cast<const half4_t*>(b);
+    half8_t h = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    f.v = h;
+}
+template <> __device__ __forceinline__ void load_vfrag<float>(Frag<float>& f, const float* a, const float* b) {
+    const float4_t x = *reinterpret_cast<const float4_t*>(a);
+    const float4_t y = *reinterpret_cast<const float4_t*>(b);
+    f.v[0] = x[0]; f.v[1] = x[1]; f.v[2] = x[2]; f.v[3] = x[3];
+    f.v[4] = y[0]; f.v[5] = y[1]; f.v[6] = y[2]; f.v[7] = y[3];
+}
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
+    constexpr int VEC = CFG::VEC, KRS = CFG::KRS, VRS = CFG::VRS, ND = CFG::ND, KP = CFG::KP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ks = reinterpret_cast<T*>(smem);                                   // [32][KRS]
+    T* Vt = reinterpret_cast<T*>(smem + CFG::K_BYTES);                    // [VROWS][VRS]
+    float* pxs = reinterpret_cast<float*>(smem + CFG::K_BYTES + CFG::V_BYTES);   // PE tables (PE only)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nthr = blockDim.x;
+    const int NW = nthr >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y;
+    const int b = bh / a.heads, hd = bh - b * a.heads;
+    const int bkv = a.swap ? (b + a.nb / 2) % a.nb : b;
+    const int q0 = (blockIdx.x * NW + wv) * 32;
+    const bool wave_active = q0 < a.Nq;
+
+    const T* qb = static_cast<const T*>(a.q) + (long long)b * a.Nq * a.sq + hd * a.D;
+    const T* kb = static_cast<const T*>(a.k) + (long long)bkv * a.Nk * a.sk + hd * a.D;
+    const T* vb = static_cast<const T*>(a.v) + (long long)bkv * a.Nk * a.sv + hd * a.D;
+
+    float* pys = nullptr;
+    int Lx = 0;
+    if constexpr (CFG::PE) {
+        Lx = 2 * a.gw - 1;
+        const int Ly = 2 * a.gh - 1;
+        pys = pxs + Lx * 16;
+        for (int i = tid; i < Lx * 16; i += nthr) pxs[i] = a.px[i];
+        for (int i = tid; i < Ly * 16; i += nthr) pys[i] = a.py[i];
+    }
+
+    // ---- Q fragments of this wave (B operand: lane = query, 8 consecutive d per k16 step), zero beyond D
+    Frag<T> qf[CFG::KSTEPS];
+    {
+        int qi = q0 + l31;
+        qi = qi < a.Nq ? qi : a.Nq - 1;
+        const T* qp = qb + (long long)qi * a.sq;
+#pragma unroll
+        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+            const int d0 = kk * 16 + hi * 8;
+            if (d0 < a.D) load_frag(qf[kk], qp + d0);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (sizeof(T) == 2) qf[kk].v[e] = (half_t)0.f; else qf[kk].v[e] = 0.f;
+                }
+            }
+        }
+    }
+
+    // ---- staging assignment
+    // K tile: 32 rows x KP pieces.   V tile: 8 key groups (4 keys) x KP pieces -> transposed quads.
+    constexpr int K_TASKS = 32 * KP, V_TASKS = 8 * KP;
+    constexpr int K_IT_MAX = (K_TASKS + 255) / 256, V_IT_MAX = (V_TASKS + 255) / 256;   // blocks have >= 4 waves (launch_attn)
+    Vec16<T> rk[K_IT_MAX];
+    Vec16<T> rv[V_IT_MAX][4];
+    auto zero16 = []() { Vec16<T> z;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { if constexpr (sizeof(T) == 2) z.v[e] = (half_t)0.f; else z.v[e] = 0.f; }
+        return z; };
+    auto fetch = [&](int kv0) {
+#pragma unroll
+        for (int it = 0; it < K_IT_MAX; ++it) {
+            const int t = tid + it * nthr;
+            if (t < K_TASKS) {
+                const int r = t / KP, pc = t - r * KP;
+                const int kv = kv0 + r;
+                rk[it] = (kv < a.Nk && pc * VEC < a.D) ? *reinterpret_cast<const Vec16<T>*>(kb + (long long)kv * a.sk + pc * VEC) : zero16();
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < V_IT_MAX; ++it) {
+            const int t = tid + it * nthr;
+            if (t < V_TASKS) {
+                const int kg = t / KP, pc = t - kg * KP;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kv = kv0 + 4 * kg + j;
+                    rv[it][j] = (kv < a.Nk && pc * VEC < a.D) ? *reinterpret_cast<const Vec16<T>*>(vb + (long long)kv * a.sv + pc * VEC) : zero16();
+                }
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int it = 0; it < K_IT_MAX; ++it) {
+            const int t = tid + it * nthr;
+            if (t < K_TASKS) {
+                const int r = t / KP, pc = t - r * KP;
+                *reinterpret_cast<Vec16<T>*>(Ks + (size_t)r * KRS + pc * VEC) = rk[it];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < V_IT_MAX; ++it) {
+            const int t = tid + it * nthr;
+            if (t < V_TASKS) {
+                const int kg = t / KP, pc = t - kg * KP;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    Quad<T> qd;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) qd.v[j] = rv[it][j].v[e];
+                    *reinterpret_cast<Quad<T>*>(Vt + (size_t)(pc * VEC + e) * VRS + 4 * kg) = qd;
+                }
+            }
+        }
+    };
+
+    float16_t oacc[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float pe_acc[CFG::PE ? 32 : 1];
+    if constexpr (CFG::PE) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) pe_acc[c] = 0.f;
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    // query grid coordinates (PE)
+    int qi_pe = q0 + l31;
+    qi_pe = qi_pe < a.Nq ? qi_pe : a.Nq - 1;
+    const int yq = CFG::PE ? qi_pe / a.gw : 0, xq = CFG::PE ? qi_pe - yq * a.gw : 0;
+
+    const int ntile = (a.Nk + 31) / 32;
+    fetch(0);
+    for (int t = 0; t < ntile; ++t) {
+        __syncthreads();                                          // previous tile fully consumed (also covers the PE table fill)
+        stash();
+        __syncthreads();
+        if (t + 1 < ntile) fetch((t + 1) * 32);                   // in flight under this tile's MFMAs
+        if (wave_active) {
+            // ---- S^T = K . Q^T
+            float16_t sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const T* kp = Ks + (size_t)l31 * KRS + hi * 8;
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                Frag<T> kf;
+                load_frag(kf, kp + kk * 16);
+                mma32(sacc, kf, qf[kk]);
+            }
+            // ---- online softmax (lane: one query, keys crow(r, hi) of this tile)
+            const int kv0 = t * 32;
+            float p[16];
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + acc_row(r, lane);
+                p[r] = kv < a.Nk ? sacc[r] * a.scale : -INFINITY;
+                mloc = fmaxf(mloc, p[r]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);               // finite: every tile has at least one valid key
+            const float alpha = expf(m_run - m_new);              // exp(-inf) = 0 on the first tile
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - m_new); lsum += p[r]; }
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            // ---- O^T += Vt . P^T
+            Frag<T> pf[2];
+            make_pfrag<T>(pf[0], p);
+            make_pfrag<T>(pf[1], p + 8);
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt) {
+                const T* vp = Vt + (size_t)(dt * 32 + l31) * VRS + 4 * hi;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Frag<T> vf;
+                    load_vfrag<T>(vf, vp + 16 * s, vp + 16 * s + 8);
+                    mma32(oacc[dt], vf, pf[s]);
+                }
+            }
+            if constexpr (CFG::PE) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) pe_acc[c] *= alpha;
+                if constexpr (sizeof(T) == 2) {                   // the reference multiplies fp16 probabilities (autocast einsum)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) p[r] = (float)(half_t)p[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + acc_row(r, lane);
+                    if (kv < a.Nk) {
+                        const int yk = kv / a.gw, xk = kv - yk * a.gw;
+                        const float4_t* tx = reinterpret_cast<const float4_t*>(pxs + (xq - xk + a.gw - 1) * 16);
+                        const float4_t* ty = reinterpret_cast<const float4_t*>(pys + (yq - yk + a.gh - 1) * 16);
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const float4_t u = tx[c4], w = ty[c4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                pe_acc[c4 * 4 + e] = __builtin_fmaf(p[r], u[e], pe_acc[c4 * 4 + e]);
+                                pe_acc[16 + c4 * 4 + e] = __builtin_fmaf(p[r], w[e], pe_acc[16 + c4 * 4 + e]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (!wave_active) return;
+    // ---- normalise and store: lane owns query q0 + l31, d = 32*dt + 8*g + 4*hi + 0..3
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + l31;
+    if constexpr (CFG::PE) {
+        // both halves hold partial sums over their 16 keys per tile
+#pragma unroll
+        for (int c = 0; c < 32; ++c) pe_acc[c] += __shfl_xor(pe_acc[c], 32, 64);
+    }
+    if (qi < a.Nq) {
+        T* op = static_cast<T*>(a.out) + ((long long)b * a.Nq + qi) * a.so + hd * a.D;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = dt * 32 + 8 * g + 4 * hi;
+                if (d < a.D) {
+                    Quad<T> qd;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qd.v[e] = from_f32<T>(oacc[dt][4 * g + e] * inv);
+                    *reinterpret_cast<Quad<T>*>(op + d) = qd;
+                }
+            }
+        if constexpr (CFG::PE) {
+            // pe_sum (b, q, head, 32) in T; the 0.5 of get_pe is applied here; half hi writes channels 16*hi .. 16*hi+15
+            T* pp = static_cast<T*>(a.pe_out) + ((long long)b * a.Nq + qi) * a.spe + hd * 32 + 16 * hi;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                Quad<T> qd;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float val = hi ? pe_acc[16 + c4 * 4 + e] : pe_acc[c4 * 4 + e];
+                    qd.v[e] = from_f32<T>(0.5f * val * inv);
+                }
+                *reinterpret_cast<Quad<T>*>(pp + c4 * 4) = qd;
+            }
+        }
+    }
+}
+
+template <typename T, int DP, bool PE>
+static int launch_attn(const AttnArgs& a, hipStream_t st) {
+    using CFG = AttnCfg<T, DP, PE>;
+    auto kern = attention_kernel<CFG, T>;
+    size_t lds = CFG::K_BYTES + CFG::V_BYTES;
+    if (PE) lds += (size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 * sizeof(float);
+    if (lds > 160 * 1024) return set_error("attention: %zu bytes of LDS needed", lds);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return set_error("attention: cannot reserve %zu bytes of LDS", lds);
+        attr_bytes = lds;
+    }
+    const int ntq = (a.Nq + 31) / 32;
+    const int nblk = (ntq + CFG::MAXW - 1) / CFG::MAXW;
+    int nw = (ntq + nblk - 1) / nblk;                              // <= 8 waves, minimal idle tail
+    nw = nw < 4 ? 4 : nw;                                          // >= 4 waves: the staging loops assume >= 256 threads
+    hipLaunchKernelGGL(kern, dim3(nblk, a.nb * a.heads), dim3(nw * 64), lds, st, a);
+    return check_launch("attention");
+}
+
+template <typename T, bool PE>
+static int dispatch_attn(const AttnArgs& a, hipStream_t st) {
+    const int dp = (a.D + 15) / 16 * 16;
+    switch (dp) {
+        case 16: return launch_attn<T, 16, PE>(a, st);
+        case 32: return launch_attn<T, 32, PE>(a, st);
+        case 48: return launch_attn<T, 48, PE>(a, st);
+        case 64: return launch_attn<T, 64, PE>(a, st);
+        case 96: return launch_attn<T, 96, PE>(a, st);
+        case 128: return launch_attn<T, 128, PE>(a, st);
+        default: break;
+    }
+    if (!PE) {
+        switch (dp) {
+            case 192: return launch_attn<T, 192, false>(a, st);
+            case 256: return launch_attn<T, 256, false>(a, st);
+            default: break;
+        }
+    }
+    return set_error("attention: unsupported head dim %d", a.D);
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_attention(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
+                              long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
+                              int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
+                              int grid_w, int grid_h, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(q && k && v && out, "attention: null pointer");
+    S2M2_REQUIRE(nb > 0 && heads > 0 && Nq > 0 && Nk > 0 && D > 0 && D % 8 == 0, "attention: bad shape nb=%d heads=%d Nq=%d Nk=%d D=%d", nb, heads, Nq, Nk, D);
+    S2M2_REQUIRE(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && out_stride % 4 == 0, "attention: strides must be multiples of 8");
+    S2M2_REQUIRE(!swap_halves || (nb % 2 == 0 && Nq == Nk), "attention: swap_halves needs an even batch and Nq == Nk");
+    const bool pe = pe_x != nullptr;
+    if (pe) {
+        S2M2_REQUIRE(pe_y && pe_out && grid_w > 0 && grid_h > 0 && grid_w * grid_h == Nq && Nq == Nk && pe_stride % 4 == 0,
+                     "attention: PE variant needs py, pe_out and a grid with w*h == Nq == Nk");
+    }
+    AttnArgs a;
+    a.q = q; a.k = k; a.v = v; a.out = out; a.sq = q_stride; a.sk = k_stride; a.sv = v_stride; a.so = out_stride;
+    a.nb = nb; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.swap = swap_halves; a.scale = scale;
+    a.px = pe_x; a.py = pe_y; a.pe_out = pe_out; a.spe = pe_stride; a.gw = grid_w; a.gh = grid_h;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == S2M2_F16) return pe ? dispatch_attn<half_t, true>(a, st) : dispatch_attn<half_t, false>(a, st);
+    if (dtype == S2M2_F32) return pe ? dispatch_attn<float, true>(a, st) : dispatch_attn<float, false>(a, st);
+    return set_error("attention: unsupported dtype %d", dtype);
+}

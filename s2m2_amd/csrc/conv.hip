@@ -30,6 +30,7 @@ struct ConvArgs {
     void* out;
     int out_stride;
     int N, H, W, KH, KW, Cin, Cout;
+    int stride, Ho, Wo;
     int act, epi;
     const void* aux0;
     const void* aux1;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv % CFG::WGM, wn = wv / CFG::WGM;
-    const long long M = (long long)p.N * p.H * p.W;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
     const long long m0 = (long long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int Ktot = p.KH * p.KW * p.Cin;
@@ -93,16 +94,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     // ---- loader state: this thread moves piece column `pc` of rows lrow + 32*it
     const int pc = tid & 7, lrow = tid >> 3;
     int ay[CFG::A_IT], ax[CFG::A_IT];
-    long long apix[CFG::A_IT];                                   // (n*H + y)*W + x, or -1 past the end
+    long long apix[CFG::A_IT];                                   // input pixel (n*H + y)*W + x of the window centre, or -1 past the end
 #pragma unroll
     for (int it = 0; it < CFG::A_IT; ++it) {
         const long long m = m0 + lrow + 32 * it;
         if (m < M) {
-            const int x = (int)(m % p.W);
-            const long long t = m / p.W;
-            ay[it] = (int)(t % p.H);
-            ax[it] = x;
-            apix[it] = m;
+            const int xo = (int)(m % p.Wo);
+            const long long t = m / p.Wo;
+            ay[it] = (int)(t % p.Ho) * p.stride;
+            ax[it] = xo * p.stride;
+            apix[it] = ((t / p.Ho) * p.H + ay[it]) * p.W + ax[it];
         } else { ay[it] = 0; ax[it] = 0; apix[it] = -1; }
     }
     // K position of this thread's piece: element k = kt*BK + pc*VEC  ->  (tap, channel); advanced incrementally
@@ -245,11 +246,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         if (p.shuffle2) {                                         // ConvTranspose2d(k=2, s=2): cout = (dy*2+dx)*C' + c'
             const int sub = co / p.shuffle2;
             oc = co - sub * p.shuffle2;
-            const int x = (int)(m % p.W);
-            const long long t = m / p.W;
-            const int y = (int)(t % p.H);
-            const long long n = t / p.H;
-            opix = (n * (2 * p.H) + 2 * y + (sub >> 1)) * (2LL * p.W) + 2 * x + (sub & 1);
+            const int x = (int)(m % p.Wo);
+            const long long t = m / p.Wo;
+            const int y = (int)(t % p.Ho);
+            const long long n = t / p.Ho;
+            opix = (n * (2 * p.Ho) + 2 * y + (sub >> 1)) * (2LL * p.Wo) + 2 * x + (sub & 1);
         }
         *reinterpret_cast<Vec16<T>*>(outp + opix * p.out_stride + oc) = v;
     }
@@ -266,7 +267,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
             return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
         attr_done = true;
     }
-    const long long M = (long long)a.N * a.H * a.W;
+    const long long M = (long long)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
     hipLaunchKernelGGL(kern, grid, dim3(256), CFG::LDS_BYTES, st, a);
     return check_launch("conv2d");
@@ -274,7 +275,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 
 template <typename T>
 static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
-    const long long M = (long long)a.N * a.H * a.W;
+    const long long M = (long long)a.N * a.Ho * a.Wo;
     if (tile == 0) {                                              // heuristic: narrow N, else fill the chip
         if (a.Cout <= 32) tile = 3;
         else if (a.Cout <= 64) tile = 4;
@@ -322,13 +323,15 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
         S2M2_REQUIRE(!d->shuffle2, "conv2d: aux epilogues are not supported with shuffle2");
     }
     if (d->shuffle2)
-        S2M2_REQUIRE(d->shuffle2 % 8 == 0 && d->Cout == 4 * d->shuffle2 && d->KH == 1 && d->KW == 1,
-                     "conv2d: shuffle2=%d needs a 1x1 kernel and Cout == 4*shuffle2 (multiple of 8)", d->shuffle2);
+        S2M2_REQUIRE(d->shuffle2 % 8 == 0 && d->Cout == 4 * d->shuffle2 && d->KH == 1 && d->KW == 1 && d->stride == 1,
+                     "conv2d: shuffle2=%d needs a 1x1 stride-1 kernel and Cout == 4*shuffle2 (multiple of 8)", d->shuffle2);
+    S2M2_REQUIRE(d->stride == 1 || d->stride == 2, "conv2d: stride=%d (1 or 2)", d->stride);
     a.nsrc = d->nsrc; a.weight = d->weight; a.bias = d->bias; a.out = d->out; a.out_stride = d->out_stride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.KH = d->KH; a.KW = d->KW; a.Cout = d->Cout;
     a.act = d->act; a.epi = d->epi; a.aux0 = d->aux0; a.aux1 = d->aux1;
     a.aux0_stride = d->aux0_stride; a.aux1_stride = d->aux1_stride;
     a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2;
+    a.stride = d->stride; a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->dtype == S2M2_F16) return dispatch_conv<half_t>(a, d->tile, st);
     if (d->dtype == S2M2_F32) return dispatch_conv<float>(a, d->tile, st);

@@ -84,6 +84,52 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(UpArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2x resampling of NHWC activations: AvgPool2d(2) (unet.py:25-30, stacked_MRT.py:22-27) and bilinear x2,
+// align_corners=False (unet.py:32-37, stacked_MRT.py:29-34; ATen upsample_bilinear2d arithmetic in fp32).
+// One 16-byte channel piece per thread; HBM-bound.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void resample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
+                                                         long long xs, long long ys) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int P = C / VEC;
+    const int Ho = MODE == 0 ? H / 2 : H * 2, Wo = MODE == 0 ? W / 2 : W * 2;
+    const long long total = (long long)N * Ho * Wo * P;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int pc = (int)(gid % P);
+    long long t = gid / P;
+    const int X = (int)(t % Wo); t /= Wo;
+    const int Y = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const T* xb = x + (long long)n * H * W * xs + pc * VEC;
+    Vec16<T> o;
+    if (MODE == 0) {
+        const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)(2 * Y) * W + 2 * X) * xs);
+        const Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)(2 * Y) * W + 2 * X + 1) * xs);
+        const Vec16<T> c = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)(2 * Y + 1) * W + 2 * X) * xs);
+        const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)(2 * Y + 1) * W + 2 * X + 1) * xs);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>((to_f32(a.v[e]) + to_f32(b.v[e]) + to_f32(c.v[e]) + to_f32(d.v[e])) * 0.25f);
+    } else {
+        const float sy = fmaxf(((float)Y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf(((float)X + 0.5f) * 0.5f - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)y0 * W + x0) * xs);
+        const Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)y0 * W + x1) * xs);
+        const Vec16<T> c = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)y1 * W + x0) * xs);
+        const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(xb + ((long long)y1 * W + x1) * xs);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+            o.v[e] = from_f32<T>(hy * (hx * to_f32(a.v[e]) + lx * to_f32(b.v[e])) + ly * (hx * to_f32(c.v[e]) + lx * to_f32(d.v[e])));
+    }
+    *reinterpret_cast<Vec16<T>*>(y + (((long long)n * Ho + Y) * Wo + X) * ys + pc * VEC) = o;
+}
+
 }  // namespace s2m2
 
 extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
@@ -110,4 +156,24 @@ extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, co
     else if (dtype == S2M2_F32) hipLaunchKernelGGL((convex_upsample_kernel<float>), grid, dim3(256), 0, st, a);
     else return set_error("convex_upsample: unsupported dtype %d", dtype);
     return check_launch("convex_upsample");
+}
+
+extern "C" int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int C, long long x_stride, long long y_stride, int mode,
+                               int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(x && y, "resample2x: null pointer");
+    S2M2_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && x_stride % 8 == 0 && y_stride % 8 == 0, "resample2x: bad shape");
+    S2M2_REQUIRE(mode == 0 || mode == 1, "resample2x: mode %d (0 = average pool 2x2, 1 = bilinear x2)", mode);
+    S2M2_REQUIRE(mode == 1 || (H % 2 == 0 && W % 2 == 0), "resample2x: average pooling needs even H, W");
+    const int vec = dtype == S2M2_F16 ? 8 : 4;
+    const long long Ho = mode == 0 ? H / 2 : H * 2, Wo = mode == 0 ? W / 2 : W * 2;
+    const long long total = (long long)N * Ho * Wo * (C / vec);
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == S2M2_F16 && mode == 0) hipLaunchKernelGGL((resample2x_kernel<half_t, 0>), grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, N, H, W, C, x_stride, y_stride);
+    else if (dtype == S2M2_F16) hipLaunchKernelGGL((resample2x_kernel<half_t, 1>), grid, dim3(256), 0, st, (const half_t*)x, (half_t*)y, N, H, W, C, x_stride, y_stride);
+    else if (dtype == S2M2_F32 && mode == 0) hipLaunchKernelGGL((resample2x_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, x_stride, y_stride);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((resample2x_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, x_stride, y_stride);
+    else return set_error("resample2x: unsupported dtype %d", dtype);
+    return check_launch("resample2x");
 }

@@ -1,25 +1,46 @@
-"""Inference engine behind ``S2M2.forward`` on MI355X.
+"""Inference engine behind ``S2M2.forward`` on MI355X: every stage of the reference forward (s2m2.py:136-197) runs as
+hand-written gfx950 kernels through the C ABI of ``libs2m2_hip.so`` (:mod:`s2m2_amd.hip`).  PyTorch is plumbing only: it owns
+device memory and the stream, packs the weights once, and prepares a few tiny (B,h,w,8) side inputs of the refiners.
 
-Activations are channels-last everywhere (NCHW-shaped tensors with ``torch.channels_last`` strides, so the
-``(B,H,W,C)`` token view the attention blocks and the HIP kernels want is free).  Weights are cast/packed once per
-(dtype, weight version).  Stage map (reference file:line -> what runs here):
+Activations are NHWC ``(N, H, W, C)`` tensors (channels contiguous, every channel count a multiple of 8), which is at the same
+time the token layout of the attention blocks.  Stage map (reference file:line -> kernel):
 
-* CNN backbone (submodules.py:63-93): PyTorch-ROCm convolutions (MIOpen) -- stays on the vendor library by design.
-* LayerNorm + correlation, Sinkhorn/argmax/regression, cost-volume lookups (submodules.py:19-60,154-243):
-  hand-written HIP kernels K1-K3 through the C ABI (:mod:`s2m2_amd.hip`).
-* Everything else is being moved to HIP kernels stage by stage; until a stage has its kernel it runs as PyTorch-ROCm
-  ops here (never on the CPU, never through oracle/).
+* CNNEncoder (submodules.py:63-93), every Conv2d / ConvTranspose2d / Linear of Unet, MRT, refiners, mask heads
+  (unet.py, stacked_MRT.py, attentions.py, refinenet.py, feature_fusion.py, submodules.py:96-145)   -> K5 ``conv2d``
+  (implicit GEMM on MFMA; torch.cat, bias, GELU/ReLU/sigmoid/tanh, residuals, GRU and FeatureFusion gates fused)
+* GroupNorm / pre-norm LayerNorm                                                                     -> K6
+* SelfAttn / CrossAttn incl. the contextual positional encoding (attentions.py:8-96)                  -> K4 ``attention``
+* AvgPool2d / bilinear x2 (unet.py:25-37)                                                             -> ``resample2x``
+* DispInit: LayerNorm + correlation, Sinkhorn OT, argmax + window regression (submodules.py:154-243) -> K1, K2
+* CostVolume lookups (submodules.py:19-60)                                                            -> K3
+* convex upsampling x4 / x1 (s2m2.py:101-133)                                                         -> K7
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
 
-from . import hip
+from . import hip, pack
 
 Tensor = torch.Tensor
+Spec = Tuple[Tensor, Optional[Tensor], int, int, int]          # packed weight, packed bias, KH, KW, Cout(padded)
+
+
+def pe_tables(h: int, w: int, device, pe_dim: int = 32) -> Tuple[Tensor, Tensor]:
+    """Separable sinc relative positional-encoding tables of the reference's get_pe (utils.py:32-60): the dense
+    pe[i, j, :] = 0.5 * [px[x_i - x_j + w - 1], py[y_i - y_j + h - 1]] is never materialised; K4 indexes the tables.
+    Returns px (2w-1, 16), py (2h-1, 16), fp32."""
+    def table(n: int) -> Tensor:
+        L = 2 * n + 1
+        sig = 5 / pe_dim
+        pos = torch.linspace(-3, 3, L, device=device).tanh()
+        dim_t = torch.linspace(-1, 1, pe_dim // 2, device=device)
+        x = (dim_t[None, :] - pos[:, None]) / sig
+        s = torch.where(x.abs() < 1e-6, torch.ones_like(x), torch.sin(3.1415 * x) / (3.1415 * x))
+        return F.normalize(s, p=2, dim=-1)[:2 * n - 1].contiguous()
+    return table(w), table(h)
 
 
 class Engine:
@@ -32,124 +53,160 @@ class Engine:
         self.refine_iter = model.refine_iter
         self.output_upsample = model.output_upsample
         self.device = next(model.parameters()).device
-        self.w: Dict[str, Tensor] = {}
-        for name, p in model.named_parameters():
-            t = p.detach().to(self.device, dtype)
-            if t.dim() == 4:
-                t = t.contiguous(memory_format=torch.channels_last)
-            self.w[name] = t
-        # LayerNorm affine of DispInit is consumed in fp32 by K1
-        self.ln_w = model.get_parameter("disp_init.layer_norm.weight").detach().float().contiguous()
-        self.ln_b = model.get_parameter("disp_init.layer_norm.bias").detach().float().contiguous()
-        self._pe_cache: Dict[Tuple[int, int], Tensor] = {}
+        self.p: Dict[str, Tensor] = {n: q.detach().to(self.device, torch.float32) for n, q in model.named_parameters()}
+        self._packed: Dict[object, Spec] = {}
+        self._pe_cache: Dict[Tuple[int, int], Tuple[Tensor, Tensor]] = {}
+        self._bufs: Dict[object, Tensor] = {}
+        self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
+        self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
 
-    # ---- dense helpers ------------------------------------------------------------------------------
-    def conv(self, p: str, x: Tensor, stride: int = 1, pad=0) -> Tensor:
-        return F.conv2d(x, self.w[p + ".weight"], self.w.get(p + ".bias"), stride=stride, padding=pad)
+    # ---- weight packing (once per engine) ------------------------------------------------------------
+    def std(self, name: str, splits: Optional[Sequence[Tuple[int, int]]] = None, transposed: bool = False) -> Spec:
+        """One nn.Conv2d / nn.Linear (or stride-1 nn.ConvTranspose2d when ``transposed``) as a K5 weight."""
+        key = (name, tuple(splits) if splits else None, transposed)
+        s = self._packed.get(key)
+        if s is None:
+            w = self.p[name + ".weight"]
+            if transposed:
+                w = pack.convT_s1_as_conv(w)
+            if w.dim() == 2:
+                w = w[:, :, None, None]
+            s = (pack.pack_conv(w, self.dtype, splits), pack.pack_bias(self.p.get(name + ".bias"), w.shape[0]),
+                 w.shape[2], w.shape[3], pack.pad8(w.shape[0]))
+            self._packed[key] = s
+        return s
 
-    def convT(self, p: str, x: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
-        return F.conv_transpose2d(x, self.w[p + ".weight"], self.w.get(p + ".bias"), stride=stride, padding=pad)
+    def merged(self, key: str, parts: Sequence[Tuple[str, int, float, bool]], cin_total: int) -> Spec:
+        """Several layers that read the same input tensor(s) stacked along Cout (each padded to 8 rows), every layer looking at its
+        own channel window [offset, offset+Cin_i) of the combined input.  parts: (name, cin_offset, weight_scale, transposed)."""
+        s = self._packed.get(key)
+        if s is None:
+            rows, biases = [], []
+            kh = kw = 1
+            for name, off, wscale, tr in parts:
+                w = self.p[name + ".weight"]
+                if tr:
+                    w = pack.convT_s1_as_conv(w)
+                if w.dim() == 2:
+                    w = w[:, :, None, None]
+                co, ci, kh, kw = w.shape
+                cop = pack.pad8(co)
+                full = w.new_zeros(cop, kh, kw, cin_total)
+                full[:co, :, :, off:off + ci] = w.permute(0, 2, 3, 1) * wscale
+                rows.append(full.reshape(cop, -1))
+                bb = w.new_zeros(cop)
+                if (name + ".bias") in self.p:
+                    bb[:co] = self.p[name + ".bias"]
+                biases.append(bb)
+            wp = torch.cat(rows, 0).to(self.dtype).contiguous()
+            s = (wp, torch.cat(biases).float().contiguous(), kh, kw, wp.shape[0])
+            self._packed[key] = s
+        return s
 
-    def lin(self, p: str, x: Tensor) -> Tensor:
-        return F.linear(x, self.w[p + ".weight"], self.w.get(p + ".bias"))
+    def convT2(self, name: str) -> Tuple[Spec, int]:
+        """nn.ConvTranspose2d(kernel 2, stride 2) as the pixel-shuffle GEMM of K5."""
+        key = (name, "T2")
+        s = self._packed.get(key)
+        if s is None:
+            w = self.p[name + ".weight"]
+            wp, cp = pack.pack_convT_2x2s2(w, self.dtype)
+            s = (wp, pack.pack_bias_shuffle(self.p.get(name + ".bias"), w.shape[1]), 1, 1, 4 * cp)
+            self._packed[key] = s
+        return s, s[4] // 4
 
     @staticmethod
-    def ln(x: Tensor) -> Tensor:
-        return F.layer_norm(x, (x.shape[-1],))
+    def cconv(spec: Spec, srcs, **kw) -> Tensor:
+        wp, bp, kh, kw_, cout = spec
+        return hip.conv2d(srcs, wp, bp, kh, kw_, cout, **kw)
 
+    def zeros(self, key, shape, dtype=None) -> Tensor:
+        """Persistent zero-initialised scratch (padding channels stay zero; the live channels are rewritten by every use)."""
+        k = (key, tuple(shape), dtype or self.dtype)
+        b = self._bufs.get(k)
+        if b is None:
+            b = torch.zeros(shape, device=self.device, dtype=dtype or self.dtype)
+            self._bufs[k] = b
+        return b
+
+    # ---- building blocks -----------------------------------------------------------------------------
     def down(self, p: str, x: Tensor) -> Tensor:
-        return self.conv(p + ".1", F.avg_pool2d(x, 2))
+        return self.cconv(self.std(p + ".1"), [hip.resample2x(x, 0)])
 
     def up(self, p: str, x: Tensor) -> Tensor:
-        return self.conv(p + ".1", F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))
+        return self.cconv(self.std(p + ".1"), [hip.resample2x(x, 1)])
 
     def conv_block(self, p: str, z: Tensor) -> Tensor:
-        a = self.conv(p + ".convs.2", F.gelu(self.conv(p + ".convs.0", z, 1, 1)), 1, 1)
-        b = self.conv(p + ".convs_1x.2", F.relu(self.conv(p + ".convs_1x.0", z)))
-        return a + b
+        """ConvBlock2D (attentions.py:255-281): conv3-GELU-conv3 + conv1-ReLU-conv1."""
+        t = self.cconv(self.std(p + ".convs.0"), [z], act=hip.ACT_GELU)
+        u = self.cconv(self.std(p + ".convs_1x.0"), [z], act=hip.ACT_RELU)
+        b = self.cconv(self.std(p + ".convs_1x.2"), [u])
+        return self.cconv(self.std(p + ".convs.2"), [t], epi=hip.EPI_ADD, aux0=b)
 
     def fusion(self, p: str, z0: Tensor, z1: Tensor) -> Tensor:
-        z = torch.cat([z0, z1], 1)
-        k = self.w[p + ".feature_gate.0.weight"].shape[-1]
-        g = torch.sigmoid(self.conv(p + ".feature_gate.2", F.gelu(self.conv(p + ".feature_gate.0", z, 1, k // 2))))
-        g = g.clamp(0.01, 0.99)
-        f = self.conv(p + ".feature_fusion.2", F.gelu(self.conv(p + ".feature_fusion.0", z, 1, k // 2)))
-        return f + g * z0 + (1 - g) * z1
+        """FeatureFusion (feature_fusion.py:4-33): out = fusion(z) + g*z0 + (1-g)*z1, g = clamp(sigmoid(gate(z)), .01, .99).
+        Both first layers read cat(z0, z1): one GEMM; the gate mix and the final add are epilogues."""
+        c = z0.shape[-1]
+        cg = self.p[p + ".feature_gate.0.weight"].shape[0]
+        spec = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
+        gf = self.cconv(spec, [z0, z1], act=hip.ACT_GELU)
+        m = self.cconv(self.std(p + ".feature_gate.2"), [gf[..., :cg]], act=hip.ACT_SIGMOID, epi=hip.EPI_GATEMIX, aux0=z0, aux1=z1)
+        return self.cconv(self.std(p + ".feature_fusion.2"), [gf[..., cg:]], epi=hip.EPI_ADD, aux0=m)
 
-    # ---- attention ----------------------------------------------------------------------------------
-    @staticmethod
-    def _heads(x: Tensor, nh: int) -> Tensor:
-        b, n, c = x.shape
-        return x.reshape(b, n, nh, c // nh).transpose(1, 2)
-
-    def pe(self, h: int, w: int) -> Tensor:
+    # ---- attention -----------------------------------------------------------------------------------
+    def pe(self, h: int, w: int) -> Tuple[Tensor, Tensor]:
         key = (h, w)
         if key not in self._pe_cache:
-            self._pe_cache[key] = _dense_pe(h, w, self.device).to(self.dtype)
+            self._pe_cache[key] = pe_tables(h, w, self.device)
         return self._pe_cache[key]
 
-    def self_attn(self, p: str, x: Tensor, nh: int, pe: Optional[Tensor]) -> Tensor:
-        b, n, c = x.shape
-        q, k, v = (self._heads(self.lin(p + "." + t, x), nh) for t in ("q", "k", "v"))
-        if (p + ".pe_proj.weight") in self.w:
-            s = torch.matmul(q * (q.shape[-1] ** -0.5), k.transpose(-1, -2))
-            a = torch.softmax(s.float(), dim=-1).to(self.dtype)
-            o = torch.matmul(a, v) + self.lin(p + ".pe_proj", torch.einsum("bhij,ijc->bhic", a, pe))
-        else:
-            o = F.scaled_dot_product_attention(q, k, v)
-        return self.lin(p + ".proj", o.transpose(1, 2).reshape(b, n, -1))
+    def qkv(self, p: str, x: Tensor) -> Tensor:
+        c = x.shape[-1]
+        spec = self.merged(p + "|qkv", [(p + ".q", 0, 1.0, False), (p + ".k", 0, 1.0, False), (p + ".v", 0, 1.0, False)], c)
+        return self.cconv(spec, [x])
 
-    def cross_attn(self, p: str, x: Tensor, y: Tensor, nh: int) -> Tuple[Tensor, Tensor]:
-        b, n, c = x.shape
-        qx, kx, vx = (self._heads(self.lin(p + "." + t, x), nh) for t in ("q", "k", "v"))
-        qy, ky, vy = (self._heads(self.lin(p + "." + t, y), nh) for t in ("q", "k", "v"))
-        ox = F.scaled_dot_product_attention(qx, ky, vy).transpose(1, 2).reshape(b, n, -1)
-        oy = F.scaled_dot_product_attention(qy, kx, vx).transpose(1, 2).reshape(b, n, -1)
-        return self.lin(p + ".proj", ox), self.lin(p + ".proj", oy)
+    def attn_core(self, p: str, z: Tensor, nh: int, two_d: bool, cross: bool, use_pe: bool) -> Tensor:
+        """pre-LN -> fused QKV projection -> K4 -> output projection with the residual add as epilogue."""
+        n, h, w, c = z.shape
+        qkv = self.qkv(p + ".attn", hip.layernorm(z))
+        v3 = qkv.reshape(n, h * w, 3 * c) if two_d else qkv.reshape(n * h, w, 3 * c)
+        q, k, v = v3[..., :c], v3[..., c:2 * c], v3[..., 2 * c:]
+        if use_pe:
+            px, py = self.pe(h, w)
+            o, pes = hip.attention(q, k, v, nh, pe=(px, py, w, h))
+            d = c // nh
+            o = self.cconv(self.std(p + ".attn.pe_proj"), [pes.reshape(1, 1, -1, 32)], epi=hip.EPI_ADD, aux0=o.reshape(1, 1, -1, d))
+        else:
+            o = hip.attention(q, k, v, nh, swap_halves=cross)
+        return self.cconv(self.std(p + ".attn.proj"), [o.reshape(n, h, w, c)], epi=hip.EPI_ADD, aux0=z)
 
     def ffn(self, p: str, z: Tensor) -> Tensor:
-        return self.lin(p + ".ffn.2", F.gelu(self.lin(p + ".ffn.0", self.ln(z)))) + z
+        hdn = self.cconv(self.std(p + ".ffn.0"), [hip.layernorm(z)], act=hip.ACT_GELU)
+        return self.cconv(self.std(p + ".ffn.2"), [hdn], epi=hip.EPI_ADD, aux0=z)
 
-    def cross_block(self, p: str, z: Tensor, nh: int, two_d: bool) -> Tensor:
-        zn = self.ln(z)
-        x, y = zn.chunk(2, 0)
-        b, h, w, c = x.shape
-        shp = (b, h * w, c) if two_d else (b * h, w, c)
-        ox, oy = self.cross_attn(p + ".attn", x.reshape(shp), y.reshape(shp), nh)
-        return torch.cat([ox.reshape(b, h, w, c), oy.reshape(b, h, w, c)], 0) + z
-
-    def self_block(self, p: str, z: Tensor, nh: int, two_d: bool, pe: Optional[Tensor]) -> Tensor:
-        b, h, w, c = z.shape
-        zz = z.reshape((b, h * w, c) if two_d else (b * h, w, c))
-        return (self.self_attn(p + ".attn", self.ln(zz), nh, pe) + zz).reshape(b, h, w, c)
-
-    def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, pe: Optional[Tensor] = None) -> Tensor:
-        """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321); z NCHW-shaped channels-last."""
-        t = z.permute(0, 2, 3, 1)
-        if (p + ".cross_attn.attn.q.weight") in self.w:
-            t = self.ffn(p + ".ffn_c", self.cross_block(p + ".cross_attn", t, nh, two_d))
-        t = self.ffn(p + ".ffn", self.self_block(p + ".self_attn", t, nh, two_d, pe))
-        return t.permute(0, 3, 1, 2)
+    def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False) -> Tensor:
+        """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321)."""
+        if (p + ".cross_attn.attn.q.weight") in self.p:
+            z = self.ffn(p + ".ffn_c", self.attn_core(p + ".cross_attn", z, nh, two_d, True, False))
+        return self.ffn(p + ".ffn", self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe))
 
     def _count(self, prefix: str) -> int:
         n = 0
-        while f"{prefix}.{n}.ffn.ffn.0.weight" in self.w:
+        while f"{prefix}.{n}.ffn.ffn.0.weight" in self.p:
             n += 1
         return n
 
-    # ---- U-Net / MRT --------------------------------------------------------------------------------
+    # ---- U-Net / MRT ---------------------------------------------------------------------------------
     def unet(self, p: str, z: Tensor):
-        use_pe = (p + ".enc3s.0.self_attn.attn.pe_proj.weight") in self.w
-        pe = self.pe(z.shape[-2] // 8, z.shape[-1] // 8) if use_pe else None
+        use_pe = (p + ".enc3s.0.self_attn.attn.pe_proj.weight") in self.p
         z0 = self.conv_block(p + ".enc0", z)
         z1 = self.conv_block(p + ".enc1", self.down(p + ".down_conv0", z0))
         z2 = self.conv_block(p + ".enc2", self.down(p + ".down_conv1", z1))
         z3 = self.down(p + ".down_conv2", z2)
         for i in range(self._count(p + ".enc3s")):
-            z3 = self.attn_block(f"{p}.enc3s.{i}", z3, 8, True, pe)
+            z3 = self.attn_block(f"{p}.enc3s.{i}", z3, 8, True, use_pe)
         for i in range(self._count(p + ".dec3s")):
-            z3 = self.attn_block(f"{p}.dec3s.{i}", z3, 8, True, None)
+            z3 = self.attn_block(f"{p}.dec3s.{i}", z3, 8, True, False)
         n2 = self.conv_block(p + ".dec2", self.fusion(p + ".concat_conv2", z2, self.up(p + ".up_conv2", z3)))
         n1 = self.conv_block(p + ".dec1", self.fusion(p + ".concat_conv1", z1, self.up(p + ".up_conv1", n2)))
         n0 = self.conv_block(p + ".dec0", self.fusion(p + ".concat_conv0", z0, self.up(p + ".up_conv0", n1)))
@@ -169,107 +226,121 @@ class Engine:
         z0 = self.attn_block(p + ".dec_attn0", self.fusion(p + ".up_concat0", z0, self.up(p + ".up_conv0", z1)), 1, False)
         return z0, z1, z2, z3
 
-    # ---- refiners -----------------------------------------------------------------------------------
+    # ---- refiners ------------------------------------------------------------------------------------
     def global_refiner(self, p: str, ctx: Tensor, disp: Tensor, conf: Tensor) -> Tensor:
+        """GlobalRefiner (refinenet.py:39-73); disp, conf (B,1,h,w) fp32."""
+        B, _, h, w = disp.shape
         mask = (conf > 0.2).float()
-        x = torch.cat([(disp / 1e2 * mask).to(self.dtype), torch.logit(mask * conf, eps=1e-1).to(self.dtype), ctx], 1)
-        f = self.conv(p + ".init_feat.2", F.gelu(self.conv(p + ".init_feat.0", x, 1, 1)))
+        small = self.zeros("gr_small", (B, h, w, 8))
+        small[..., 0] = (disp / 1e2 * mask)[:, 0]
+        small[..., 1] = torch.logit(mask * conf, eps=1e-1)[:, 0]
+        f = self.cconv(self.std(p + ".init_feat.0", splits=[(2, 8), (self.C, self.C)]), [small, ctx], act=hip.ACT_GELU)
+        f = self.cconv(self.std(p + ".init_feat.2"), [f])
         f = self.unet(p + ".refine_unet", f)[0]
-        upd = self.conv(p + ".out_feat.0", f, 1, 1).float() * 1e2
+        upd = self.cconv(self.std(p + ".out_feat.0"), [f])[..., 0].float().unsqueeze(1) * 1e2
         return mask * disp + (1 - mask) * upd
 
     def gru(self, p: str, h: Tensor, x: Tensor) -> Tensor:
-        for sfx, pad in (("1", (1, 0)), ("2", (0, 1))):
-            hx = torch.cat([h, x], 1)
-            z = torch.sigmoid(self.conv(f"{p}.convz{sfx}", hx, 1, pad))
-            r = torch.sigmoid(self.conv(f"{p}.convr{sfx}", hx, 1, pad))
-            q = torch.tanh(self.conv(f"{p}.convq{sfx}", torch.cat([r * h, x], 1), 1, pad))
-            h = (1 - z) * h + z * q
+        """ConvGRU (refinenet.py:7-36): two separable passes; the gate arithmetic lives in the conv epilogues."""
+        for sfx in ("1", "2"):
+            z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
+            rh = self.cconv(self.std(f"{p}.convr{sfx}"), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
+            h = self.cconv(self.std(f"{p}.convq{sfx}"), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
 
     def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it):
+        """LocalRefiner.forward (refinenet.py:126-154)."""
+        B, _, h, w = disp.shape
+        C = self.C
         cl = torch.logit(conf, eps=1e-2)
         ol = torch.logit(occ, eps=1e-2)
-        c1, c2 = hip.cv_lookup(cv, disp.contiguous(), 4, channels_last=True, out_dtype=self.dtype)          # K3
-        c1, c2 = c1.permute(0, 3, 1, 2), c2.permute(0, 3, 1, 2)
+        corr = self.zeros("lr_corr", (B, h, w, 32))
+        hip.cv_lookup_into(cv, disp.contiguous(), corr, 0, 16, 4)                                        # K3
         if cap is not None:
-            cap[f"corr1_it{it}"], cap[f"corr2_it{it}"] = c1, c2
-        f1 = self.conv(p + ".corr_feat1.2", F.gelu(self.conv(p + ".corr_feat1.0", c1 / 16)))
-        f2 = self.conv(p + ".corr_feat2.2", F.gelu(self.conv(p + ".corr_feat2.0", c2 / 16)))
-        fd = self.conv(p + ".disp_feat.2", F.gelu(self.conv(p + ".disp_feat.0", (disp / 1e2).to(self.dtype), 1, 1)), 1, 1)
-        fc = self.conv(p + ".conf_occ_feat.2", F.gelu(self.conv(p + ".conf_occ_feat.0", torch.cat([cl, ol], 1).to(self.dtype), 1, 1)))
-        x = torch.cat([fd, f1, f2, ctx, fc], 1)
-        x = self.conv(p + ".disp_corr_ctx_cat.2", F.gelu(self.conv(p + ".disp_corr_ctx_cat.0", x)), 1, 1)
+            cap[f"corr1_it{it}"], cap[f"corr2_it{it}"] = corr[..., 0:9].permute(0, 3, 1, 2), corr[..., 16:25].permute(0, 3, 1, 2)
+        # corr/16 -> 1x1(9->96) GELU 1x1(96->64), both levels as block-diagonal GEMMs (the 1/16 is folded into the weights)
+        cf = self.cconv(self.merged(p + "|corrA", [(p + ".corr_feat1.0", 0, 1 / 16, False), (p + ".corr_feat2.0", 16, 1 / 16, False)], 32),
+                        [corr], act=hip.ACT_GELU)
+        f12 = self.cconv(self.merged(p + "|corrB", [(p + ".corr_feat1.2", 0, 1.0, False), (p + ".corr_feat2.2", 96, 1.0, False)], 192), [cf])
+        small = self.zeros("lr_small", (B, h, w, 8))
+        small[..., 0] = (disp / 1e2)[:, 0]
+        small[..., 1] = cl[:, 0]
+        small[..., 2] = ol[:, 0]
+        dc = self.cconv(self.merged(p + "|dcA", [(p + ".disp_feat.0", 0, 1.0, False), (p + ".conf_occ_feat.0", 1, 1.0, False)], 8),
+                        [small], act=hip.ACT_GELU)
+        fd = self.cconv(self.std(p + ".disp_feat.2"), [dc[..., :96]])
+        fc = self.cconv(self.std(p + ".conf_occ_feat.2"), [dc[..., 96:160]])
+        x = self.cconv(self.std(p + ".disp_corr_ctx_cat.0"), [fd, f12, ctx, fc], act=hip.ACT_GELU)
+        x = self.cconv(self.std(p + ".disp_corr_ctx_cat.2"), [x])
         x = self.unet(p + ".refine_unet", x)[0]
         hn = self.gru(p + ".gru", hidden, x)
-        dd = self.conv(p + ".disp_update.2", F.gelu(self.conv(p + ".disp_update.0", hn, 1, 1)), 1, 1).float()
-        co = self.conv(p + ".conf_occ_update.2", F.gelu(self.conv(p + ".conf_occ_update.0", hn, 1, 1)), 1, 1).float()
-        return hn, disp + dd, torch.sigmoid(co[:, 0:1] + cl), torch.sigmoid(co[:, 1:2] + ol)
+        u = self.cconv(self.merged(p + "|updA", [(p + ".disp_update.0", 0, 1.0, False), (p + ".conf_occ_update.0", 0, 1.0, False)], C),
+                       [hn], act=hip.ACT_GELU)
+        dco = self.cconv(self.merged(p + "|updB", [(p + ".disp_update.2", 0, 1.0, False), (p + ".conf_occ_update.2", C, 1.0, False)], 2 * C),
+                         [u]).float()
+        dd = dco[..., 0].unsqueeze(1)
+        return hn, disp + dd, torch.sigmoid(dco[..., 8].unsqueeze(1) + cl), torch.sigmoid(dco[..., 9].unsqueeze(1) + ol)
 
-    # ---- upsampling ---------------------------------------------------------------------------------
+    # ---- upsampling masks ----------------------------------------------------------------------------
     def mask4x(self, p: str, hidden: Tensor, f2x: Tensor) -> Tensor:
-        a = self.convT(p + ".conv_x", hidden, 2)
-        b = self.conv(p + ".conv_y", f2x, 1, 1)
-        y = F.relu(self.conv(p + ".conv_concat.0", torch.cat([a, b], 1), 1, 1))
-        return self.convT(p + ".conv_concat.2", y, 2)
+        """UpsampleMask4x (submodules.py:96-115) -> logits (B,H,W,16), 9 used."""
+        sx, cx = self.convT2(p + ".conv_x")
+        a = self.cconv(sx, [hidden], shuffle2=cx)
+        b = self.cconv(self.std(p + ".conv_y"), [f2x])
+        y = self.cconv(self.std(p + ".conv_concat.0"), [a, b], act=hip.ACT_RELU)
+        s2, c2 = self.convT2(p + ".conv_concat.2")
+        return self.cconv(s2, [y], shuffle2=c2)
 
-    def mask1x(self, p: str, disp: Tensor, rgb: Tensor, f2x: Tensor) -> Tensor:
-        a = F.relu(self.convT(p + ".conv_disp.0", disp.to(self.dtype), 1, 1))
-        b = F.relu(self.convT(p + ".conv_rgb.0", rgb, 1, 1))
-        c = self.convT(p + ".conv_ctx", f2x, 2)
-        y = F.relu(self.conv(p + ".conv_concat.0", torch.cat([a, b, c], 1), 1, 1))
-        return self.convT(p + ".conv_concat.2", y)
+    def mask1x(self, p: str, disp_up: Tensor, rgb8: Tensor, f2x: Tensor) -> Tensor:
+        """UpsampleMask1x (submodules.py:118-145) -> logits (B,H,W,16), 9 used.  rgb8: (B,H,W,8) normalised image in channels 1..3,
+        channel 0 receives the upsampled disparity."""
+        rgb8[..., 0] = disp_up[:, 0].to(self.dtype)
+        ab = self.cconv(self.merged(p + "|dispRgb", [(p + ".conv_disp.0", 0, 1.0, True), (p + ".conv_rgb.0", 1, 1.0, True)], 8),
+                        [rgb8], act=hip.ACT_RELU)
+        sc, cc = self.convT2(p + ".conv_ctx")
+        c = self.cconv(sc, [f2x], shuffle2=cc)
+        y = self.cconv(self.std(p + ".conv_concat.0"), [ab, c], act=hip.ACT_RELU)
+        return self.cconv(self.std(p + ".conv_concat.2", transposed=True), [y])
 
-    @staticmethod
-    def _neigh9(x: Tensor) -> Tensor:
-        B, _, h, w = x.shape
-        xp = F.pad(x, (1, 1, 1, 1), mode="replicate")
-        return torch.cat([xp[:, :, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)], 1)
-
-    def upsample4x(self, x: Tensor, logits: Tensor) -> Tensor:
-        n = F.interpolate(self._neigh9(x), scale_factor=4, mode="nearest")
-        return (n * logits.float().softmax(1)).sum(1, keepdim=True)
-
-    def upsample1x(self, x: Tensor, logits: Tensor) -> Tensor:
-        n = self._neigh9(x)
-        if self.output_upsample:
-            n = F.interpolate(n, scale_factor=2, mode="nearest")
-            logits = F.interpolate(logits, scale_factor=2, mode="bilinear", align_corners=False)
-        return (n * logits.float().softmax(1)).sum(1, keepdim=True)
-
-    # ---- whole forward ------------------------------------------------------------------------------
+    # ---- whole forward -------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, img0: Tensor, img1: Tensor, cap: Optional[dict] = None):
         dt = self.dtype
-        B = img0.shape[0]
+        B, _, H, W = img0.shape
+        C = self.C
         x = torch.cat([img0, img1], 0).to(torch.float32)
-        x = ((x / 255.0 - 0.5) * 2).to(dt).contiguous(memory_format=torch.channels_last)
-        # backbone (PyTorch-ROCm / MIOpen)
+        x = ((x / 255.0 - 0.5) * 2).to(dt)
+        x8 = torch.zeros((2 * B, H, W, 8), device=x.device, dtype=dt)          # channels 1..3 = normalised RGB (0 is free, see mask1x)
+        x8[..., 1:4] = x.permute(0, 2, 3, 1)
+        # CNN backbone (submodules.py:63-93)
         p = "cnn_backbone"
-        t = self.conv(p + ".conv0.2", F.gelu(self.conv(p + ".conv0.0", x)))
-        f2 = self.conv(p + ".conv1_down.2", F.gelu(self.conv(p + ".conv1_down.0", t, 2, 2)), 1, 1)
-        f2 = F.group_norm(f2, 8, self.w[p + ".norm1.weight"], self.w[p + ".norm1.bias"])
-        f2 = self.conv(p + ".conv2.2", F.gelu(self.conv(p + ".conv2.0", f2, 1, 1)), 1, 1) + f2
-        f4 = self.conv(p + ".conv2_down.0", f2, 2, 1)
+        t = self.cconv(self._conv0(), [x8], act=hip.ACT_GELU)
+        t = self.cconv(self.std(p + ".conv0.2"), [t])
+        t = self.cconv(self.std(p + ".conv1_down.0"), [t], act=hip.ACT_GELU, stride=2)
+        f2 = self.cconv(self.std(p + ".conv1_down.2"), [t])
+        f2 = hip.groupnorm_nhwc(f2, 8, self.p[p + ".norm1.weight"], self.p[p + ".norm1.bias"])
+        t = self.cconv(self.std(p + ".conv2.0"), [f2], act=hip.ACT_GELU)
+        f2 = self.cconv(self.std(p + ".conv2.2"), [t], epi=hip.EPI_ADD, aux0=f2)
+        f4 = self.cconv(self.std(p + ".conv2_down.0"), [f2], stride=2)
         f2_left = f2[:B]
         # feature pyramid + multi-resolution transformer
         py = self.unet("feat_pyramid", f4)
         z = py
         for i in range(self.ntr):
             z = self.mrt(f"transformer.uformer_list.{i}", *z)
-        tr = z[0]
-        tokens = tr.permute(0, 2, 3, 1).contiguous()                        # (2B,h,w,C): free for channels-last
+        tr = z[0]                                                               # (2B,h,w,C) tokens
         # K1 + K2: cost volume, optimal transport, initial disparity
         if self.k1_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        cv = hip.ln_corr(tokens, self.ln_w, self.ln_b)
+        cv = hip.ln_corr(tr, self.ln_w, self.ln_b)
         if self.k1_events is not None:
             ev1.record()
             self.k1_events.append((ev0, ev1))
         disp, conf, occ, amax = hip.sinkhorn_regress(cv, self.use_positivity, 3, want_argmax=True)
         if cap is not None:
-            cap.update(feature_tr_4x=tr, feature_py_4x=py[0], cv=cv, argmax=amax, disp0=disp, conf0=conf, occ0=occ)
+            cap.update(feature_tr_4x=tr.permute(0, 3, 1, 2), feature_py_4x=py[0].permute(0, 3, 1, 2), cv=cv, argmax=amax,
+                       disp0=disp, conf0=conf, occ0=occ)
         tr0 = tr[:B]
         disp = self.global_refiner("global_refiner", tr0, disp, conf)
         if self.use_positivity:
@@ -277,7 +348,7 @@ class Engine:
         if cap is not None:
             cap["disp_g"] = disp
         fus = self.fusion("feat_fusion_layer", tr0, py[0][:B])
-        ctx = self.conv("ctx_feat.2", F.gelu(self.conv("ctx_feat.0", fus)))
+        ctx = self.cconv(self.std("ctx_feat.2"), [self.cconv(self.std("ctx_feat.0"), [fus], act=hip.ACT_GELU)])
         hidden = torch.tanh(ctx)
         w = disp.shape[-1]
         xs = torch.arange(w, device=disp.device, dtype=torch.float32).reshape(1, 1, 1, w)
@@ -289,30 +360,13 @@ class Engine:
             if cap is not None:
                 cap[f"disp_it{it}"], cap[f"conf_it{it}"], cap[f"occ_it{it}"] = disp, conf, occ
         m4 = self.mask4x("upsample_mask_4x_refine", hidden, f2_left)
-        d_up = self.upsample4x(disp * 4, m4)
-        o_up = self.upsample4x(occ, m4)
-        c_up = self.upsample4x(conf, m4)
-        m1 = self.mask1x("upsample_mask_1x", d_up, x[:B], f2_left)
-        d_up = self.upsample1x(d_up, m1)
-        o_up = self.upsample1x(o_up, m1)
-        c_up = self.upsample1x(c_up, m1)
-        if self.output_upsample:
-            d_up = 2 * d_up
+        d_up, o_up, c_up = hip.convex_upsample([disp, occ, conf], m4, 4, scales=[4.0, 1.0, 1.0])
+        m1 = self.mask1x("upsample_mask_1x", d_up, x8[:B], f2_left)
+        up = self.output_upsample
+        d_up, o_up, c_up = hip.convex_upsample([d_up, o_up, c_up], m1, 2 if up else 1, scales=[2.0 if up else 1.0, 1.0, 1.0],
+                                               logit_up2=up)
         return d_up, o_up, c_up
 
-
-def _dense_pe(h: int, w: int, device, pe_dim: int = 32) -> Tensor:
-    """Dense (N,N,32) sinc relative positional encoding (reference utils.py:32-60); fp32.
-    TODO(kernel): never materialise -- the attention-with-PE kernel consumes the two separable tables."""
-    def table(n: int) -> Tensor:
-        L = 2 * n + 1
-        sig = 5 / pe_dim
-        pos = torch.linspace(-3, 3, L, device=device).tanh()
-        dim_t = torch.linspace(-1, 1, pe_dim // 2, device=device)
-        x = (dim_t[None, :] - pos[:, None]) / sig
-        s = torch.where(x.abs() < 1e-6, torch.ones_like(x), torch.sin(3.1415 * x) / (3.1415 * x))
-        return F.normalize(s, p=2, dim=-1)
-    px, py = table(w), table(h)
-    ys, xs = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
-    xs, ys = xs.reshape(-1), ys.reshape(-1)
-    return 0.5 * torch.cat([px[xs[:, None] - xs[None, :] + w - 1], py[ys[:, None] - ys[None, :] + h - 1]], dim=2)
+    def _conv0(self) -> Spec:
+        """cnn_backbone.conv0.0 (1x1, 3 -> 16) reading the RGB planes from channels 1..3 of the 8-channel input tensor."""
+        return self.merged("cnn_backbone.conv0.0|rgb@1", [("cnn_backbone.conv0.0", 1, 1.0, False)], 8)

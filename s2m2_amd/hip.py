@@ -31,7 +31,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("src", _vp * 4), ("src_c", _i * 4), ("src_stride", _i * 4), ("nsrc", _i), ("weight", _vp), ("bias", _vp),
                 ("out", _vp), ("out_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Cout", _i),
                 ("act", _i), ("epi", _i), ("aux0", _vp), ("aux1", _vp), ("aux0_stride", _i), ("aux1_stride", _i),
-                ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i)]
+                ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("stride", _i)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -45,6 +45,9 @@ SIGNATURES = {
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
     "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "s2m2_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _ll,
+                            _i, _i, _i, _vp]),
+    "s2m2_resample2x": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _i, _vp]),
     "s2m2_layernorm": (_i, [_vp, _vp, _ll, _i, _ll, _ll, _i, _vp]),
     "s2m2_groupnorm_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "s2m2_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, ctypes.c_float, _i, _vp]),
@@ -138,7 +141,8 @@ def _nhwc(t: torch.Tensor):
 
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, act: int = ACT_NONE,
            epi: int = EPI_NONE, aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0) -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0,
+           stride: int = 1) -> torch.Tensor:
     """Implicit-GEMM convolution / linear layer (s2m2_conv2d).  srcs: list of (N,H,W,Cs) tensors, concatenated along C;
     weight: packed (Cout, KH*KW*sum(Cs)) (see s2m2_amd.pack); bias fp32 (Cout) or None.  Returns (N,H,W,Cout), or
     (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM."""
@@ -160,9 +164,10 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
         raise ValueError(f"conv2d: packed weight must be {(Cout, KH * KW * cin)} {dt}, got {tuple(weight.shape)} {weight.dtype}")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cout or not bias.is_contiguous()):
         raise ValueError("conv2d: bias must be fp32 (Cout)")
+    ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    exp_shape = (n, 2 * h, 2 * w, shuffle2) if shuffle2 else (n, ho, wo, Cout)
     if out is None:
-        out = torch.empty((n, 2 * h, 2 * w, shuffle2) if shuffle2 else (n, h, w, Cout), device=x0.device, dtype=dt)
-    exp_shape = (n, 2 * h, 2 * w, shuffle2) if shuffle2 else (n, h, w, Cout)
+        out = torch.empty(exp_shape, device=x0.device, dtype=dt)
     if tuple(out.shape) != exp_shape or out.dtype != dt:
         raise ValueError(f"conv2d: out must be {exp_shape} {dt}, got {tuple(out.shape)} {out.dtype}")
     d.nsrc = len(srcs)
@@ -174,13 +179,14 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
     d.act, d.epi = act, epi
     for name, a in (("aux0", aux0), ("aux1", aux1)):
         if a is not None:
-            if a.dtype != dt or tuple(a.shape) != (n, h, w, Cout):
-                raise ValueError(f"conv2d: {name} must be {(n, h, w, Cout)} {dt}")
+            if a.dtype != dt or tuple(a.shape) != (n, ho, wo, Cout):
+                raise ValueError(f"conv2d: {name} must be {(n, ho, wo, Cout)} {dt}, got {tuple(a.shape)} {a.dtype}")
             setattr(d, name, a.data_ptr())
             setattr(d, name + "_stride", _nhwc(a))
     d.out_scale = out_scale
     d.shuffle2 = shuffle2
     d.tile = tile
+    d.stride = stride
     d.dtype = _DT[dt]
     _check(load().s2m2_conv2d(ctypes.byref(d), _stream()), "s2m2_conv2d")
     return out
@@ -231,3 +237,49 @@ def convex_upsample(maps, logits: torch.Tensor, factor: int, scales=None, logit_
     _check(load().s2m2_convex_upsample(xp, op, sc, n, logits.data_ptr(), ls, B, hs, ws, factor, int(logit_up2),
                                        _DT[logits.dtype], _stream()), "s2m2_convex_upsample")
     return outs
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, swap_halves: bool = False,
+              pe: Optional[Tuple[torch.Tensor, torch.Tensor, int, int]] = None, scale: Optional[float] = None):
+    """q, k, v: (nb, N, heads*D) views with contiguous channels and dense token rows (e.g. slices of a fused QKV buffer).
+    -> out (nb, Nq, heads*D) [, pe_sum (nb, Nq, heads*32) when pe = (px (2w-1,16) fp32, py (2h-1,16) fp32, w, h)]."""
+    nb, Nq, C = q.shape
+    Nk = k.shape[1]
+    D = C // heads
+    for t in (q, k, v):
+        if t.stride(2) != 1 or (t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1)) or not t.is_cuda:
+            raise ValueError("attention: q/k/v must be device tensors with contiguous channels and dense token rows")
+    out = torch.empty((nb, Nq, C), device=q.device, dtype=q.dtype)
+    pe_out = None
+    px = py = None
+    gw = gh = 0
+    if pe is not None:
+        px, py, gw, gh = pe
+        _dev(px, py)
+        pe_out = torch.empty((nb, Nq, heads * 32), device=q.device, dtype=q.dtype)
+    _check(load().s2m2_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(1), k.stride(1), v.stride(1), C,
+                                 nb, heads, Nq, Nk, D, float(scale if scale is not None else D ** -0.5), int(swap_halves),
+                                 px.data_ptr() if px is not None else None, py.data_ptr() if py is not None else None,
+                                 pe_out.data_ptr() if pe_out is not None else None, heads * 32, gw, gh, _DT[q.dtype], _stream()),
+           "s2m2_attention")
+    return (out, pe_out) if pe is not None else out
+
+
+def resample2x(x: torch.Tensor, mode: int) -> torch.Tensor:
+    """(N,H,W,C) -> AvgPool2d(2) (mode 0) or bilinear x2, align_corners=False (mode 1)."""
+    n, h, w, c = x.shape
+    xs = _nhwc(x)
+    out = torch.empty((n, h // 2, w // 2, c) if mode == 0 else (n, 2 * h, 2 * w, c), device=x.device, dtype=x.dtype)
+    _check(load().s2m2_resample2x(x.data_ptr(), out.data_ptr(), n, h, w, c, xs, c, mode, _DT[x.dtype], _stream()), "s2m2_resample2x")
+    return out
+
+
+def cv_lookup_into(cv: torch.Tensor, disp: torch.Tensor, buf: torch.Tensor, off1: int, off2: int, radius: int = 4) -> None:
+    """K3 writing straight into channel slots of a wider NHWC tensor: taps of level 0 -> buf[..., off1:off1+2r+1], level 1 ->
+    buf[..., off2:off2+2r+1] (buf (B,h,w,Cb) contiguous; the other channels are left untouched)."""
+    _dev(cv, disp, buf)
+    B, h, w, _ = cv.shape
+    cb = buf.shape[-1]
+    es = buf.element_size()
+    _check(load().s2m2_cv_lookup(cv.data_ptr(), disp.data_ptr(), buf.data_ptr() + off1 * es, buf.data_ptr() + off2 * es, B, h, w,
+                                 radius, _DT[cv.dtype], _DT[buf.dtype], h * w * cb, cb, 1, _stream()), "s2m2_cv_lookup")

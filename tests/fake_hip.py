@@ -1,0 +1,106 @@
+"""CPU stand-ins for the functions of :mod:`s2m2_amd.hip`, used ONLY by tests/test_engine_wiring_cpu.py to exercise the engine's
+host logic (weight packing, channel padding, merged layers, stage wiring) without a GPU.  Each function restates the
+documented semantics of its C-ABI entry point (include/s2m2_hip.h) with plain PyTorch CPU ops / the oracle."""
+import types
+
+import torch
+import torch.nn.functional as F
+
+from oracle import s2m2_oracle as O
+
+ACTS = [lambda t: t, F.gelu, F.relu, torch.sigmoid, torch.tanh]
+
+
+def make():
+    ns = types.SimpleNamespace(ACT_NONE=0, ACT_GELU=1, ACT_RELU=2, ACT_SIGMOID=3, ACT_TANH=4,
+                               EPI_NONE=0, EPI_ADD=1, EPI_MUL=2, EPI_GRU=3, EPI_GATEMIX=4, load=lambda: None)
+
+    def ln_corr(tokens, g, b, cv_dtype=None):
+        return O.ln_corr(tokens.permute(0, 3, 1, 2).float(), g, b)
+
+    def sinkhorn_regress(cv, pos, ot_iter=3, want_argmax=False):
+        d, c, o, ind = O.regress(O.sinkhorn_prob(cv.float(), pos, ot_iter))
+        return (d, c, o, ind.int()) if want_argmax else (d, c, o)
+
+    def cv_lookup_into(cv, disp, buf, off1, off2, radius=4):
+        c1, c2 = O.cv_lookup(cv.float(), disp.float(), radius)
+        T = 2 * radius + 1
+        buf[..., off1:off1 + T] = c1.permute(0, 2, 3, 1).to(buf.dtype)
+        buf[..., off2:off2 + T] = c2.permute(0, 2, 3, 1).to(buf.dtype)
+
+    def conv2d(srcs, weight, bias, KH, KW, Cout, act=0, epi=0, aux0=None, aux1=None, out=None, out_scale=1.0, shuffle2=0, tile=0,
+               stride=1):
+        if isinstance(srcs, torch.Tensor):
+            srcs = [srcs]
+        x = torch.cat([s.float() for s in srcs], -1)
+        n, h, w, cin = x.shape
+        assert tuple(weight.shape) == (Cout, KH * KW * cin) and Cout % 8 == 0 and cin % 8 == 0
+        wt = weight.float().reshape(Cout, KH, KW, cin).permute(0, 3, 1, 2)
+        y = F.conv2d(x.permute(0, 3, 1, 2), wt, bias, stride=stride, padding=(KH // 2, KW // 2))
+        y = (ACTS[act](y) * out_scale).permute(0, 2, 3, 1)
+        if epi == 1:
+            y = y + aux0.float()
+        elif epi == 2:
+            y = y * aux0.float()
+        elif epi == 3:
+            y = (1 - aux0.float()) * aux1.float() + aux0.float() * y
+        elif epi == 4:
+            g = y.clamp(0.01, 0.99)
+            y = g * aux0.float() + (1 - g) * aux1.float()
+        if shuffle2:
+            cp = shuffle2
+            y = y.reshape(n, h, w, 2, 2, cp).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, cp)
+        y = y.to(srcs[0].dtype)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y.contiguous()
+
+    def layernorm(x, out=None):
+        return F.layer_norm(x.float(), (x.shape[-1],)).to(x.dtype)
+
+    def groupnorm_nhwc(x, groups, gamma, beta, eps=1e-5):
+        return F.group_norm(x.float().permute(0, 3, 1, 2), groups, gamma, beta, eps).permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+    def resample2x(x, mode):
+        xn = x.float().permute(0, 3, 1, 2)
+        y = F.avg_pool2d(xn, 2) if mode == 0 else F.interpolate(xn, scale_factor=2, mode="bilinear", align_corners=False)
+        return y.permute(0, 2, 3, 1).contiguous().to(x.dtype)
+
+    def attention(q, k, v, heads, swap_halves=False, pe=None, scale=None):
+        nb, N, C = q.shape
+        d = C // heads
+        sp = lambda t: t.float().reshape(t.shape[0], t.shape[1], heads, d).transpose(1, 2)
+        qh, kh, vh = sp(q), sp(k), sp(v)
+        if swap_halves:
+            kh, vh = kh.roll(nb // 2, 0), vh.roll(nb // 2, 0)
+        a = torch.softmax(qh @ kh.transpose(-1, -2) * (scale if scale is not None else d ** -0.5), -1)
+        o = (a @ vh).transpose(1, 2).reshape(nb, N, C).to(q.dtype)
+        if pe is None:
+            return o
+        px, py, gw, gh = pe
+        ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+        xs, ys = xs.reshape(-1), ys.reshape(-1)
+        dense = 0.5 * torch.cat([px[xs[:, None] - xs[None, :] + gw - 1], py[ys[:, None] - ys[None, :] + gh - 1]], 2)
+        ps = torch.einsum("bhij,ijc->bhic", a, dense).transpose(1, 2).reshape(nb, N, heads * 32).to(q.dtype)
+        return o, ps
+
+    def convex_upsample(maps, logits, factor, scales=None, logit_up2=False):
+        lg = logits[..., :9].float().permute(0, 3, 1, 2)
+        if logit_up2:
+            lg = F.interpolate(lg, scale_factor=2, mode="bilinear", align_corners=False)
+        wgt = lg.softmax(1)
+        outs = []
+        for m, s in zip(maps, scales or [1.0] * len(maps)):
+            m = m.float().reshape(m.shape[0], 1, m.shape[-2], m.shape[-1])
+            B, _, h, w = m.shape
+            xp = F.pad(m, (1, 1, 1, 1), mode="replicate")
+            n9 = torch.cat([xp[:, :, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)], 1)
+            if factor > 1:
+                n9 = F.interpolate(n9, scale_factor=factor, mode="nearest")
+            outs.append((n9 * wgt).sum(1, keepdim=True) * s)
+        return outs
+
+    for f in (ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample):
+        setattr(ns, f.__name__, f)
+    return ns

@@ -1,5 +1,5 @@
-"""Host-logic test (no GPU): the engine's stage wiring, weight plumbing and state_dict naming, with the three HIP
-entry points replaced by CPU stand-ins built from the oracle.  This checks the Python around the kernels only --
+"""Host-logic test (no GPU): the engine's stage wiring, weight plumbing and state_dict naming, with the HIP
+entry points replaced by CPU stand-ins (tests/fake_hip.py: plain PyTorch CPU ops / the oracle).  This checks the Python around the kernels only --
 the kernels themselves are covered by the -m gpu tests through the real C ABI."""
 import types
 
@@ -14,20 +14,7 @@ from s2m2_amd.model import S2M2, build_model
 from s2m2_amd.weights import seeded_state_dict
 
 
-def _fake_hip():
-    def ln_corr(tokens, g, b, cv_dtype=None):
-        return O.ln_corr(tokens.permute(0, 3, 1, 2).float(), g, b)
-
-    def sinkhorn_regress(cv, pos, ot_iter=3, want_argmax=False):
-        d, c, o, ind = O.regress(O.sinkhorn_prob(cv.float(), pos, ot_iter))
-        return (d, c, o, ind.int()) if want_argmax else (d, c, o)
-
-    def cv_lookup(cv, disp, radius=4, channels_last=False, out_dtype=torch.float32):
-        c1, c2 = O.cv_lookup(cv.float(), disp.float(), radius)
-        if channels_last:
-            c1, c2 = c1.permute(0, 2, 3, 1), c2.permute(0, 2, 3, 1)
-        return c1.to(out_dtype), c2.to(out_dtype)
-    return types.SimpleNamespace(load=lambda: None, ln_corr=ln_corr, sinkhorn_regress=sinkhorn_regress, cv_lookup=cv_lookup)
+from fake_hip import make as _fake_hip
 
 
 @pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_64x64_pos_r1_up"])

@@ -80,3 +80,14 @@ def test_convex_upsample_output_upsample_branch(hip, dtype):
     lg = F.interpolate(logits[..., :9].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
     ref = (F.interpolate(_neigh9(m), scale_factor=2, mode="nearest") * lg.float().softmax(1)).sum(1, keepdim=True)
     assert float((o - ref).abs().max()) < (5e-5 if dtype == torch.float32 else 5e-2) * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_resample2x(hip, dtype, mode):
+    g = torch.Generator(device="cuda").manual_seed(mode)
+    x = torch.randn(2, 14, 22, 128, device="cuda", generator=g).to(dtype)
+    y = hip.resample2x(x, mode)
+    xn = x.float().permute(0, 3, 1, 2)
+    ref = F.avg_pool2d(xn, 2) if mode == 0 else F.interpolate(xn, scale_factor=2, mode="bilinear", align_corners=False)
+    assert float((y.float() - ref.permute(0, 2, 3, 1)).abs().max()) < (1e-6 if dtype == torch.float32 else 2e-3)
