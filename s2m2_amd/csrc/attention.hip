@@ -138,7 +138,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { if constexpr (sizeof(T) == 2) z.v[e] = (half_t)0.f; else z.v[e] = 0.f; }
         return z; };
-    auto fetch = [&](int kv0) {
+    auto fetch = [&](int kv0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < K_IT_MAX; ++it) {
             const int t = tid + it * nthr;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < K_IT_MAX; ++it) {
             const int t = tid + it * nthr;

@@ -42,6 +42,13 @@ template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ half_t from_f32<half_t>(float x) { return (half_t)x; }
 
+// load through an explicit global (address space 1) pointer: keeps the access a global_load even where the compiler cannot
+// prove the address space of a selected pointer (a flat load would also tick lgkmcnt and serialise with the LDS traffic)
+typedef float raw16_t __attribute__((ext_vector_type(4)));       // 16 opaque bytes in 4 VGPRs
+__device__ __forceinline__ raw16_t global_load16(const void* p) {
+    return *(const __attribute__((address_space(1))) raw16_t*)(p);
+}
+
 // 16-byte vector of T (8 halfs / 4 floats)
 template <typename T> struct Vec16;
 template <> struct alignas(16) Vec16<half_t> { half_t v[8]; };

@@ -18,6 +18,13 @@
 // fp16: v_mfma_f32_32x32x16_f16, fp32 accumulate.  fp32 (parity mode): exact v_mfma_f32_32x32x2_f32.
 #include "common.h"
 
+// compile-time ablation switches (tools/conv_ablate.py; never set in the shipped library):
+// 1 no global loads inside the K loop, 2 no MFMA, 4 no LDS stash inside the loop, 8 no fragment reads,
+// 16 no bias/activation math, 32 no global stores, 64 no K loop at all
+#ifndef S2M2_CONV_DBG
+#define S2M2_CONV_DBG 0
+#endif
+
 namespace s2m2 {
 
 struct ConvArgs {
@@ -37,6 +44,7 @@ struct ConvArgs {
     int aux0_stride, aux1_stride;
     float out_scale;
     int shuffle2;
+    const void* zero;           // 256 zero bytes in global memory (what out-of-range pieces read)
 };
 
 template <typename T, int BM_, int BN_, int WGM_>
@@ -57,13 +65,60 @@ struct ConvCfg {
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be whole 32x32 MFMA tiles");
 };
 
-__device__ __forceinline__ float activate(float x, int act) {
-    switch (act) {
-        case S2M2_ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-        case S2M2_ACT_RELU: return fmaxf(x, 0.f);
-        case S2M2_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
-        case S2M2_ACT_TANH: return tanhf(x);
-        default: return x;
+// Activations in the epilogue run on all BM*BN accumulators, so they must be a handful of VALU ops each: libm's erff / tanhf
+// (~100 instructions with divergent range splits) made the GELU epilogue as expensive as the whole K loop.
+//  erf: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 (below fp32 round-off of the surrounding arithmetic);
+//  exp: v_exp_f32 (1 ulp);  sigmoid / tanh from it.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = fast_rcp(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    pl = __builtin_fmaf(pl, t, 1.421413741f);
+    pl = __builtin_fmaf(pl, t, -0.284496736f);
+    pl = __builtin_fmaf(pl, t, 0.254829592f);
+    const float r = 1.0f - pl * t * fast_exp(-ax * ax);
+    return copysignf(r, x);
+}
+template <int ACT> __device__ __forceinline__ float activate(float x) {
+    if (ACT == S2M2_ACT_GELU) return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    if (ACT == S2M2_ACT_RELU) return fmaxf(x, 0.f);
+    if (ACT == S2M2_ACT_SIGMOID) return fast_rcp(1.0f + fast_exp(-x));
+    if (ACT == S2M2_ACT_TANH) return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x));
+    return x;
+}
+
+// epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]; ACT is a compile-time constant here (a
+// runtime switch per element made the compiler evaluate every activation and select)
+template <typename CFG, typename T, int ACT>
+__device__ __forceinline__ void stage_tile(const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, const float* __restrict__ bias, int Cout,
+                                           float out_scale, int n0, int wm, int wn, int lane) {
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i) {
+        T* crow = Cs + (size_t)(wm * CFG::WM + i * 32 + (lane & 31)) * CFG::CRS;
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wn * CFG::WN + j * 32 + 8 * g + 4 * hi;         // local cout of the quad
+                const int co = n0 + cl;
+                float4_t bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias && co < Cout) bv = *reinterpret_cast<const float4_t*>(bias + co);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = (S2M2_CONV_DBG & 16) ? acc[i][j][4 * g + e] : activate<ACT>(acc[i][j][4 * g + e] + bv[e]) * out_scale;
+                if constexpr (sizeof(T) == 2) {
+                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4_t*>(crow + cl) = h;
+                } else {
+                    float4_t f = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<float4_t*>(crow + cl) = f;
+                }
+            }
+        }
     }
 }
 
@@ -73,6 +128,104 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero_vec() {
     for (int e = 0; e < (int)(16 / sizeof(T)); ++e) z.v[e] = from_f32<T>(0.f);
     return z;
 }
+
+// Per-thread state of the global -> register -> LDS tile loader: piece column `pc` of rows lrow + 32*it.
+//  * everything that does not change along K is computed once (pixel index, a bit mask of the taps that fall inside the image,
+//    weight row pointers); a fetch is ~7 VALU ops per 16-byte piece: 24-bit multiply-add for the element offset, one bit test,
+//    one 64-bit select between the real address and a 16-byte zero block (zero padding, K / Cout / M tails) -- no branches;
+//  * kernel-argument arrays are never indexed with a runtime value (that becomes memory loads + vmcnt(0) in front of every tile):
+//    the per-lane source is picked with masked telescoping sums over scalars.
+template <typename CFG, typename T>
+struct ConvLoader {
+    static constexpr int VEC = CFG::VEC, BK = CFG::BK, RS = CFG::RS, BN = CFG::BN;
+    int pc, lrow, Ktot;
+    int apix[CFG::A_IT];                       // input pixel (n*H + y)*W + x of the window centre
+    unsigned tapmask[CFG::A_IT];               // bit (ky*KW + kx): that tap of this row is inside the image (0 for rows past M)
+    const T* wrow[CFG::B_IT];                  // weight row of this thread (nullptr: row past Cout / BN)
+    int kc, ky, kx;                            // K position of this thread's piece: channel within the tap, tap coordinates
+    const T *s0, *s1, *s2, *s3;                // sources / strides / cumulative channel counts as named scalars
+    int st0, st1, st2, st3, c0n, c1n, c2n;
+    raw16_t ra[CFG::A_IT], rb[CFG::B_IT];
+
+    __device__ __forceinline__ void init(const ConvArgs& p, int tid, long long m0, int n0, long long M, int Ktot_) {
+        pc = tid & 7; lrow = tid >> 3; Ktot = Ktot_;
+        s0 = static_cast<const T*>(p.src[0]); s1 = static_cast<const T*>(p.src[1]);
+        s2 = static_cast<const T*>(p.src[2]); s3 = static_cast<const T*>(p.src[3]);
+        st0 = p.src_stride[0]; st1 = p.src_stride[1]; st2 = p.src_stride[2]; st3 = p.src_stride[3];
+        c0n = p.src_c[0]; c1n = c0n + p.src_c[1]; c2n = c1n + p.src_c[2];
+        const int ph = p.KH / 2, pw = p.KW / 2;
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const long long m = m0 + lrow + 32 * it;
+            apix[it] = 0; tapmask[it] = 0u;
+            if (m < M) {                                          // M < 2^24 (checked on the host): 32-bit divisions
+                const unsigned mu = (unsigned)m;
+                const unsigned t = mu / (unsigned)p.Wo;
+                const int xo = (int)(mu - t * (unsigned)p.Wo);
+                const unsigned n = t / (unsigned)p.Ho;
+                const int y = (int)(t - n * (unsigned)p.Ho) * p.stride, x = xo * p.stride;
+                apix[it] = ((int)n * p.H + y) * p.W + x;
+                unsigned mk = 0u;
+                for (int a = 0; a < p.KH; ++a)
+                    for (int b = 0; b < p.KW; ++b) {
+                        const int yy = y + a - ph, xx = x + b - pw;
+                        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << (a * p.KW + b);
+                    }
+                tapmask[it] = mk;
+            }
+        }
+        const T* wp = static_cast<const T*>(p.weight);
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) {
+            const int r = lrow + 32 * it;
+            const int co = n0 + r;
+            wrow[it] = (r < BN && co < p.Cout) ? wp + (size_t)co * Ktot + pc * VEC : nullptr;
+        }
+        kc = pc * VEC; ky = 0; kx = 0;
+        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.KW) { kx = 0; ++ky; } }
+    }
+
+    // issue the loads of K tile kt (element k = kt*BK + pc*VEC -> (tap, channel)), then advance to the next tile
+    __device__ __forceinline__ void fetch(const ConvArgs& p, int kt) {
+        const T* zp = static_cast<const T*>(p.zero);
+        const bool kvalid = kt * BK + pc * VEC < Ktot;
+        const T* sp = s0;
+        unsigned ss = (unsigned)st0, c = (unsigned)kc;
+        if (p.nsrc > 1) {                                         // wave-uniform branch on a scalar
+            const bool g0 = kc >= c0n, g1 = kc >= c1n, g2 = kc >= c2n;
+            const long long d1 = (const char*)s1 - (const char*)s0, d2 = (const char*)s2 - (const char*)s1, d3 = (const char*)s3 - (const char*)s2;
+            sp = reinterpret_cast<const T*>((const char*)s0 + ((g0 ? d1 : 0) + (g1 ? d2 : 0) + (g2 ? d3 : 0)));
+            ss = (unsigned)(st0 + (g0 ? st1 - st0 : 0) + (g1 ? st2 - st1 : 0) + (g2 ? st3 - st2 : 0));
+            c = (unsigned)(kc - ((g0 ? c0n : 0) + (g1 ? c1n - c0n : 0) + (g2 ? c2n - c1n : 0)));
+        }
+        const int tapoff = (ky - p.KH / 2) * p.W + (kx - p.KW / 2);
+        const unsigned tapbit = kvalid ? 1u << (ky * p.KW + kx) : 0u;
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const unsigned e = __umul24((unsigned)(apix[it] + tapoff), ss) + c;      // pixel < 2^24, stride < 2^24, numel < 2^31
+            const T* src = (tapmask[it] & tapbit) ? sp + e : zp;
+            ra[it] = global_load16(src);
+        }
+        const int koff = kt * BK;
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) {
+            const T* src = (kvalid && wrow[it]) ? wrow[it] + koff : zp;
+            rb[it] = global_load16(src);
+        }
+        kc += BK;
+        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.KW) { kx = 0; ++ky; } }
+    }
+
+    __device__ __forceinline__ void stash(T* a, T* b) const {
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) *reinterpret_cast<raw16_t*>(a + (size_t)(lrow + 32 * it) * RS + pc * VEC) = ra[it];
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) {
+            const int r = lrow + 32 * it;
+            if (r < BN) *reinterpret_cast<raw16_t*>(b + (size_t)r * RS + pc * VEC) = rb[it];
+        }
+    }
+};
 
 template <typename CFG, typename T>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
@@ -89,70 +242,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int n0 = blockIdx.y * BN;
     const int Ktot = p.KH * p.KW * p.Cin;
     const int nkt = (Ktot + BK - 1) / BK;
-    const int ph = p.KH / 2, pw = p.KW / 2;
 
-    // ---- loader state: this thread moves piece column `pc` of rows lrow + 32*it
-    const int pc = tid & 7, lrow = tid >> 3;
-    int ay[CFG::A_IT], ax[CFG::A_IT];
-    long long apix[CFG::A_IT];                                   // input pixel (n*H + y)*W + x of the window centre, or -1 past the end
-#pragma unroll
-    for (int it = 0; it < CFG::A_IT; ++it) {
-        const long long m = m0 + lrow + 32 * it;
-        if (m < M) {
-            const int xo = (int)(m % p.Wo);
-            const long long t = m / p.Wo;
-            ay[it] = (int)(t % p.Ho) * p.stride;
-            ax[it] = xo * p.stride;
-            apix[it] = ((t / p.Ho) * p.H + ay[it]) * p.W + ax[it];
-        } else { ay[it] = 0; ax[it] = 0; apix[it] = -1; }
-    }
-    // K position of this thread's piece: element k = kt*BK + pc*VEC  ->  (tap, channel); advanced incrementally
-    int kc = pc * VEC, ky = 0, kx = 0;                            // channel within the tap, tap coordinates
-    while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.KW) { kx = 0; ++ky; } }
-
-    Vec16<T> ra[CFG::A_IT], rb[CFG::B_IT];
-    auto fetch = [&](int kt) {
-        const int k = kt * BK + pc * VEC;
-        const bool kvalid = k < Ktot;
-        // source of channel kc
-        int s = 0, c = kc;
-        if (p.nsrc > 1 && c >= p.src_c[0]) { c -= p.src_c[0]; s = 1;
-            if (p.nsrc > 2 && c >= p.src_c[1]) { c -= p.src_c[1]; s = 2;
-                if (p.nsrc > 3 && c >= p.src_c[2]) { c -= p.src_c[2]; s = 3; } } }
-        const T* sp = static_cast<const T*>(p.src[s]);
-        const int ss = p.src_stride[s];
-        const int dy = ky - ph, dx = kx - pw;
-#pragma unroll
-        for (int it = 0; it < CFG::A_IT; ++it) {
-            const int yy = ay[it] + dy, xx = ax[it] + dx;
-            const bool ok = kvalid && apix[it] >= 0 && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            if (ok) ra[it] = *reinterpret_cast<const Vec16<T>*>(sp + (apix[it] + (long long)dy * p.W + dx) * ss + c);
-            else ra[it] = zero_vec<T>();
-        }
-        const T* wp = static_cast<const T*>(p.weight);
-#pragma unroll
-        for (int it = 0; it < CFG::B_IT; ++it) {
-            const int r = lrow + 32 * it;
-            const int co = n0 + r;
-            if (r < BN && kvalid && co < p.Cout) rb[it] = *reinterpret_cast<const Vec16<T>*>(wp + (size_t)co * Ktot + k);
-            else rb[it] = zero_vec<T>();
-        }
-        // advance to the next K tile
-        kc += BK;
-        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.KW) { kx = 0; ++ky; } }
-    };
-    auto stash = [&](int buf) {
-        T* a = As + (size_t)buf * BM * RS;
-        T* b = Bs + (size_t)buf * BN * RS;
-#pragma unroll
-        for (int it = 0; it < CFG::A_IT; ++it)
-            *reinterpret_cast<Vec16<T>*>(a + (size_t)(lrow + 32 * it) * RS + pc * VEC) = ra[it];
-#pragma unroll
-        for (int it = 0; it < CFG::B_IT; ++it) {
-            const int r = lrow + 32 * it;
-            if (r < BN) *reinterpret_cast<Vec16<T>*>(b + (size_t)r * RS + pc * VEC) = rb[it];
-        }
-    };
+    // ---- loader: this thread moves piece column `pc` of rows lrow + 32*it (see ConvLoader)
+    ConvLoader<CFG, T> ld;
+    ld.init(p, tid, m0, n0, M, Ktot);
 
     float16_t acc[CFG::MT][CFG::NTL];
 #pragma unroll
@@ -162,55 +255,44 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    fetch(0);
-    stash(0);
+    ld.fetch(p, 0);
+    ld.stash(As, Bs);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; kt < ((S2M2_CONV_DBG & 64) ? 0 : nkt); ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) fetch(kt + 1);                          // global loads in flight under the MFMAs
+        if (kt + 1 < nkt && !(S2M2_CONV_DBG & 1)) ld.fetch(p, kt + 1);   // global loads in flight under the MFMAs
         const T* a = As + (size_t)buf * BM * RS + (size_t)(wm * CFG::WM + (lane & 31)) * RS + (lane >> 5) * 8;
         const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + (lane & 31)) * RS + (lane >> 5) * 8;
 #pragma unroll
         for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
             Frag<T> xf[CFG::MT], wf[CFG::NTL];
 #pragma unroll
-            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * 32 * RS + kk * 16);
+            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], (S2M2_CONV_DBG & 8) ? a : a + (size_t)i * 32 * RS + kk * 16);
 #pragma unroll
-            for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], b + (size_t)j * 32 * RS + kk * 16);
+            for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], (S2M2_CONV_DBG & 8) ? b : b + (size_t)j * 32 * RS + kk * 16);
+            if (!(S2M2_CONV_DBG & 2)) {
 #pragma unroll
-            for (int i = 0; i < CFG::MT; ++i)
+                for (int i = 0; i < CFG::MT; ++i)
 #pragma unroll
-                for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
+                    for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
+            } else {
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CFG::NTL; ++j) acc[i][j][0] += to_f32(wf[j].v[0]) + to_f32(xf[i].v[0]);
+            }
         }
-        if (kt + 1 < nkt) stash(buf ^ 1);
+        if (kt + 1 < nkt && !(S2M2_CONV_DBG & 4)) ld.stash(As + (size_t)(buf ^ 1) * BM * RS, Bs + (size_t)(buf ^ 1) * BN * RS);
         __syncthreads();
     }
 
     // ---- epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]
-    const int hi = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < CFG::MT; ++i) {
-        T* crow = Cs + (size_t)(wm * CFG::WM + i * 32 + (lane & 31)) * CFG::CRS;
-#pragma unroll
-        for (int j = 0; j < CFG::NTL; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = wn * CFG::WN + j * 32 + 8 * g + 4 * hi;         // local cout of the quad
-                const int co = n0 + cl;
-                float4_t bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && co < p.Cout) bv = *reinterpret_cast<const float4_t*>(p.bias + co);
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = activate(acc[i][j][4 * g + e] + bv[e], p.act) * p.out_scale;
-                if constexpr (sizeof(T) == 2) {
-                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<half4_t*>(crow + cl) = h;
-                } else {
-                    float4_t f = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<float4_t*>(crow + cl) = f;
-                }
-            }
-        }
+    switch (p.act) {                                              // block-uniform
+        case S2M2_ACT_GELU: stage_tile<CFG, T, S2M2_ACT_GELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        case S2M2_ACT_RELU: stage_tile<CFG, T, S2M2_ACT_RELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        case S2M2_ACT_SIGMOID: stage_tile<CFG, T, S2M2_ACT_SIGMOID>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        case S2M2_ACT_TANH: stage_tile<CFG, T, S2M2_ACT_TANH>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        default: stage_tile<CFG, T, S2M2_ACT_NONE>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
     }
     __syncthreads();
 
@@ -252,8 +334,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
             const long long n = t / p.Ho;
             opix = (n * (2 * p.Ho) + 2 * y + (sub >> 1)) * (2LL * p.Wo) + 2 * x + (sub & 1);
         }
-        *reinterpret_cast<Vec16<T>*>(outp + opix * p.out_stride + oc) = v;
+        if (!(S2M2_CONV_DBG & 32)) *reinterpret_cast<Vec16<T>*>(outp + opix * p.out_stride + oc) = v;
     }
+}
+
+// 256 zero bytes, allocated on the first call (before any graph capture: the engine warms up eagerly)
+static const void* zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
+    }
+    return z;
 }
 
 template <typename T, int BM, int BN, int WGM>
@@ -279,7 +370,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     if (tile == 0) {                                              // heuristic: narrow N, else fill the chip
         if (a.Cout <= 32) tile = 3;
         else if (a.Cout <= 64) tile = 4;
-        else tile = ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 384 ? 1 : 2;
+        else tile = ((M + 63) / 64) * ((a.Cout + 63) / 64) > 6000 ? 1 : 2;     // 64x64 unless the grid is huge (measured, tools/convbench.py)
     }
     switch (tile) {
         case 1: return launch_conv<T, 128, 128, 2>(a, st);
@@ -297,8 +388,8 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     S2M2_REQUIRE(d, "conv2d: null descriptor");
     S2M2_REQUIRE(d->nsrc >= 1 && d->nsrc <= 4, "conv2d: nsrc=%d (1..4)", d->nsrc);
     S2M2_REQUIRE(d->weight && d->out, "conv2d: null weight/out");
-    S2M2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0, "conv2d: bad shape N=%d H=%d W=%d", d->N, d->H, d->W);
-    S2M2_REQUIRE((d->KH & 1) && (d->KW & 1) && d->KH <= 7 && d->KW <= 7, "conv2d: kernel %dx%d must be odd and <= 7", d->KH, d->KW);
+    S2M2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && (long long)d->N * d->H * d->W < (1LL << 24), "conv2d: bad shape (at most 2^24 pixels) N=%d H=%d W=%d", d->N, d->H, d->W);
+    S2M2_REQUIRE((d->KH & 1) && (d->KW & 1) && d->KH * d->KW <= 32, "conv2d: kernel %dx%d must be odd with at most 32 taps", d->KH, d->KW);
     S2M2_REQUIRE(d->Cout > 0 && d->Cout % 8 == 0, "conv2d: Cout=%d must be a positive multiple of 8", d->Cout);
     S2M2_REQUIRE(d->out_stride % 8 == 0, "conv2d: out_stride=%d must be a multiple of 8", d->out_stride);
     ConvArgs a;
@@ -311,6 +402,7 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
             S2M2_REQUIRE(d->src[s], "conv2d: src[%d] is null", s);
             S2M2_REQUIRE(d->src_c[s] > 0 && d->src_c[s] % 8 == 0 && d->src_stride[s] % 8 == 0 && d->src_stride[s] >= d->src_c[s],
                          "conv2d: src[%d] channels=%d stride=%d must be multiples of 8", s, d->src_c[s], d->src_stride[s]);
+            S2M2_REQUIRE((long long)d->N * d->H * d->W * d->src_stride[s] < (1LL << 31), "conv2d: src[%d] has 2^31 or more elements", s);
             a.Cin += d->src_c[s];
         }
     }
@@ -331,6 +423,8 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.act = d->act; a.epi = d->epi; a.aux0 = d->aux0; a.aux1 = d->aux1;
     a.aux0_stride = d->aux0_stride; a.aux1_stride = d->aux1_stride;
     a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2;
+    a.zero = zero_page();
+    S2M2_REQUIRE(a.zero, "conv2d: cannot allocate the zero page");
     a.stride = d->stride; a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->dtype == S2M2_F16) return dispatch_conv<half_t>(a, d->tile, st);

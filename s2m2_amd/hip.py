@@ -85,13 +85,17 @@ def _dev(*ts: torch.Tensor) -> None:
             raise ValueError("s2m2_amd.hip: tensors must be contiguous device tensors")
 
 
-def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype: Optional[torch.dtype] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w).  [A4]"""
     _dev(feat, ln_w, ln_b)
     twoB, h, w, C = feat.shape
     B = twoB // 2
     cv_dtype = cv_dtype or feat.dtype
-    cv = torch.empty((B, h, w, w), device=feat.device, dtype=cv_dtype)
+    cv = out if out is not None else torch.empty((B, h, w, w), device=feat.device, dtype=cv_dtype)
+    if tuple(cv.shape) != (B, h, w, w) or not cv.is_contiguous():
+        raise ValueError("ln_corr: out must be a contiguous (B,h,w,w) tensor")
+    cv_dtype = cv.dtype
     _check(load().s2m2_ln_corr(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
                                B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream()), "s2m2_ln_corr")
     return cv

@@ -10,6 +10,7 @@
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -46,6 +47,8 @@ class S2M2(nn.Module):
             node.register_parameter(leaf, nn.Parameter(torch.empty(shape), requires_grad=False))
         self.reset_parameters()
         self._engines: Dict[Tuple, "object"] = {}
+        self._graphs: Dict[Tuple, "object"] = {}
+        self._seen = set()
 
     # -- weights -------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -74,6 +77,8 @@ class S2M2(nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             self._engines.clear()                          # weights changed -> drop stale packed copies
+            self._graphs.clear()
+            self._seen.clear()
             eng = Engine(self, dtype)
             self._engines[key] = eng
         return eng
@@ -98,7 +103,20 @@ class S2M2(nn.Module):
         if img0.shape[-1] % 32 or img0.shape[-2] % 32:
             raise ValueError("image height and width must be multiples of 32 (pad with image_pad first)")
         with torch.autocast("cuda", enabled=False):
-            return self.engine(dtype).run(img0, img1, capture)
+            eng = self.engine(dtype)
+            if capture is not None or os.environ.get("S2M2_GRAPH", "1") == "0":
+                return eng.run(img0, img1, capture)
+            # hipGraph replay from the second call with the same geometry on (the first call runs eagerly and warms everything up)
+            key = (tuple(img0.shape), dtype, eng.k1_events is not None)
+            runner = self._graphs.get(key)
+            if runner is None:
+                if key not in self._seen:
+                    self._seen.add(key)
+                    return eng.run(img0, img1, None)
+                from .engine import GraphRunner
+                runner = GraphRunner(eng, img0.shape[0], img0.shape[2], img0.shape[3], split_k1=eng.k1_events is not None)
+                self._graphs[key] = runner
+            return runner(img0, img1)
 
 
 def build_model(model_type: str, use_positivity: bool = True, refine_iter: int = 3, output_upsample: bool = False) -> S2M2:
