@@ -139,9 +139,12 @@ int s2m2_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float*
  *   logits NHWC at the OUTPUT resolution, 9 used channels, rows padded to logit_stride >= 16 elements, dtype `dtype`;
  *   logit_up2 = 1 (output_upsample, s2m2.py:123-127): logits are (B, hs, ws, .) and bilinearly upsampled x2
  *   (align_corners=False, rounded to `dtype`) on the fly; factor must be 2.
+ *   chan_out != NULL: map 0 is also stored, in `dtype`, at chan_out[pixel * chan_stride] (the disparity input channel of
+ *   UpsampleMask1x, submodules.py:137, written straight into the 8-channel image tensor).
  */
 int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
-                         int logit_stride, int B, int hs, int ws, int factor, int logit_up2, int dtype, void* stream);
+                         int logit_stride, int B, int hs, int ws, int factor, int logit_up2, void* chan_out,
+                         long long chan_stride, int dtype, void* stream);
 
 /*
  * [A2,A3] multi-head attention softmax(Q K^T * scale) V, flash style (no score matrix in memory).  Replaces
@@ -165,6 +168,28 @@ int s2m2_attention(const void* q, const void* k, const void* v, void* out, long 
  */
 int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int C, long long x_stride, long long y_stride, int mode,
                     int dtype, void* stream);
+
+/*
+ * [A0,A7,A11,A13] fused per-pixel stages between the big kernels (each is a chain of separate elementwise kernels in PyTorch):
+ *   s2m2_image_prep     normalize_img (s2m2.py:80-89) + left/right concat (:143) + NHWC packing: img0, img1 (B,3,H,W) planar,
+ *                       img_dtype S2M2_F32 / S2M2_F16 / 2 (uint8), values in [0,255] -> x8 (2B,H,W,8) with channels 1..3 =
+ *                       (v/255 - 0.5)*2 and channels 0, 4..7 = 0 (channel 0 later carries the upsampled disparity, A15)
+ *   s2m2_refine_prep    mode 0 (GlobalRefiner, refinenet.py:63-68): small8[...,0] = disp/100*mask, [...,1] = logit(mask*conf, 0.1),
+ *                       mask = conf > 0.2;  mode 1 (LocalRefiner, :134-141): disp/100, logit(conf, 0.01), logit(occ, 0.01)
+ *   s2m2_global_update  out = mask*disp + (1-mask)*upd*100 [clamped at 0]  (refinenet.py:70-71, s2m2.py:160-161); upd = channel 0
+ *                       of an NHWC tensor with pixel stride upd_stride
+ *   s2m2_refine_update  in place: disp += dco[0]; conf = sigmoid(dco[8] + logit(conf, .01)); occ likewise with dco[9]
+ *                       (refinenet.py:149-151); then clamp disp at 0 if use_positivity and occ *= (x - disp >= 0) (s2m2.py:177-180)
+ *   s2m2_tanh           y = tanh(x) on n elements (hidden = tanh(ctx), s2m2.py:166)
+ *   disp, conf, occ, out: (B,h,w) fp32.
+ */
+int s2m2_image_prep(const void* img0, const void* img1, void* x8, int B, int H, int W, int img_dtype, int dtype, void* stream);
+int s2m2_refine_prep(const float* disp, const float* conf, const float* occ, void* small8, long long npix, int mode, int dtype, void* stream);
+int s2m2_global_update(const void* upd, int upd_stride, const float* disp, const float* conf, float* out, long long npix, int clamp0,
+                       int dtype, void* stream);
+int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf, float* occ, long long npix, int w, int use_positivity,
+                       int dtype, void* stream);
+int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

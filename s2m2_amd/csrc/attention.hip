@@ -33,8 +33,9 @@ struct AttnArgs {
     const float* px; const float* py; void* pe_out; long long spe; int gw, gh;
 };
 
-template <typename T, int DP_, bool PE_>
+template <typename T, int DP_, bool PE_, int MINW_ = 4>
 struct AttnCfg {
+    static constexpr int MINW = MINW_;                   // fewest waves a block is launched with (sizes the staging registers)
     static constexpr int DP = DP_;                       // head dim rounded up to a multiple of 16
     static constexpr bool PE = PE_;
     static constexpr int VEC = 16 / sizeof(T);
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     // ---- staging assignment
     // K tile: 32 rows x KP pieces.   V tile: 8 key groups (4 keys) x KP pieces -> transposed quads.
     constexpr int K_TASKS = 32 * KP, V_TASKS = 8 * KP;
-    constexpr int K_IT_MAX = (K_TASKS + 255) / 256, V_IT_MAX = (V_TASKS + 255) / 256;   // blocks have >= 4 waves (launch_attn)
+    constexpr int MINT = 64 * CFG::MINW;                        // blocks have >= MINW waves (launch_attn)
+    constexpr int K_IT_MAX = (K_TASKS + MINT - 1) / MINT, V_IT_MAX = (V_TASKS + MINT - 1) / MINT;
     Vec16<T> rk[K_IT_MAX];
     Vec16<T> rv[V_IT_MAX][4];
     auto zero16 = []() { Vec16<T> z;
@@ -327,9 +329,9 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int DP, bool PE>
-static int launch_attn(const AttnArgs& a, hipStream_t st) {
-    using CFG = AttnCfg<T, DP, PE>;
+template <typename T, int DP, bool PE, int MINW>
+static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
+    using CFG = AttnCfg<T, DP, PE, MINW>;
     auto kern = attention_kernel<CFG, T>;
     size_t lds = CFG::K_BYTES + CFG::V_BYTES;
     if (PE) lds += (size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 * sizeof(float);
@@ -341,11 +343,25 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         attr_bytes = lds;
     }
     const int ntq = (a.Nq + 31) / 32;
-    const int nblk = (ntq + CFG::MAXW - 1) / CFG::MAXW;
-    int nw = (ntq + nblk - 1) / nblk;                              // <= 8 waves, minimal idle tail
-    nw = nw < 4 ? 4 : nw;                                          // >= 4 waves: the staging loops assume >= 256 threads
+    const int nblk = (ntq + nw - 1) / nw;
     hipLaunchKernelGGL(kern, dim3(nblk, a.nb * a.heads), dim3(nw * 64), lds, st, a);
     return check_launch("attention");
+}
+
+template <typename T, int DP, bool PE>
+static int launch_attn(const AttnArgs& a, hipStream_t st) {
+    constexpr int MAXW = AttnCfg<T, DP, PE>::MAXW;
+    const int ntq = (a.Nq + 31) / 32;
+    const int bh = a.nb * a.heads;
+    int nblk = (ntq + MAXW - 1) / MAXW;
+    int nw = (ntq + nblk - 1) / nblk;                              // <= MAXW waves per block, minimal idle tail
+    if constexpr (DP <= 64) {
+        // few (batch, head) pairs (the 2-D global blocks at 1/32): smaller blocks until the grid covers the chip; every block
+        // re-stages K/V from L2, which is cheap next to an idle GPU
+        while (nw > 1 && (long long)((ntq + nw - 1) / nw) * bh < 512) nw = (nw + 1) / 2;
+        if (nw < 4) return launch_attn_w<T, DP, PE, 1>(a, nw, st);
+    }
+    return launch_attn_w<T, DP, PE, 4>(a, nw < 4 ? 4 : nw, st);
 }
 
 template <typename T, bool PE>

@@ -1,0 +1,166 @@
+// K8 -- the small per-pixel stages between the big kernels of the forward, each fused into ONE launch (PyTorch runs every line
+// of them as its own elementwise kernel: ~340 launches and ~1.2 ms per 1216x1024 pair, profiles/r01):
+//   image_prep     normalize_img + left/right concat + NHWC/8-channel packing       (s2m2.py:80-89,140-143)
+//   refine_prep    side inputs of GlobalRefiner / LocalRefiner                      (refinenet.py:63-68, 134-141)
+//   global_update  disp = mask*disp + (1-mask)*update*100 [, clamp]                 (refinenet.py:70-71, s2m2.py:160-161)
+//   refine_update  disp += d; conf/occ = sigmoid(d + logit); clamp; occ mask        (refinenet.py:149-151, s2m2.py:177-180)
+//   unary          tanh of the context features (hidden state init)                 (s2m2.py:166)
+// All maps are (B,h,w) fp32; "small" side inputs are (B,h,w,8) NHWC in the activation dtype with unused channels zero.
+#include "common.h"
+
+namespace s2m2 {
+
+__device__ __forceinline__ float logit_eps(float p, float eps) {
+    p = fminf(fmaxf(p, eps), 1.0f - eps);
+    return logf(p / (1.0f - p));
+}
+
+template <typename TI, typename T>
+__global__ __launch_bounds__(256) void image_prep_kernel(const TI* __restrict__ img0, const TI* __restrict__ img1, T* __restrict__ x8,
+                                                         int B, long long HW) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= 2LL * B * HW) return;
+    const long long n = gid / HW, pix = gid - n * HW;
+    const TI* src = (n < B ? img0 + n * 3 * HW : img1 + (n - B) * 3 * HW) + pix;
+    alignas(16) T o[8];
+    o[0] = from_f32<T>(0.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[1 + c] = from_f32<T>(((float)src[c * HW] / 255.0f - 0.5f) * 2.0f);
+#pragma unroll
+    for (int c = 4; c < 8; ++c) o[c] = from_f32<T>(0.f);
+    T* dst = x8 + gid * 8;
+    if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<Vec16<T>*>(dst) = *reinterpret_cast<Vec16<T>*>(o);
+    } else {
+        *reinterpret_cast<Vec16<T>*>(dst) = *reinterpret_cast<Vec16<T>*>(o);
+        *reinterpret_cast<Vec16<T>*>(dst + 4) = *reinterpret_cast<Vec16<T>*>(o + 4);
+    }
+}
+
+// mode 0 (global refiner): ch0 = disp/100*mask, ch1 = logit(mask*conf, 0.1), mask = conf > 0.2
+// mode 1 (local refiner):  ch0 = disp/100, ch1 = logit(conf, 0.01), ch2 = logit(occ, 0.01)
+template <typename T>
+__global__ __launch_bounds__(256) void refine_prep_kernel(const float* __restrict__ disp, const float* __restrict__ conf,
+                                                          const float* __restrict__ occ, T* __restrict__ small, long long n, int mode) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    float v0, v1, v2 = 0.f;
+    if (mode == 0) {
+        const float c = conf[gid];
+        const float mask = c > 0.2f ? 1.0f : 0.0f;
+        v0 = disp[gid] / 1e2f * mask;
+        v1 = logit_eps(mask * c, 1e-1f);
+    } else {
+        v0 = disp[gid] / 1e2f;
+        v1 = logit_eps(conf[gid], 1e-2f);
+        v2 = logit_eps(occ[gid], 1e-2f);
+    }
+    T* d = small + gid * 8;
+    d[0] = from_f32<T>(v0); d[1] = from_f32<T>(v1); d[2] = from_f32<T>(v2);
+#pragma unroll
+    for (int c = 3; c < 8; ++c) d[c] = from_f32<T>(0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void global_update_kernel(const T* __restrict__ upd, int upd_stride, const float* __restrict__ disp,
+                                                            const float* __restrict__ conf, float* __restrict__ out, long long n, int clamp0) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    const float mask = conf[gid] > 0.2f ? 1.0f : 0.0f;
+    float d = mask * disp[gid] + (1.0f - mask) * (to_f32(upd[gid * upd_stride]) * 1e2f);
+    if (clamp0) d = fmaxf(d, 0.f);
+    out[gid] = d;
+}
+
+// dco: (.., stride) with channel 0 = disparity delta, channels 8, 9 = confidence / occlusion logit deltas
+template <typename T>
+__global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict__ dco, int stride, float* __restrict__ disp,
+                                                            float* __restrict__ conf, float* __restrict__ occ, long long n, int w, int use_pos) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n) return;
+    const T* r = dco + gid * stride;
+    float d = disp[gid] + to_f32(r[0]);
+    const float c = 1.0f / (1.0f + expf(-(to_f32(r[8]) + logit_eps(conf[gid], 1e-2f))));
+    float o = 1.0f / (1.0f + expf(-(to_f32(r[9]) + logit_eps(occ[gid], 1e-2f))));
+    if (use_pos) d = fmaxf(d, 0.f);
+    const float x = (float)(gid % w);
+    o = (x - d >= 0.f) ? o : 0.f;
+    disp[gid] = d; conf[gid] = c; occ[gid] = o;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_kernel(const T* __restrict__ x, T* __restrict__ y, long long npieces) {
+    constexpr int VEC = 16 / sizeof(T);
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= npieces) return;
+    const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + gid * VEC);
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(tanhf(to_f32(v.v[e])));
+    *reinterpret_cast<Vec16<T>*>(y + gid * VEC) = o;
+}
+
+static inline dim3 grid1(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace s2m2
+
+extern "C" int s2m2_image_prep(const void* img0, const void* img1, void* x8, int B, int H, int W, int img_dtype, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(img0 && img1 && x8 && B > 0 && H > 0 && W > 0, "image_prep: bad arguments");
+    const long long HW = (long long)H * W, n = 2LL * B * HW;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // img_dtype: S2M2_F32 / S2M2_F16 / 2 = uint8
+    #define S2M2_IP(TI, T) hipLaunchKernelGGL((image_prep_kernel<TI, T>), grid1(n), dim3(256), 0, st, (const TI*)img0, (const TI*)img1, (T*)x8, B, HW)
+    if (dtype == S2M2_F16) {
+        if (img_dtype == S2M2_F32) S2M2_IP(float, half_t); else if (img_dtype == S2M2_F16) S2M2_IP(half_t, half_t);
+        else if (img_dtype == 2) S2M2_IP(unsigned char, half_t); else return set_error("image_prep: unsupported image dtype %d", img_dtype);
+    } else if (dtype == S2M2_F32) {
+        if (img_dtype == S2M2_F32) S2M2_IP(float, float); else if (img_dtype == S2M2_F16) S2M2_IP(half_t, float);
+        else if (img_dtype == 2) S2M2_IP(unsigned char, float); else return set_error("image_prep: unsupported image dtype %d", img_dtype);
+    } else return set_error("image_prep: unsupported dtype %d", dtype);
+    #undef S2M2_IP
+    return check_launch("image_prep");
+}
+
+extern "C" int s2m2_refine_prep(const float* disp, const float* conf, const float* occ, void* small8, long long npix, int mode, int dtype,
+                                void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(disp && conf && small8 && npix > 0 && (mode == 0 || (mode == 1 && occ)), "refine_prep: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == S2M2_F16) hipLaunchKernelGGL((refine_prep_kernel<half_t>), grid1(npix), dim3(256), 0, st, disp, conf, occ, (half_t*)small8, npix, mode);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((refine_prep_kernel<float>), grid1(npix), dim3(256), 0, st, disp, conf, occ, (float*)small8, npix, mode);
+    else return set_error("refine_prep: unsupported dtype %d", dtype);
+    return check_launch("refine_prep");
+}
+
+extern "C" int s2m2_global_update(const void* upd, int upd_stride, const float* disp, const float* conf, float* out, long long npix,
+                                  int clamp0, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(upd && disp && conf && out && npix > 0 && upd_stride > 0, "global_update: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == S2M2_F16) hipLaunchKernelGGL((global_update_kernel<half_t>), grid1(npix), dim3(256), 0, st, (const half_t*)upd, upd_stride, disp, conf, out, npix, clamp0);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((global_update_kernel<float>), grid1(npix), dim3(256), 0, st, (const float*)upd, upd_stride, disp, conf, out, npix, clamp0);
+    else return set_error("global_update: unsupported dtype %d", dtype);
+    return check_launch("global_update");
+}
+
+extern "C" int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf, float* occ, long long npix, int w,
+                                  int use_positivity, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(dco && disp && conf && occ && npix > 0 && w > 0 && dco_stride >= 10, "refine_update: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == S2M2_F16) hipLaunchKernelGGL((refine_update_kernel<half_t>), grid1(npix), dim3(256), 0, st, (const half_t*)dco, dco_stride, disp, conf, occ, npix, w, use_positivity);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((refine_update_kernel<float>), grid1(npix), dim3(256), 0, st, (const float*)dco, dco_stride, disp, conf, occ, npix, w, use_positivity);
+    else return set_error("refine_update: unsupported dtype %d", dtype);
+    return check_launch("refine_update");
+}
+
+extern "C" int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(x && y && n > 0 && n % 8 == 0, "tanh: bad arguments (n must be a multiple of 8)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == S2M2_F16) hipLaunchKernelGGL((tanh_kernel<half_t>), grid1(n / 8), dim3(256), 0, st, (const half_t*)x, (half_t*)y, n / 8);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((tanh_kernel<float>), grid1(n / 4), dim3(256), 0, st, (const float*)x, (float*)y, n / 4);
+    else return set_error("tanh: unsupported dtype %d", dtype);
+    return check_launch("tanh");
+}

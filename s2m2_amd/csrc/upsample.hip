@@ -16,6 +16,8 @@ struct UpArgs {
     float scale[3];
     const void* logits;
     int nmaps, logit_stride, B, hs, ws, factor, logit_up2;
+    void* chan_out;            // optional: map 0 also stored in the activation dtype at chan_out[gid * chan_stride]
+    long long chan_stride;
 };
 
 template <typename T>
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(UpArgs a) {
 #pragma unroll
         for (int n = 0; n < 9; ++n) acc += xm[(long long)yy[n / 3] * a.ws + xx[n % 3]] * (l[n] * inv);
         a.out[m][gid] = acc * a.scale[m];
+        if (m == 0 && a.chan_out) static_cast<T*>(a.chan_out)[gid * a.chan_stride] = from_f32<T>(acc * a.scale[0]);
     }
 }
 
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(256) void resample2x_kernel(const T* __restrict__ x
 }  // namespace s2m2
 
 extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
-                                    int logit_stride, int B, int hs, int ws, int factor, int logit_up2, int dtype, void* stream) {
+                                    int logit_stride, int B, int hs, int ws, int factor, int logit_up2, void* chan_out,
+                                    long long chan_stride, int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(x && out && logits && scale, "convex_upsample: null pointer");
     S2M2_REQUIRE(nmaps >= 1 && nmaps <= 3, "convex_upsample: nmaps=%d (1..3)", nmaps);
@@ -149,6 +153,7 @@ extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, co
     }
     a.logits = logits; a.nmaps = nmaps; a.logit_stride = logit_stride; a.B = B; a.hs = hs; a.ws = ws; a.factor = factor;
     a.logit_up2 = logit_up2;
+    a.chan_out = chan_out; a.chan_stride = chan_stride;
     const long long total = (long long)B * hs * factor * ws * factor;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid((unsigned)((total + 255) / 256));

@@ -228,17 +228,12 @@ class Engine:
 
     # ---- refiners ------------------------------------------------------------------------------------
     def global_refiner(self, p: str, ctx: Tensor, disp: Tensor, conf: Tensor) -> Tensor:
-        """GlobalRefiner (refinenet.py:39-73); disp, conf (B,1,h,w) fp32."""
-        B, _, h, w = disp.shape
-        mask = (conf > 0.2).float()
-        small = self.zeros("gr_small", (B, h, w, 8))
-        small[..., 0] = (disp / 1e2 * mask)[:, 0]
-        small[..., 1] = torch.logit(mask * conf, eps=1e-1)[:, 0]
+        """GlobalRefiner (refinenet.py:39-73) + the clamp of s2m2.py:160-161; disp, conf (B,1,h,w) fp32."""
+        small = hip.refine_prep(disp, conf, None, 0, self.dtype)
         f = self.cconv(self.std(p + ".init_feat.0", splits=[(2, 8), (self.C, self.C)]), [small, ctx], act=hip.ACT_GELU)
         f = self.cconv(self.std(p + ".init_feat.2"), [f])
         f = self.unet(p + ".refine_unet", f)[0]
-        upd = self.cconv(self.std(p + ".out_feat.0"), [f])[..., 0].float().unsqueeze(1) * 1e2
-        return mask * disp + (1 - mask) * upd
+        return hip.global_update(self.cconv(self.std(p + ".out_feat.0"), [f]), disp, conf, self.use_positivity)
 
     def gru(self, p: str, h: Tensor, x: Tensor) -> Tensor:
         """ConvGRU (refinenet.py:7-36): two separable passes; the gate arithmetic lives in the conv epilogues."""
@@ -249,11 +244,9 @@ class Engine:
         return h
 
     def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it):
-        """LocalRefiner.forward (refinenet.py:126-154)."""
+        """LocalRefiner.forward (refinenet.py:126-154) + the loop epilogue of s2m2.py:177-180 (clamp, occlusion mask)."""
         B, _, h, w = disp.shape
         C = self.C
-        cl = torch.logit(conf, eps=1e-2)
-        ol = torch.logit(occ, eps=1e-2)
         corr = self.zeros("lr_corr", (B, h, w, 32))
         hip.cv_lookup_into(cv, disp.contiguous(), corr, 0, 16, 4)                                        # K3
         if cap is not None:
@@ -262,10 +255,7 @@ class Engine:
         cf = self.cconv(self.merged(p + "|corrA", [(p + ".corr_feat1.0", 0, 1 / 16, False), (p + ".corr_feat2.0", 16, 1 / 16, False)], 32),
                         [corr], act=hip.ACT_GELU)
         f12 = self.cconv(self.merged(p + "|corrB", [(p + ".corr_feat1.2", 0, 1.0, False), (p + ".corr_feat2.2", 96, 1.0, False)], 192), [cf])
-        small = self.zeros("lr_small", (B, h, w, 8))
-        small[..., 0] = (disp / 1e2)[:, 0]
-        small[..., 1] = cl[:, 0]
-        small[..., 2] = ol[:, 0]
+        small = hip.refine_prep(disp, conf, occ, 1, self.dtype)
         dc = self.cconv(self.merged(p + "|dcA", [(p + ".disp_feat.0", 0, 1.0, False), (p + ".conf_occ_feat.0", 1, 1.0, False)], 8),
                         [small], act=hip.ACT_GELU)
         fd = self.cconv(self.std(p + ".disp_feat.2"), [dc[..., :96]])
@@ -277,9 +267,8 @@ class Engine:
         u = self.cconv(self.merged(p + "|updA", [(p + ".disp_update.0", 0, 1.0, False), (p + ".conf_occ_update.0", 0, 1.0, False)], C),
                        [hn], act=hip.ACT_GELU)
         dco = self.cconv(self.merged(p + "|updB", [(p + ".disp_update.2", 0, 1.0, False), (p + ".conf_occ_update.2", C, 1.0, False)], 2 * C),
-                         [u]).float()
-        dd = dco[..., 0].unsqueeze(1)
-        return hn, disp + dd, torch.sigmoid(dco[..., 8].unsqueeze(1) + cl), torch.sigmoid(dco[..., 9].unsqueeze(1) + ol)
+                         [u])
+        return (hn,) + hip.refine_update(dco, disp, conf, occ, self.use_positivity)
 
     # ---- upsampling masks ----------------------------------------------------------------------------
     def mask4x(self, p: str, hidden: Tensor, f2x: Tensor) -> Tensor:
@@ -291,10 +280,9 @@ class Engine:
         s2, c2 = self.convT2(p + ".conv_concat.2")
         return self.cconv(s2, [y], shuffle2=c2)
 
-    def mask1x(self, p: str, disp_up: Tensor, rgb8: Tensor, f2x: Tensor) -> Tensor:
-        """UpsampleMask1x (submodules.py:118-145) -> logits (B,H,W,16), 9 used.  rgb8: (B,H,W,8) normalised image in channels 1..3,
-        channel 0 receives the upsampled disparity."""
-        rgb8[..., 0] = disp_up[:, 0].to(self.dtype)
+    def mask1x(self, p: str, rgb8: Tensor, f2x: Tensor) -> Tensor:
+        """UpsampleMask1x (submodules.py:118-145) -> logits (B,H,W,16), 9 used.  rgb8: (B,H,W,8) with the x4-upsampled disparity in
+        channel 0 (written by K7) and the normalised image in channels 1..3."""
         ab = self.cconv(self.merged(p + "|dispRgb", [(p + ".conv_disp.0", 0, 1.0, True), (p + ".conv_rgb.0", 1, 1.0, True)], 8),
                         [rgb8], act=hip.ACT_RELU)
         sc, cc = self.convT2(p + ".conv_ctx")
@@ -306,12 +294,8 @@ class Engine:
     @torch.no_grad()
     def features(self, img0: Tensor, img1: Tensor):
         """normalise -> CNN backbone -> feature pyramid -> multi-resolution transformer (s2m2.py:140-150)."""
-        dt = self.dtype
-        B, _, H, W = img0.shape
-        x = torch.cat([img0, img1], 0).to(torch.float32)
-        x = ((x / 255.0 - 0.5) * 2).to(dt)
-        x8 = torch.zeros((2 * B, H, W, 8), device=x.device, dtype=dt)          # channels 1..3 = normalised RGB (0 is free, see mask1x)
-        x8[..., 1:4] = x.permute(0, 2, 3, 1)
+        B = img0.shape[0]
+        x8 = hip.image_prep(img0, img1, self.dtype)                             # (2B,H,W,8): channels 1..3 = normalised RGB, 0 free
         p = "cnn_backbone"                                                      # CNNEncoder (submodules.py:63-93)
         t = self.cconv(self._conv0(), [x8], act=hip.ACT_GELU)
         t = self.cconv(self.std(p + ".conv0.2"), [t])
@@ -342,25 +326,18 @@ class Engine:
                        disp0=disp, conf0=conf, occ0=occ)
         tr0 = tr[:B]
         disp = self.global_refiner("global_refiner", tr0, disp, conf)
-        if self.use_positivity:
-            disp = disp.clamp(min=0)
         if cap is not None:
             cap["disp_g"] = disp
         fus = self.fusion("feat_fusion_layer", tr0, py0[:B])
         ctx = self.cconv(self.std("ctx_feat.2"), [self.cconv(self.std("ctx_feat.0"), [fus], act=hip.ACT_GELU)])
-        hidden = torch.tanh(ctx)
-        w = disp.shape[-1]
-        xs = torch.arange(w, device=disp.device, dtype=torch.float32).reshape(1, 1, 1, w)
+        hidden = hip.tanh(ctx)
         for it in range(self.refine_iter):
             hidden, disp, conf, occ = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, cap, it)
-            if self.use_positivity:
-                disp = disp.clamp(min=0)
-            occ = occ * (xs - disp >= 0)
             if cap is not None:
                 cap[f"disp_it{it}"], cap[f"conf_it{it}"], cap[f"occ_it{it}"] = disp, conf, occ
         m4 = self.mask4x("upsample_mask_4x_refine", hidden, f2_left)
-        d_up, o_up, c_up = hip.convex_upsample([disp, occ, conf], m4, 4, scales=[4.0, 1.0, 1.0])
-        m1 = self.mask1x("upsample_mask_1x", d_up, x8, f2_left)
+        d_up, o_up, c_up = hip.convex_upsample([disp, occ, conf], m4, 4, scales=[4.0, 1.0, 1.0], chan_out=x8[..., 0])
+        m1 = self.mask1x("upsample_mask_1x", x8, f2_left)
         up = self.output_upsample
         return tuple(hip.convex_upsample([d_up, o_up, c_up], m1, 2 if up else 1, scales=[2.0 if up else 1.0, 1.0, 1.0], logit_up2=up))
 

@@ -44,10 +44,15 @@ SIGNATURES = {
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
-    "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _ll, _i, _vp]),
     "s2m2_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _ll,
                             _i, _i, _i, _vp]),
     "s2m2_resample2x": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _i, _vp]),
+    "s2m2_image_prep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "s2m2_refine_prep": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "s2m2_global_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
+    "s2m2_refine_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "s2m2_tanh": (_i, [_vp, _vp, _ll, _i, _vp]),
     "s2m2_layernorm": (_i, [_vp, _vp, _ll, _i, _ll, _ll, _i, _vp]),
     "s2m2_groupnorm_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "s2m2_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, ctypes.c_float, _i, _vp]),
@@ -223,8 +228,10 @@ def groupnorm_nhwc(x: torch.Tensor, groups: int, gamma: torch.Tensor, beta: torc
     return out
 
 
-def convex_upsample(maps, logits: torch.Tensor, factor: int, scales=None, logit_up2: bool = False):
-    """maps: list of (B,1,hs,ws) or (B,hs,ws) fp32 tensors; logits (B,Ho,Wo,>=16) NHWC (9 used).  -> list of (B,1,Ho,Wo) fp32."""
+def convex_upsample(maps, logits: torch.Tensor, factor: int, scales=None, logit_up2: bool = False,
+                    chan_out: Optional[torch.Tensor] = None):
+    """maps: list of (B,1,hs,ws) or (B,hs,ws) fp32 tensors; logits (B,Ho,Wo,>=16) NHWC (9 used).  -> list of (B,1,Ho,Wo) fp32.
+    chan_out: optional (B,Ho,Wo) view (one channel of an NHWC tensor, dense pixels) that also receives map 0 in its dtype."""
     B, hs, ws = maps[0].shape[0], maps[0].shape[-2], maps[0].shape[-1]
     n = len(maps)
     maps = [m.float().contiguous() for m in maps]
@@ -238,8 +245,12 @@ def convex_upsample(maps, logits: torch.Tensor, factor: int, scales=None, logit_
     xp = (_vp * n)(*[m.data_ptr() for m in maps])
     op = (_vp * n)(*[o.data_ptr() for o in outs])
     sc = (ctypes.c_float * n)(*[float(v) for v in (scales or [1.0] * n)])
+    if chan_out is not None and (chan_out.dtype != logits.dtype or tuple(chan_out.shape) != (B, Ho, Wo)):
+        raise ValueError("convex_upsample: chan_out must be a (B,Ho,Wo) channel view in the logits dtype")
     _check(load().s2m2_convex_upsample(xp, op, sc, n, logits.data_ptr(), ls, B, hs, ws, factor, int(logit_up2),
-                                       _DT[logits.dtype], _stream()), "s2m2_convex_upsample")
+                                       chan_out.data_ptr() if chan_out is not None else None,
+                                       chan_out.stride(2) if chan_out is not None else 0, _DT[logits.dtype], _stream()),
+           "s2m2_convex_upsample")
     return outs
 
 
@@ -287,3 +298,54 @@ def cv_lookup_into(cv: torch.Tensor, disp: torch.Tensor, buf: torch.Tensor, off1
     es = buf.element_size()
     _check(load().s2m2_cv_lookup(cv.data_ptr(), disp.data_ptr(), buf.data_ptr() + off1 * es, buf.data_ptr() + off2 * es, B, h, w,
                                  radius, _DT[cv.dtype], _DT[buf.dtype], h * w * cb, cb, 1, _stream()), "s2m2_cv_lookup")
+
+
+_IMG_DT = {torch.float32: 0, torch.float16: 1, torch.uint8: 2}
+
+
+def image_prep(img0: torch.Tensor, img1: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """img0, img1 (B,3,H,W) fp32 / fp16 / uint8 in [0,255] -> x8 (2B,H,W,8): channels 1..3 = normalised RGB, others 0."""
+    if img0.dtype not in _IMG_DT:
+        img0 = img0.float()
+    img1 = img1.to(img0.dtype)
+    img0, img1 = img0.contiguous(), img1.contiguous()
+    _dev(img0, img1)
+    B, _, H, W = img0.shape
+    x8 = torch.empty((2 * B, H, W, 8), device=img0.device, dtype=dtype)
+    _check(load().s2m2_image_prep(img0.data_ptr(), img1.data_ptr(), x8.data_ptr(), B, H, W, _IMG_DT[img0.dtype], _DT[dtype], _stream()),
+           "s2m2_image_prep")
+    return x8
+
+
+def refine_prep(disp: torch.Tensor, conf: torch.Tensor, occ: Optional[torch.Tensor], mode: int, dtype: torch.dtype) -> torch.Tensor:
+    """(B,1,h,w) fp32 maps -> (B,h,w,8) side input of the global (mode 0) / local (mode 1) refiner."""
+    _dev(disp, conf, occ)
+    B, _, h, w = disp.shape
+    out = torch.empty((B, h, w, 8), device=disp.device, dtype=dtype)
+    _check(load().s2m2_refine_prep(disp.data_ptr(), conf.data_ptr(), occ.data_ptr() if occ is not None else None, out.data_ptr(),
+                                   B * h * w, mode, _DT[dtype], _stream()), "s2m2_refine_prep")
+    return out
+
+
+def global_update(upd: torch.Tensor, disp: torch.Tensor, conf: torch.Tensor, clamp0: bool) -> torch.Tensor:
+    """upd (B,h,w,C>=1) NHWC (channel 0 used), disp/conf (B,1,h,w) fp32 -> refined disparity (B,1,h,w) fp32."""
+    _dev(disp, conf)
+    out = torch.empty_like(disp)
+    _check(load().s2m2_global_update(upd.data_ptr(), _nhwc(upd), disp.data_ptr(), conf.data_ptr(), out.data_ptr(), disp.numel(),
+                                     int(clamp0), _DT[upd.dtype], _stream()), "s2m2_global_update")
+    return out
+
+
+def refine_update(dco: torch.Tensor, disp: torch.Tensor, conf: torch.Tensor, occ: torch.Tensor, use_positivity: bool):
+    """dco (B,h,w,>=10) NHWC deltas; disp/conf/occ (B,1,h,w) fp32 -> new (disp, conf, occ) (fresh tensors)."""
+    disp, conf, occ = disp.clone(), conf.clone(), occ.clone()
+    _check(load().s2m2_refine_update(dco.data_ptr(), _nhwc(dco), disp.data_ptr(), conf.data_ptr(), occ.data_ptr(), disp.numel(),
+                                     disp.shape[-1], int(use_positivity), _DT[dco.dtype], _stream()), "s2m2_refine_update")
+    return disp, conf, occ
+
+
+def tanh(x: torch.Tensor) -> torch.Tensor:
+    _dev(x)
+    y = torch.empty_like(x)
+    _check(load().s2m2_tanh(x.data_ptr(), y.data_ptr(), x.numel(), _DT[x.dtype], _stream()), "s2m2_tanh")
+    return y

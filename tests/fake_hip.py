@@ -85,7 +85,7 @@ def make():
         ps = torch.einsum("bhij,ijc->bhic", a, dense).transpose(1, 2).reshape(nb, N, heads * 32).to(q.dtype)
         return o, ps
 
-    def convex_upsample(maps, logits, factor, scales=None, logit_up2=False):
+    def convex_upsample(maps, logits, factor, scales=None, logit_up2=False, chan_out=None):
         lg = logits[..., :9].float().permute(0, 3, 1, 2)
         if logit_up2:
             lg = F.interpolate(lg, scale_factor=2, mode="bilinear", align_corners=False)
@@ -99,8 +99,47 @@ def make():
             if factor > 1:
                 n9 = F.interpolate(n9, scale_factor=factor, mode="nearest")
             outs.append((n9 * wgt).sum(1, keepdim=True) * s)
+        if chan_out is not None:
+            chan_out.copy_(outs[0][:, 0].to(chan_out.dtype))
         return outs
 
-    for f in (ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample):
+    def image_prep(img0, img1, dtype):
+        x = torch.cat([img0, img1], 0).float()
+        x8 = torch.zeros(x.shape[0], x.shape[2], x.shape[3], 8, dtype=dtype)
+        x8[..., 1:4] = ((x / 255.0 - 0.5) * 2).permute(0, 2, 3, 1).to(dtype)
+        return x8
+
+    def refine_prep(disp, conf, occ, mode, dtype):
+        B, _, h, w = disp.shape
+        small = torch.zeros(B, h, w, 8, dtype=dtype)
+        if mode == 0:
+            mask = (conf > 0.2).float()
+            small[..., 0] = (disp / 1e2 * mask)[:, 0]
+            small[..., 1] = torch.logit(mask * conf, eps=1e-1)[:, 0]
+        else:
+            small[..., 0] = (disp / 1e2)[:, 0]
+            small[..., 1] = torch.logit(conf, eps=1e-2)[:, 0]
+            small[..., 2] = torch.logit(occ, eps=1e-2)[:, 0]
+        return small
+
+    def global_update(upd, disp, conf, clamp0):
+        mask = (conf > 0.2).float()
+        d = mask * disp + (1 - mask) * (upd[..., 0].float().unsqueeze(1) * 1e2)
+        return d.clamp(min=0) if clamp0 else d
+
+    def refine_update(dco, disp, conf, occ, use_positivity):
+        dco = dco.float()
+        d = disp + dco[..., 0].unsqueeze(1)
+        c = torch.sigmoid(dco[..., 8].unsqueeze(1) + torch.logit(conf, eps=1e-2))
+        o = torch.sigmoid(dco[..., 9].unsqueeze(1) + torch.logit(occ, eps=1e-2))
+        if use_positivity:
+            d = d.clamp(min=0)
+        xs = torch.arange(d.shape[-1], dtype=torch.float32).reshape(1, 1, 1, -1)
+        return d, c, o * (xs - d >= 0)
+
+    def tanh(x):
+        return torch.tanh(x)
+
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample):
         setattr(ns, f.__name__, f)
     return ns

@@ -91,3 +91,47 @@ def test_resample2x(hip, dtype, mode):
     xn = x.float().permute(0, 3, 1, 2)
     ref = F.avg_pool2d(xn, 2) if mode == 0 else F.interpolate(xn, scale_factor=2, mode="bilinear", align_corners=False)
     assert float((y.float() - ref.permute(0, 2, 3, 1)).abs().max()) < (1e-6 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("img_dtype", [torch.float32, torch.uint8])
+def test_image_prep(hip, dtype, img_dtype):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randint(0, 256, (2, 3, 18, 26), device="cuda", generator=g).to(img_dtype)
+    b = torch.randint(0, 256, (2, 3, 18, 26), device="cuda", generator=g).to(img_dtype)
+    x8 = hip.image_prep(a, b, dtype)
+    ref = ((torch.cat([a, b]).float() / 255.0 - 0.5) * 2).permute(0, 2, 3, 1)
+    assert tuple(x8.shape) == (4, 18, 26, 8)
+    assert float((x8[..., 1:4].float() - ref).abs().max()) < (1e-6 if dtype == torch.float32 else 1e-3)
+    assert float(x8[..., 0].abs().max()) == 0 and float(x8[..., 4:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_refiner_pointwise_stages(hip, dtype):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    B, h, w = 2, 11, 17
+    disp = torch.rand(B, 1, h, w, device="cuda", generator=g) * 40 - 2
+    conf = torch.rand(B, 1, h, w, device="cuda", generator=g)
+    occ = torch.rand(B, 1, h, w, device="cuda", generator=g)
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    s0 = hip.refine_prep(disp, conf, None, 0, dtype).float()
+    mask = (conf > 0.2).float()
+    assert float((s0[..., 0] - (disp / 1e2 * mask)[:, 0]).abs().max()) < tol
+    assert float((s0[..., 1] - torch.logit(mask * conf, eps=1e-1)[:, 0]).abs().max()) < tol * 4
+    assert float(s0[..., 2:].abs().max()) == 0
+    s1 = hip.refine_prep(disp, conf, occ, 1, dtype).float()
+    assert float((s1[..., 1] - torch.logit(conf, eps=1e-2)[:, 0]).abs().max()) < tol * 8
+    assert float((s1[..., 2] - torch.logit(occ, eps=1e-2)[:, 0]).abs().max()) < tol * 8
+    upd = torch.randn(B, h, w, 8, device="cuda", generator=g).to(dtype)
+    out = hip.global_update(upd, disp, conf, True)
+    ref = (mask * disp + (1 - mask) * upd[..., 0].float().unsqueeze(1) * 1e2).clamp(min=0)
+    assert float((out - ref).abs().max()) < 1e-4
+    dco = torch.randn(B, h, w, 16, device="cuda", generator=g).to(dtype)
+    d2, c2, o2 = hip.refine_update(dco, disp, conf, occ, True)
+    rd = (disp + dco[..., 0].float().unsqueeze(1)).clamp(min=0)
+    rc = torch.sigmoid(dco[..., 8].float().unsqueeze(1) + torch.logit(conf, eps=1e-2))
+    ro = torch.sigmoid(dco[..., 9].float().unsqueeze(1) + torch.logit(occ, eps=1e-2))
+    ro = ro * (torch.arange(w, device="cuda").float().reshape(1, 1, 1, w) - rd >= 0)
+    assert float((d2 - rd).abs().max()) < 1e-5 and float((c2 - rc).abs().max()) < 1e-5 and float((o2 - ro).abs().max()) < 1e-5
+    x = torch.randn(3, 5, 7, 128, device="cuda", generator=g).to(dtype)
+    assert float((hip.tanh(x).float() - torch.tanh(x.float())).abs().max()) < (1e-6 if dtype == torch.float32 else 1e-3)
