@@ -113,6 +113,8 @@ typedef struct s2m2_conv_desc {
     int shuffle2;
     int tile;
     int dtype;
+    int korder;             /* K order of the packed weight: 0 = (Cout, KH, KW, Cin); 1 = (Cout, KH, Cin/CH, KW, CH) with CH = 64 bytes of
+                               channels (32 fp16 / 16 fp32; Cin % CH == 0): horizontal taps become consecutive K tiles -> L1 reuse */
     int stride;             /* 1 or 2: out[y,x] is centred on in[y*stride, x*stride]; output (N, ceil(H/stride), ceil(W/stride), Cout) */
 } s2m2_conv_desc;
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);

@@ -41,10 +41,12 @@ struct AttnCfg {
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int KSTEPS = DP / 16;
     static constexpr int ND = (DP + 31) / 32;            // 32-wide output d tiles
+    static constexpr int KT = DP <= 64 ? 4 : (DP <= 128 ? 2 : 1);   // 32-key sub-tiles staged per block barrier (latency amortisation)
+    static constexpr int KVT = 32 * KT;                  // keys per stage
     static constexpr int KRS = DP + VEC;                 // K tile row stride (elements)
-    static constexpr int VRS = 32 + 4;                   // Vt row stride (elements): 32 keys + pad
+    static constexpr int VRS = KVT + 4;                  // Vt row stride (elements): keys of one stage + pad
     static constexpr int VROWS = ND * 32;
-    static constexpr size_t K_BYTES = (size_t)32 * KRS * sizeof(T);
+    static constexpr size_t K_BYTES = (size_t)KVT * KRS * sizeof(T);
     static constexpr size_t V_BYTES = (size_t)VROWS * VRS * sizeof(T);
     static constexpr int KP = DP / VEC;                  // 16-byte pieces per K/V row
     static constexpr int MAXW = (DP * sizeof(T) >= 384) ? 4 : 8;   // waves per block: 512 registers per lane for the wide heads
@@ -81,7 +83,7 @@ template <typename CFG, typename T>
 __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     constexpr int VEC = CFG::VEC, KRS = CFG::KRS, VRS = CFG::VRS, ND = CFG::ND, KP = CFG::KP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Ks = reinterpret_cast<T*>(smem);                                   // [32][KRS]
+    T* Ks = reinterpret_cast<T*>(smem);                                   // [KVT][KRS]
     T* Vt = reinterpret_cast<T*>(smem + CFG::K_BYTES);                    // [VROWS][VRS]
     float* pxs = reinterpret_cast<float*>(smem + CFG::K_BYTES + CFG::V_BYTES);   // PE tables (PE only)
 
@@ -130,8 +132,9 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     }
 
     // ---- staging assignment
-    // K tile: 32 rows x KP pieces.   V tile: 8 key groups (4 keys) x KP pieces -> transposed quads.
-    constexpr int K_TASKS = 32 * KP, V_TASKS = 8 * KP;
+    // K stage: KVT rows x KP pieces.   V stage: KVT/4 key groups (4 keys) x KP pieces -> transposed quads.
+    constexpr int KVT = CFG::KVT;
+    constexpr int K_TASKS = KVT * KP, V_TASKS = (KVT / 4) * KP;
     constexpr int MINT = 64 * CFG::MINW;                        // blocks have >= MINW waves (launch_attn)
     constexpr int K_IT_MAX = (K_TASKS + MINT - 1) / MINT, V_IT_MAX = (V_TASKS + MINT - 1) / MINT;
     Vec16<T> rk[K_IT_MAX];
@@ -204,82 +207,86 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     qi_pe = qi_pe < a.Nq ? qi_pe : a.Nq - 1;
     const int yq = CFG::PE ? qi_pe / a.gw : 0, xq = CFG::PE ? qi_pe - yq * a.gw : 0;
 
-    const int ntile = (a.Nk + 31) / 32;
+    const int nstage = (a.Nk + KVT - 1) / KVT;
     fetch(0);
-    for (int t = 0; t < ntile; ++t) {
-        __syncthreads();                                          // previous tile fully consumed (also covers the PE table fill)
+    for (int t = 0; t < nstage; ++t) {
+        __syncthreads();                                          // previous stage fully consumed (also covers the PE table fill)
         stash();
         __syncthreads();
-        if (t + 1 < ntile) fetch((t + 1) * 32);                   // in flight under this tile's MFMAs
+        if (t + 1 < nstage) fetch((t + 1) * KVT);                 // in flight under this stage's MFMAs
         if (wave_active) {
-            // ---- S^T = K . Q^T
-            float16_t sacc;
+#pragma unroll 1
+            for (int sub = 0; sub < CFG::KT; ++sub) {
+                const int kv0 = t * KVT + sub * 32;
+                if (kv0 >= a.Nk) break;
+                // ---- S^T = K . Q^T
+                float16_t sacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-            const T* kp = Ks + (size_t)l31 * KRS + hi * 8;
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                const T* kp = Ks + (size_t)(sub * 32 + l31) * KRS + hi * 8;
 #pragma unroll
-            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-                Frag<T> kf;
-                load_frag(kf, kp + kk * 16);
-                mma32(sacc, kf, qf[kk]);
-            }
-            // ---- online softmax (lane: one query, keys crow(r, hi) of this tile)
-            const int kv0 = t * 32;
-            float p[16];
-            float mloc = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + acc_row(r, lane);
-                p[r] = kv < a.Nk ? sacc[r] * a.scale : -INFINITY;
-                mloc = fmaxf(mloc, p[r]);
-            }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);               // finite: every tile has at least one valid key
-            const float alpha = expf(m_run - m_new);              // exp(-inf) = 0 on the first tile
-            float lsum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - m_new); lsum += p[r]; }
-            l_run = l_run * alpha + lsum;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-            // ---- O^T += Vt . P^T
-            Frag<T> pf[2];
-            make_pfrag<T>(pf[0], p);
-            make_pfrag<T>(pf[1], p + 8);
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt) {
-                const T* vp = Vt + (size_t)(dt * 32 + l31) * VRS + 4 * hi;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    Frag<T> vf;
-                    load_vfrag<T>(vf, vp + 16 * s, vp + 16 * s + 8);
-                    mma32(oacc[dt], vf, pf[s]);
+                for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                    Frag<T> kf;
+                    load_frag(kf, kp + kk * 16);
+                    mma32(sacc, kf, qf[kk]);
                 }
-            }
-            if constexpr (CFG::PE) {
-#pragma unroll
-                for (int c = 0; c < 32; ++c) pe_acc[c] *= alpha;
-                if constexpr (sizeof(T) == 2) {                   // the reference multiplies fp16 probabilities (autocast einsum)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) p[r] = (float)(half_t)p[r];
-                }
+                // ---- online softmax (lane: one query, keys crow(r, hi) of this sub-tile)
+                float p[16];
+                float mloc = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + acc_row(r, lane);
-                    if (kv < a.Nk) {
-                        const int yk = kv / a.gw, xk = kv - yk * a.gw;
-                        const float4_t* tx = reinterpret_cast<const float4_t*>(pxs + (xq - xk + a.gw - 1) * 16);
-                        const float4_t* ty = reinterpret_cast<const float4_t*>(pys + (yq - yk + a.gh - 1) * 16);
+                    p[r] = kv < a.Nk ? sacc[r] * a.scale : -INFINITY;
+                    mloc = fmaxf(mloc, p[r]);
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float m_new = fmaxf(m_run, mloc);           // finite: every sub-tile has at least one valid key
+                const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+                float lsum = 0.f;
 #pragma unroll
-                        for (int c4 = 0; c4 < 4; ++c4) {
-                            const float4_t u = tx[c4], w = ty[c4];
+                for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - m_new); lsum += p[r]; }
+                l_run = l_run * alpha + lsum;
+                m_run = m_new;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                pe_acc[c4 * 4 + e] = __builtin_fmaf(p[r], u[e], pe_acc[c4 * 4 + e]);
-                                pe_acc[16 + c4 * 4 + e] = __builtin_fmaf(p[r], w[e], pe_acc[16 + c4 * 4 + e]);
+                for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                // ---- O^T += Vt . P^T
+                Frag<T> pf[2];
+                make_pfrag<T>(pf[0], p);
+                make_pfrag<T>(pf[1], p + 8);
+#pragma unroll
+                for (int dt = 0; dt < ND; ++dt) {
+                    const T* vp = Vt + (size_t)(dt * 32 + l31) * VRS + sub * 32 + 4 * hi;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        Frag<T> vf;
+                        load_vfrag<T>(vf, vp + 16 * s, vp + 16 * s + 8);
+                        mma32(oacc[dt], vf, pf[s]);
+                    }
+                }
+                if constexpr (CFG::PE) {
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) pe_acc[c] *= alpha;
+                    if constexpr (sizeof(T) == 2) {               // the reference multiplies fp16 probabilities (autocast einsum)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) p[r] = (float)(half_t)p[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + acc_row(r, lane);
+                        if (kv < a.Nk) {
+                            const int yk = kv / a.gw, xk = kv - yk * a.gw;
+                            const float4_t* tx = reinterpret_cast<const float4_t*>(pxs + (xq - xk + a.gw - 1) * 16);
+                            const float4_t* ty = reinterpret_cast<const float4_t*>(pys + (yq - yk + a.gh - 1) * 16);
+#pragma unroll
+                            for (int c4 = 0; c4 < 4; ++c4) {
+                                const float4_t u = tx[c4], w = ty[c4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    pe_acc[c4 * 4 + e] = __builtin_fmaf(p[r], u[e], pe_acc[c4 * 4 + e]);
+                                    pe_acc[16 + c4 * 4 + e] = __builtin_fmaf(p[r], w[e], pe_acc[16 + c4 * 4 + e]);
+                                }
                             }
                         }
                     }
@@ -358,8 +365,8 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     if constexpr (DP <= 64) {
         // few (batch, head) pairs (the 2-D global blocks at 1/32): smaller blocks until the grid covers the chip; every block
         // re-stages K/V from L2, which is cheap next to an idle GPU
-        while (nw > 1 && (long long)((ntq + nw - 1) / nw) * bh < 512) nw = (nw + 1) / 2;
-        if (nw < 4) return launch_attn_w<T, DP, PE, 1>(a, nw, st);
+        while (nw > 2 && (long long)((ntq + nw - 1) / nw) * bh < 512) nw = (nw + 1) / 2;
+        if (nw < 4) return launch_attn_w<T, DP, PE, 2>(a, nw, st);
     }
     return launch_attn_w<T, DP, PE, 4>(a, nw < 4 ? 4 : nw, st);
 }

@@ -44,20 +44,22 @@ struct ConvArgs {
     int aux0_stride, aux1_stride;
     float out_scale;
     int shuffle2;
+    int korder;                 // 0: K = (ky, kx, c);  1: K = (ky, c / CH, kx, c % CH), CH = 64 bytes of channels (L1 reuse along kx)
     const void* zero;           // 256 zero bytes in global memory (what out-of-range pieces read)
 };
 
-template <typename T, int BM_, int BN_, int WGM_>
+template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8>
 struct ConvCfg {
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_;
     static constexpr int VEC = 16 / sizeof(T);
-    static constexpr int PPR = 8;                        // 16-byte pieces per K-tile row
+    static constexpr int PPR = PPR_;                     // 16-byte pieces per K-tile row (8: 128-byte rows, 4: 64-byte rows)
+    static constexpr int RPI = 256 / PPR;                // tile rows covered by one pass of the 256 loader threads
     static constexpr int BK = PPR * VEC;                 // 64 fp16 / 32 fp32
     static constexpr int RS = BK + VEC;                  // LDS row stride (elements)
     static constexpr int KSTEPS = BK / 16;               // k16 fragments per tile
     static constexpr int WM = BM / WGM, WN = BN / WGN;   // per-wave tile
     static constexpr int MT = WM / 32, NTL = WN / 32;
-    static constexpr int A_IT = BM / 32, B_IT = (BN + 31) / 32;   // rows per thread (row = tid/8 + 32*it)
+    static constexpr int A_IT = (BM + RPI - 1) / RPI, B_IT = (BN + RPI - 1) / RPI;   // rows per thread (row = tid/PPR + RPI*it)
     static constexpr int CRS = BN + VEC;                 // staging row stride
     static constexpr size_t TILE_BYTES = (size_t)2 * (BM + BN) * RS * sizeof(T);
     static constexpr size_t STAGE_BYTES = (size_t)BM * CRS * sizeof(T);
@@ -129,7 +131,90 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero_vec() {
     return z;
 }
 
-// Per-thread state of the global -> register -> LDS tile loader: piece column `pc` of rows lrow + 32*it.
+// epilogue 2: the staged tile comes back as 16-byte pieces of whole pixel rows: aux combine, coalesced store
+template <typename CFG, typename T>
+__device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int tid, long long m0, int n0, long long M) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, VEC = CFG::VEC;
+    constexpr int PCR = BN / VEC;                                 // pieces per staged row
+    constexpr int TOTAL = BM * PCR;
+    T* outp = static_cast<T*>(p.out);
+#pragma unroll 2
+    for (int q = tid; q < TOTAL; q += 256) {
+        const int r = q / PCR, pcc = q - r * PCR;
+        const long long m = m0 + r;
+        const int co = n0 + pcc * VEC;
+        if (m >= M || co >= p.Cout) continue;
+        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
+        if (p.epi != S2M2_EPI_NONE) {
+            const Vec16<T> a0 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux0) + m * p.aux0_stride + co);
+            Vec16<T> a1 = a0;
+            if (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX)
+                a1 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux1) + m * p.aux1_stride + co);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float x = to_f32(v.v[e]), u = to_f32(a0.v[e]), w = to_f32(a1.v[e]);
+                float o;
+                if (p.epi == S2M2_EPI_ADD) o = x + u;
+                else if (p.epi == S2M2_EPI_MUL) o = x * u;
+                else if (p.epi == S2M2_EPI_GRU) o = (1.0f - u) * w + u * x;                      // aux0 = z, aux1 = h, x = q
+                else { const float gte = fminf(fmaxf(x, 0.01f), 0.99f); o = gte * u + (1.0f - gte) * w; }   // x = gate
+                v.v[e] = from_f32<T>(o);
+            }
+        }
+        long long opix = m;
+        int oc = co;
+        if (p.shuffle2) {                                         // ConvTranspose2d(k=2, s=2): cout = (dy*2+dx)*C' + c'
+            const int sub = co / p.shuffle2;
+            oc = co - sub * p.shuffle2;
+            const int x = (int)(m % p.Wo);
+            const long long t = m / p.Wo;
+            const int y = (int)(t % p.Ho);
+            const long long n = t / p.Ho;
+            opix = (n * (2 * p.Ho) + 2 * y + (sub >> 1)) * (2LL * p.Wo) + 2 * x + (sub & 1);
+        }
+        if (!(S2M2_CONV_DBG & 32)) *reinterpret_cast<Vec16<T>*>(outp + opix * p.out_stride + oc) = v;
+    }
+}
+
+template <typename CFG, typename T, int UNUSED = 0>
+__device__ __forceinline__ void stage_tile_act(const ConvArgs& p, const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, int n0, int wm, int wn, int lane) {
+    switch (p.act) {                                              // block-uniform
+        case S2M2_ACT_GELU: stage_tile<CFG, T, S2M2_ACT_GELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        case S2M2_ACT_RELU: stage_tile<CFG, T, S2M2_ACT_RELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        case S2M2_ACT_SIGMOID: stage_tile<CFG, T, S2M2_ACT_SIGMOID>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        case S2M2_ACT_TANH: stage_tile<CFG, T, S2M2_ACT_TANH>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        default: stage_tile<CFG, T, S2M2_ACT_NONE>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+    }
+}
+
+// K cursor of one lane: which (tap, channel) its 16-byte piece of the NEXT tile comes from.  Two K orders (weights are packed to
+// match, the weight side only ever sees the linear K index):
+//   0  (ky, kx, c)                  any Cin
+//   1  (ky, c / CH, kx, c % CH)     CH = 64 bytes of channels, Cin % CH == 0: consecutive tiles sweep kx over the SAME cache lines
+//      (pixel x+1 at tap kx is pixel x at tap kx+1), so the three horizontal taps of a 3x3 kernel hit in L1 instead of L2.
+template <int CH>
+struct KCursor {
+    int ky, kx, kc;
+    __device__ __forceinline__ void init(const ConvArgs& p, int elem) {          // elem: K offset of the piece inside tile 0
+        ky = 0; kx = 0;
+        if (p.korder) { kc = elem % CH; step(p, elem / CH); }
+        else { kc = elem; norm(p); }
+    }
+    __device__ __forceinline__ void norm(const ConvArgs& p) {
+        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.KW) { kx = 0; ++ky; } }
+    }
+    __device__ __forceinline__ void step(const ConvArgs& p, int n) {
+        for (int i = 0; i < n; ++i) {
+            if (++kx == p.KW) { kx = 0; kc += CH; if (kc >= p.Cin) { kc -= p.Cin; ++ky; } }
+        }
+    }
+    template <int BK> __device__ __forceinline__ void advance(const ConvArgs& p) {
+        if (p.korder) step(p, BK / CH);
+        else { kc += BK; norm(p); }
+    }
+};
+
+// Per-thread state of the global -> register -> LDS tile loader: piece column `pc` of rows lrow + RPI*it.
 //  * everything that does not change along K is computed once (pixel index, a bit mask of the taps that fall inside the image,
 //    weight row pointers); a fetch is ~7 VALU ops per 16-byte piece: 24-bit multiply-add for the element offset, one bit test,
 //    one 64-bit select between the real address and a 16-byte zero block (zero padding, K / Cout / M tails) -- no branches;
@@ -142,13 +227,13 @@ struct ConvLoader {
     int apix[CFG::A_IT];                       // input pixel (n*H + y)*W + x of the window centre
     unsigned tapmask[CFG::A_IT];               // bit (ky*KW + kx): that tap of this row is inside the image (0 for rows past M)
     const T* wrow[CFG::B_IT];                  // weight row of this thread (nullptr: row past Cout / BN)
-    int kc, ky, kx;                            // K position of this thread's piece: channel within the tap, tap coordinates
+    KCursor<4 * VEC> cur;                      // K position of this thread's piece: channel within the tap, tap coordinates
     const T *s0, *s1, *s2, *s3;                // sources / strides / cumulative channel counts as named scalars
     int st0, st1, st2, st3, c0n, c1n, c2n;
     raw16_t ra[CFG::A_IT], rb[CFG::B_IT];
 
     __device__ __forceinline__ void init(const ConvArgs& p, int tid, long long m0, int n0, long long M, int Ktot_) {
-        pc = tid & 7; lrow = tid >> 3; Ktot = Ktot_;
+        pc = tid % CFG::PPR; lrow = tid / CFG::PPR; Ktot = Ktot_;
         s0 = static_cast<const T*>(p.src[0]); s1 = static_cast<const T*>(p.src[1]);
         s2 = static_cast<const T*>(p.src[2]); s3 = static_cast<const T*>(p.src[3]);
         st0 = p.src_stride[0]; st1 = p.src_stride[1]; st2 = p.src_stride[2]; st3 = p.src_stride[3];
@@ -156,9 +241,9 @@ struct ConvLoader {
         const int ph = p.KH / 2, pw = p.KW / 2;
 #pragma unroll
         for (int it = 0; it < CFG::A_IT; ++it) {
-            const long long m = m0 + lrow + 32 * it;
+            const long long m = m0 + lrow + CFG::RPI * it;
             apix[it] = 0; tapmask[it] = 0u;
-            if (m < M) {                                          // M < 2^24 (checked on the host): 32-bit divisions
+            if (m < M && lrow + CFG::RPI * it < CFG::BM) {                                          // M < 2^24 (checked on the host): 32-bit divisions
                 const unsigned mu = (unsigned)m;
                 const unsigned t = mu / (unsigned)p.Wo;
                 const int xo = (int)(mu - t * (unsigned)p.Wo);
@@ -177,18 +262,18 @@ struct ConvLoader {
         const T* wp = static_cast<const T*>(p.weight);
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
-            const int r = lrow + 32 * it;
+            const int r = lrow + CFG::RPI * it;
             const int co = n0 + r;
             wrow[it] = (r < BN && co < p.Cout) ? wp + (size_t)co * Ktot + pc * VEC : nullptr;
         }
-        kc = pc * VEC; ky = 0; kx = 0;
-        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.KW) { kx = 0; ++ky; } }
+        cur.init(p, pc * VEC);
     }
 
     // issue the loads of K tile kt (element k = kt*BK + pc*VEC -> (tap, channel)), then advance to the next tile
     __device__ __forceinline__ void fetch(const ConvArgs& p, int kt) {
         const T* zp = static_cast<const T*>(p.zero);
         const bool kvalid = kt * BK + pc * VEC < Ktot;
+        const int kc = cur.kc, ky = cur.ky, kx = cur.kx;
         const T* sp = s0;
         unsigned ss = (unsigned)st0, c = (unsigned)kc;
         if (p.nsrc > 1) {                                         // wave-uniform branch on a scalar
@@ -212,16 +297,18 @@ struct ConvLoader {
             const T* src = (kvalid && wrow[it]) ? wrow[it] + koff : zp;
             rb[it] = global_load16(src);
         }
-        kc += BK;
-        while (kc >= p.Cin) { kc -= p.Cin; if (++kx == p.KW) { kx = 0; ++ky; } }
+        cur.template advance<BK>(p);
     }
 
     __device__ __forceinline__ void stash(T* a, T* b) const {
 #pragma unroll
-        for (int it = 0; it < CFG::A_IT; ++it) *reinterpret_cast<raw16_t*>(a + (size_t)(lrow + 32 * it) * RS + pc * VEC) = ra[it];
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const int r = lrow + CFG::RPI * it;
+            if (r < CFG::BM) *reinterpret_cast<raw16_t*>(a + (size_t)r * RS + pc * VEC) = ra[it];
+        }
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
-            const int r = lrow + 32 * it;
+            const int r = lrow + CFG::RPI * it;
             if (r < BN) *reinterpret_cast<raw16_t*>(b + (size_t)r * RS + pc * VEC) = rb[it];
         }
     }
@@ -287,55 +374,225 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     }
 
     // ---- epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]
-    switch (p.act) {                                              // block-uniform
-        case S2M2_ACT_GELU: stage_tile<CFG, T, S2M2_ACT_GELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        case S2M2_ACT_RELU: stage_tile<CFG, T, S2M2_ACT_RELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        case S2M2_ACT_SIGMOID: stage_tile<CFG, T, S2M2_ACT_SIGMOID>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        case S2M2_ACT_TANH: stage_tile<CFG, T, S2M2_ACT_TANH>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        default: stage_tile<CFG, T, S2M2_ACT_NONE>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-    }
+    stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
     __syncthreads();
 
-    // ---- epilogue 2: whole-row 16-byte pieces: aux combine, coalesced store
-    constexpr int PCR = BN / VEC;                                 // pieces per staged row
-    constexpr int TOTAL = BM * PCR;
-    T* outp = static_cast<T*>(p.out);
-#pragma unroll 2
-    for (int q = tid; q < TOTAL; q += 256) {
-        const int r = q / PCR, pcc = q - r * PCR;
-        const long long m = m0 + r;
-        const int co = n0 + pcc * VEC;
-        if (m >= M || co >= p.Cout) continue;
-        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
-        if (p.epi != S2M2_EPI_NONE) {
-            const Vec16<T> a0 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux0) + m * p.aux0_stride + co);
-            Vec16<T> a1 = a0;
-            if (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX)
-                a1 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux1) + m * p.aux1_stride + co);
+    store_tile<CFG, T>(p, Cs, tid, m0, n0, M);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v2 pipeline: global -> LDS DIRECT (global_load_lds_dwordx4, no VGPR staging, no ds_write) into a ring of NS stages.
+//   stage  = KP planes x (BM + BN) rows x 64 bytes: a plane holds 4 16-byte pieces (32 fp16 / 16 fp32 of K) per row, rows dense
+//            (an LDS-direct wave instruction fills 1024 contiguous bytes = 16 rows), bank conflicts of the ds_read_b128
+//            fragment reads removed by an XOR swizzle applied on the SOURCE side: slot s of row r holds piece s ^ ((r>>2)&3),
+//            which is constant per lane, so every lane keeps ONE K cursor per plane;
+//   ring   = tile kt+NS-1 is requested while tile kt is multiplied: NS-1 tiles of latency cover, ONE block barrier per tile,
+//            s_waitcnt vmcnt(N) counted (never 0 inside the loop); K tails / zero padding read the zero block, so every
+//            iteration issues the same number of loads and the counted wait stays valid.
+// Everything else (operand roles, epilogues) is shared with the v1 kernel above.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BM_, int BN_, int KP_, int NS_>
+struct ConvCfg2 {
+    static constexpr int BM = BM_, BN = BN_, KP = KP_, NS = NS_, WGM = 2, WGN = 2;
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int PBK = 4 * VEC;                  // K elements per plane (64 bytes)
+    static constexpr int BK = KP * PBK;
+    static constexpr int PSTEPS = PBK / 16 > 0 ? PBK / 16 : 1;     // k16 steps per plane: 2 (fp16), 1 (fp32)
+    static constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NTL = WN / 32;
+    static constexpr int A_INS = BM / 64, B_INS = BN / 64;        // LDS-direct instructions per wave and plane (16 rows each)
+    static constexpr int LPS = KP * (A_INS + B_INS);             // loads per lane and stage
+    static constexpr int PLANE_BYTES = (BM + BN) * 64;
+    static constexpr int STAGE_BYTES = KP * PLANE_BYTES;
+    static constexpr int CRS = BN + VEC;
+    static constexpr size_t TILE_BYTES = (size_t)NS * STAGE_BYTES;
+    static constexpr size_t STAGE_C_BYTES = (size_t)BM * CRS * sizeof(T);
+    static constexpr size_t LDS_BYTES = TILE_BYTES > STAGE_C_BYTES ? TILE_BYTES : STAGE_C_BYTES;
+};
+
+// LDS fragment reads of the v2 kernel are inline asm on purpose: the compiler orders every ds_read it can see behind ALL pending
+// LDS-direct loads (it cannot tell the ring slots apart) with s_waitcnt vmcnt(0), which would drain the ring every iteration.
+// Here the protocol is explicit: counted vmcnt + s_barrier before a slot is read, lgkmcnt(0) before the fragments are used.
+__device__ __forceinline__ raw16_t lds_read16(unsigned addr) {
+    raw16_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <typename T> struct RawFrag;                                  // the registers of one k16 fragment as raw 16-byte reads
+template <> struct RawFrag<half_t> { raw16_t a; };
+template <> struct RawFrag<float> { raw16_t a, b; };
+__device__ __forceinline__ void issue_frag(RawFrag<half_t>& f, unsigned rowaddr, int step, int hi, int sw) {
+    f.a = lds_read16(rowaddr + (((step * 2 + hi) ^ sw) << 4));
+}
+__device__ __forceinline__ void issue_frag(RawFrag<float>& f, unsigned rowaddr, int step, int hi, int sw) {
+    (void)step;
+    f.a = lds_read16(rowaddr + (((2 * hi) ^ sw) << 4));
+    f.b = lds_read16(rowaddr + (((2 * hi + 1) ^ sw) << 4));
+}
+__device__ __forceinline__ void settle(RawFrag<half_t>& f) { asm volatile("" : "+v"(f.a)); }
+__device__ __forceinline__ void settle(RawFrag<float>& f) { asm volatile("" : "+v"(f.a), "+v"(f.b)); }
+__device__ __forceinline__ Frag<half_t> to_frag(const RawFrag<half_t>& r) { Frag<half_t> f; f.v = __builtin_bit_cast(half8_t, r.a); return f; }
+__device__ __forceinline__ Frag<float> to_frag(const RawFrag<float>& r) {
+    Frag<float> f;
+    f.v[0] = r.a[0]; f.v[1] = r.a[1]; f.v[2] = r.a[2]; f.v[3] = r.a[3];
+    f.v[4] = r.b[0]; f.v[5] = r.b[1]; f.v[6] = r.b[2]; f.v[7] = r.b[3];
+    return f;
+}
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, VEC = CFG::VEC, KP = CFG::KP, NS = CFG::NS;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    T* Cs = reinterpret_cast<T*>(smem);                          // [BM][CRS]   (after the K loop)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv & 1, wn = wv >> 1;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int Ktot = p.KH * p.KW * p.Cin;
+    const int nkt = (Ktot + CFG::BK - 1) / CFG::BK;
+
+    // ---- loader state (per lane): piece column q of rows  wv*(rows/4) + 16*i + (lane>>2)
+    const int q = (lane & 3) ^ ((lane >> 4) & 3);
+    const int rsub = lane >> 2;
+    int apix[CFG::A_INS];
+    unsigned tapmask[CFG::A_INS];
+    const T* wrow[CFG::B_INS];
+    {
+        const int ph = p.KH / 2, pw = p.KW / 2;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float x = to_f32(v.v[e]), u = to_f32(a0.v[e]), w = to_f32(a1.v[e]);
-                float o;
-                if (p.epi == S2M2_EPI_ADD) o = x + u;
-                else if (p.epi == S2M2_EPI_MUL) o = x * u;
-                else if (p.epi == S2M2_EPI_GRU) o = (1.0f - u) * w + u * x;                      // aux0 = z, aux1 = h, x = q
-                else { const float gte = fminf(fmaxf(x, 0.01f), 0.99f); o = gte * u + (1.0f - gte) * w; }   // x = gate
-                v.v[e] = from_f32<T>(o);
+        for (int i = 0; i < CFG::A_INS; ++i) {
+            const long long m = m0 + wv * (BM / 4) + 16 * i + rsub;
+            apix[i] = 0; tapmask[i] = 0u;
+            if (m < M) {
+                const unsigned mu = (unsigned)m;
+                const unsigned t = mu / (unsigned)p.Wo;
+                const int xo = (int)(mu - t * (unsigned)p.Wo);
+                const unsigned n = t / (unsigned)p.Ho;
+                const int y = (int)(t - n * (unsigned)p.Ho) * p.stride, x = xo * p.stride;
+                apix[i] = ((int)n * p.H + y) * p.W + x;
+                unsigned mk = 0u;
+                for (int a = 0; a < p.KH; ++a)
+                    for (int b = 0; b < p.KW; ++b) {
+                        const int yy = y + a - ph, xx = x + b - pw;
+                        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mk |= 1u << (a * p.KW + b);
+                    }
+                tapmask[i] = mk;
             }
         }
-        long long opix = m;
-        int oc = co;
-        if (p.shuffle2) {                                         // ConvTranspose2d(k=2, s=2): cout = (dy*2+dx)*C' + c'
-            const int sub = co / p.shuffle2;
-            oc = co - sub * p.shuffle2;
-            const int x = (int)(m % p.Wo);
-            const long long t = m / p.Wo;
-            const int y = (int)(t % p.Ho);
-            const long long n = t / p.Ho;
-            opix = (n * (2 * p.Ho) + 2 * y + (sub >> 1)) * (2LL * p.Wo) + 2 * x + (sub & 1);
+        const T* wp = static_cast<const T*>(p.weight);
+#pragma unroll
+        for (int i = 0; i < CFG::B_INS; ++i) {
+            const int co = n0 + wv * (BN / 4) + 16 * i + rsub;
+            wrow[i] = co < p.Cout ? wp + (size_t)co * Ktot + q * VEC : nullptr;
         }
-        if (!(S2M2_CONV_DBG & 32)) *reinterpret_cast<Vec16<T>*>(outp + opix * p.out_stride + oc) = v;
     }
+    // one K cursor per plane: channel within the tap, tap coordinates of piece q of the NEXT tile to request
+    KCursor<CFG::PBK> cur[KP];
+#pragma unroll
+    for (int pl = 0; pl < KP; ++pl) cur[pl].init(p, pl * CFG::PBK + q * VEC);
+    const T* zp = static_cast<const T*>(p.zero);
+    const T* const s0 = static_cast<const T*>(p.src[0]);
+    const T* const s1 = static_cast<const T*>(p.src[1]);
+    const T* const s2 = static_cast<const T*>(p.src[2]);
+    const T* const s3 = static_cast<const T*>(p.src[3]);
+    const int st0 = p.src_stride[0], st1 = p.src_stride[1], st2 = p.src_stride[2], st3 = p.src_stride[3];
+    const int c0n = p.src_c[0], c1n = c0n + p.src_c[1], c2n = c1n + p.src_c[2];
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* gbl_ptr;
+    char* const ring = smem;
+    const unsigned ring_addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;   // LDS byte address
+    // request K tile kt into ring slot `slot` (kt may run past the end: everything then reads the zero block)
+    auto request = [&](int kt, int slot) __attribute__((always_inline)) {
+        char* stage = ring + (size_t)slot * CFG::STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < KP; ++pl) {
+            const bool kvalid = kt * CFG::BK + pl * CFG::PBK + q * VEC < Ktot;
+            const int kcp = cur[pl].kc, kyp = cur[pl].ky, kxp = cur[pl].kx;
+            const T* sp = s0;
+            unsigned ss = (unsigned)st0, c = (unsigned)kcp;
+            if (p.nsrc > 1) {
+                const bool g0 = kcp >= c0n, g1 = kcp >= c1n, g2 = kcp >= c2n;
+                const long long d1 = (const char*)s1 - (const char*)s0, d2 = (const char*)s2 - (const char*)s1, d3 = (const char*)s3 - (const char*)s2;
+                sp = reinterpret_cast<const T*>((const char*)s0 + ((g0 ? d1 : 0) + (g1 ? d2 : 0) + (g2 ? d3 : 0)));
+                ss = (unsigned)(st0 + (g0 ? st1 - st0 : 0) + (g1 ? st2 - st1 : 0) + (g2 ? st3 - st2 : 0));
+                c = (unsigned)(kcp - ((g0 ? c0n : 0) + (g1 ? c1n - c0n : 0) + (g2 ? c2n - c1n : 0)));
+            }
+            const int tapoff = (kyp - p.KH / 2) * p.W + (kxp - p.KW / 2);
+            const unsigned tapbit = kvalid ? 1u << (kyp * p.KW + kxp) : 0u;
+            char* plane = stage + (size_t)pl * CFG::PLANE_BYTES;
+#pragma unroll
+            for (int i = 0; i < CFG::A_INS; ++i) {
+                const unsigned e = __umul24((unsigned)(apix[i] + tapoff), ss) + c;
+                const T* src = (tapmask[i] & tapbit) ? sp + e : zp;
+                __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(plane + (wv * (BM / 4) + 16 * i) * 64), 16, 0, 0);
+            }
+            const int koff = kt * CFG::BK + pl * CFG::PBK;
+#pragma unroll
+            for (int i = 0; i < CFG::B_INS; ++i) {
+                const T* src = (kvalid && wrow[i]) ? wrow[i] + koff : zp;
+                __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(plane + (BM + wv * (BN / 4) + 16 * i) * 64), 16, 0, 0);
+            }
+            cur[pl].template advance<CFG::BK>(p);
+        }
+    };
+
+    float16_t acc[CFG::MT][CFG::NTL];
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int sw = (l31 >> 2) & 3;                                // swizzle of this lane's fragment rows
+    int issued = 0;
+#pragma unroll 1
+    for (; issued < NS - 1; ++issued) request(issued, issued);
+    int slot_c = 0, slot_i = NS - 1;                             // ring slots: being multiplied / next to fill
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt has landed for this wave once at most NS-2 younger tiles are pending; the barrier publishes every wave's part
+        // and guarantees that slot_i (multiplied in the previous iteration) is free
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * CFG::LPS) : "memory");
+        __builtin_amdgcn_s_barrier();                            // plain barrier: no fence, the DMA ring is tracked by hand
+        request(kt + NS - 1, slot_i);
+        const unsigned stage = ring_addr + (unsigned)slot_c * CFG::STAGE_BYTES;
+#pragma unroll
+        for (int pl = 0; pl < KP; ++pl) {
+            const unsigned plane = stage + (unsigned)pl * CFG::PLANE_BYTES;
+            const unsigned a = plane + (unsigned)(wm * CFG::WM + l31) * 64;
+            const unsigned b = plane + (unsigned)(BM + wn * CFG::WN + l31) * 64;
+#pragma unroll
+            for (int st = 0; st < CFG::PSTEPS; ++st) {
+                RawFrag<T> xr[CFG::MT], wr[CFG::NTL];
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i) issue_frag(xr[i], a + (unsigned)i * 32 * 64, st, hi, sw);
+#pragma unroll
+                for (int j = 0; j < CFG::NTL; ++j) issue_frag(wr[j], b + (unsigned)j * 32 * 64, st, hi, sw);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i) settle(xr[i]);
+#pragma unroll
+                for (int j = 0; j < CFG::NTL; ++j) settle(wr[j]);
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], to_frag(wr[j]), to_frag(xr[i]));    // D[cout][pixel]
+            }
+        }
+        slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+        slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the tail requests (zero block) must land before LDS is reused
+    __syncthreads();
+
+    stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+    __syncthreads();
+    store_tile<CFG, T>(p, Cs, tid, m0, n0, M);
 }
 
 // 256 zero bytes, allocated on the first call (before any graph capture: the engine warms up eagerly)
@@ -347,10 +604,27 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BM, int BN, int WGM>
+template <typename T, int BM, int BN, int WGM, int PPR = 8>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    using CFG = ConvCfg<T, BM, BN, WGM>;
+    using CFG = ConvCfg<T, BM, BN, WGM, PPR>;
     auto kern = conv_igemm_kernel<CFG, T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)CFG::LDS_BYTES) != hipSuccess)
+            return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
+        attr_done = true;
+    }
+    const long long M = (long long)a.N * a.Ho * a.Wo;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), CFG::LDS_BYTES, st, a);
+    return check_launch("conv2d");
+}
+
+template <typename T, int BM, int BN, int KP, int NS>
+static int launch_conv2(const ConvArgs& a, hipStream_t st) {
+    using CFG = ConvCfg2<T, BM, BN, KP, NS>;
+    auto kern = conv_igemm2_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -367,16 +641,24 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 template <typename T>
 static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     const long long M = (long long)a.N * a.Ho * a.Wo;
-    if (tile == 0) {                                              // heuristic: narrow N, else fill the chip
-        if (a.Cout <= 32) tile = 3;
-        else if (a.Cout <= 64) tile = 4;
-        else tile = ((M + 63) / 64) * ((a.Cout + 63) / 64) > 6000 ? 1 : 2;     // 64x64 unless the grid is huge (measured, tools/convbench.py)
+    if (tile == 0) {                                              // measured on MI355X (tools/convbench.py, profiles/r01)
+        const int Ktot = a.KH * a.KW * a.Cin;
+        if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
+        else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 5;   // 128x128, 64-byte K rows, 3 blocks/CU
+        else tile = Ktot <= 512 ? 6 : 2;                          // 64x64 with 64- / 128-byte K rows
     }
     switch (tile) {
         case 1: return launch_conv<T, 128, 128, 2>(a, st);
         case 2: return launch_conv<T, 64, 64, 2>(a, st);
         case 3: return launch_conv<T, 128, 32, 4>(a, st);
         case 4: return launch_conv<T, 128, 64, 2>(a, st);
+        case 5: return launch_conv<T, 128, 128, 2, 4>(a, st);      // 64-byte K rows: half the LDS, 3 blocks per CU
+        case 6: return launch_conv<T, 64, 64, 2, 4>(a, st);
+        case 7: return launch_conv2<T, 128, 128, 1, 4>(a, st);     // v2 (LDS-direct ring): 64 KB, 3 tiles ahead
+        case 8: return launch_conv2<T, 128, 128, 2, 2>(a, st);     // v2: 128-byte K rows, 1 tile ahead
+        case 9: return launch_conv2<T, 128, 128, 2, 3>(a, st);     // v2: 96 KB, 2 tiles ahead
+        case 10: return launch_conv2<T, 64, 64, 2, 4>(a, st);      // v2: 64x64, 64 KB
+        case 11: return launch_conv2<T, 64, 64, 1, 4>(a, st);      // v2: 64x64, 32 KB
         default: return set_error("conv2d: unknown tile id %d", tile);
     }
 }
@@ -422,10 +704,12 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.N = d->N; a.H = d->H; a.W = d->W; a.KH = d->KH; a.KW = d->KW; a.Cout = d->Cout;
     a.act = d->act; a.epi = d->epi; a.aux0 = d->aux0; a.aux1 = d->aux1;
     a.aux0_stride = d->aux0_stride; a.aux1_stride = d->aux1_stride;
-    a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2;
+    a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2; a.korder = d->korder;
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "conv2d: cannot allocate the zero page");
     a.stride = d->stride; a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
+    S2M2_REQUIRE(d->korder == 0 || d->korder == 1, "conv2d: korder=%d (0 or 1)", d->korder);
+    S2M2_REQUIRE(!d->korder || a.Cin % (d->dtype == S2M2_F16 ? 32 : 16) == 0, "conv2d: korder 1 needs Cin=%d to be a multiple of 64 bytes of channels", a.Cin);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->dtype == S2M2_F16) return dispatch_conv<half_t>(a, d->tile, st);
     if (d->dtype == S2M2_F32) return dispatch_conv<float>(a, d->tile, st);

@@ -31,7 +31,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("src", _vp * 4), ("src_c", _i * 4), ("src_stride", _i * 4), ("nsrc", _i), ("weight", _vp), ("bias", _vp),
                 ("out", _vp), ("out_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Cout", _i),
                 ("act", _i), ("epi", _i), ("aux0", _vp), ("aux1", _vp), ("aux0_stride", _i), ("aux1_stride", _i),
-                ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("stride", _i)]
+                ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("korder", _i), ("stride", _i)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -151,7 +151,7 @@ def _nhwc(t: torch.Tensor):
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, act: int = ACT_NONE,
            epi: int = EPI_NONE, aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0,
-           stride: int = 1) -> torch.Tensor:
+           stride: int = 1, korder: int = 0) -> torch.Tensor:
     """Implicit-GEMM convolution / linear layer (s2m2_conv2d).  srcs: list of (N,H,W,Cs) tensors, concatenated along C;
     weight: packed (Cout, KH*KW*sum(Cs)) (see s2m2_amd.pack); bias fp32 (Cout) or None.  Returns (N,H,W,Cout), or
     (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM."""
@@ -196,6 +196,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
     d.shuffle2 = shuffle2
     d.tile = tile
     d.stride = stride
+    d.korder = korder
     d.dtype = _DT[dt]
     _check(load().s2m2_conv2d(ctypes.byref(d), _stream()), "s2m2_conv2d")
     return out

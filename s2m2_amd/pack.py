@@ -14,8 +14,21 @@ def pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
 
+def chunk_channels(dtype: torch.dtype) -> int:
+    """CH of K order 1: 64 bytes of channels."""
+    return 64 // torch.empty((), dtype=dtype).element_size()
+
+
+def reorder_k(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """(Cout, KH, KW, Cin) -> K order 1 of s2m2_conv2d: (Cout, KH, Cin/CH, KW, CH)."""
+    co, kh, kw, ci = w.shape
+    ch = chunk_channels(dtype)
+    assert ci % ch == 0, (ci, ch)
+    return w.reshape(co, kh, kw, ci // ch, ch).permute(0, 1, 3, 2, 4)
+
+
 def pack_conv(w: torch.Tensor, dtype: torch.dtype, splits: Optional[Sequence[Tuple[int, int]]] = None,
-              cout_pad: Optional[int] = None) -> torch.Tensor:
+              cout_pad: Optional[int] = None, korder: int = 0) -> torch.Tensor:
     """nn.Conv2d / nn.Linear weight (Cout, Cin[, KH, KW]) -> packed (Cout_p, KH*KW*Cin_p).
 
     splits: [(real, padded), ...] how the Cin input channels are laid out over the (concatenated, individually padded)
@@ -35,7 +48,10 @@ def pack_conv(w: torch.Tensor, dtype: torch.dtype, splits: Optional[Sequence[Tup
             blk = torch.cat([blk, blk.new_zeros(co, kh, kw, padded - real)], -1)
         cols.append(blk)
         off += real
-    wp = torch.cat(cols, -1).reshape(co, -1)
+    wp = torch.cat(cols, -1)                                      # (Cout, KH, KW, Cin_p)
+    if korder:
+        wp = reorder_k(wp, dtype)
+    wp = wp.reshape(co, -1)
     cop = cout_pad if cout_pad is not None else pad8(co)
     if cop > co:
         wp = torch.cat([wp, wp.new_zeros(cop - co, wp.shape[1])], 0)
