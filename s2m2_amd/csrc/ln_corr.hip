@@ -20,6 +20,7 @@
 // Algorithmic traffic per pair: 2*h*w*C*sizeof(T) read + h*w*w*sizeof(TO) written.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 // compile-time ablation switches for tools/k1_ablate.py (never set in the shipped library):
 // 1 no global stores, 2 no MFMA, 4 no LayerNorm arithmetic, 8 no multiply/store phase at all
@@ -29,8 +30,9 @@
 
 namespace s2m2 {
 
-template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_>
+template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool PIPE_ = false>
 struct LnCorrCfg {
+    static constexpr bool PIPE = PIPE_;                 // right tokens normalised in 4 rounds, column tiles stored as soon as their tokens exist
     static constexpr int C = C_;
     static constexpr int RIF = RIF_;                    // token rounds (8 tokens per wave each) kept in flight in registers
     static constexpr bool EARLY_B = EARLY_B_;           // right tokens of chunk 0 are requested together with the left ones
@@ -143,16 +145,22 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     Frag<T> afrag[CFG::KSTEPS];
     {
         Vec16<T> rawA[CFG::RIF][CFG::PPL];
-        if (wave_active) {
+        // unconditional (token indices are clamped): a branch here lets the compiler hoist the first LayerNorm under it and push
+        // the right-token requests behind the arrival of the left tokens
 #pragma unroll
-            for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawA[r], left, i0 + r * 8 + trow, w, sub);
-        }
+        for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawA[r], left, i0 + r * 8 + trow, w, sub);
         if (CFG::EARLY_B) {
 #pragma unroll
-            for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, wv * 32 + r * 8 + trow, w, sub);
+            for (int r = 0; r < CFG::RIF; ++r)
+                load_token<CFG, T>(rawB[r], right, CFG::PIPE ? r * 8 * NW + wv * 8 + trow : wv * 32 + r * 8 + trow, w, sub);
         }
-        // left operand: normalise -> (this wave's slice of Bs as scratch) -> k16 fragments in registers
-        if (wave_active) {
+        // keep every request above in front of the arithmetic below: without this the scheduler sinks the right-token loads under
+        // the LayerNorm of the left tokens (one full memory latency lost)
+        __builtin_amdgcn_sched_barrier(0);
+        // left operand: normalise -> (this wave's slice of Bs as scratch) -> k16 fragments in registers.  Unconditional (clamped
+        // duplicates for a wave past the row end): any branch between the requests and their first use lets the optimiser sink
+        // the loads into it, behind the other requests and behind the scheduling barrier above.
+        {
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
                 if (r0 > 0) {
@@ -169,6 +177,75 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
             for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
             __builtin_amdgcn_wave_barrier();
         }
+    }
+
+    if constexpr (CFG::PIPE) {
+        // ---- pipelined single-chunk path (w <= 32*NW, whole rows): the four 8-token rounds of every wave form four 8*NW-token
+        // slabs of the right row, ordered slab-major in memory request order.  After slab r is normalised, every column tile whose
+        // 32 tokens lie below 8*NW*(r+1) is multiplied and stored while the later slabs are still arriving from HBM, so the
+        // store phase of a row overlaps its own load phase inside the CU.  Barriers are plain s_barrier + lgkmcnt(0): a fenced
+        // __syncthreads() would wait for the loads still in flight.
+        auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        lds_barrier();                                            // all A-operand scratch reads done before right tokens land there
+        const int ntile_all = (w + 31) / 32;
+        float16_t acc0, acc1;
+        auto mma_pair = [&](int ct0, bool two) {
+            const T* bp0 = Bs + (size_t)(ct0 * 32 + (lane & 31)) * CFG::RS + (lane >> 5) * 8;
+            const T* bp1 = two ? bp0 + 32 * CFG::RS : bp0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            if (!(dbg & 2)) {
+#pragma unroll
+                for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                    Frag<T> b0, b1;
+                    load_frag(b0, bp0 + kk * 16);
+                    load_frag(b1, bp1 + kk * 16);
+                    mma32(acc0, b0, afrag[kk]);                   // D[j][i]: lane = left pixel i, registers = right pixels j
+                    mma32(acc1, b1, afrag[kk]);
+                }
+            }
+        };
+        int done = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jtok = r * 8 * NW + wv * 8 + trow;
+            normalize_store<CFG, T>(rawB[r], Bs + (size_t)jtok * CFG::RS, gb, sub, dbg);
+            lds_barrier();
+            int ready = r == 3 ? ntile_all : (8 * NW * (r + 1)) / 32;
+            ready = ready < ntile_all ? ready : ntile_all;
+            if (wave_active && !(dbg & 8) && ready > done) {
+                const int npair = (ready - done + 1) >> 1;
+                auto pair_ct = [&](int pp) { int pr = pp + wv; pr = pr % npair; return done + 2 * pr; };
+                mma_pair(pair_ct(0), pair_ct(0) + 1 < ready);
+                for (int pp = 0; pp < npair; ++pp) {
+                    const int ct0 = pair_ct(pp);
+                    TO* wrow = Wc + (size_t)(lane & 31) * CFG::CRS + 4 * (lane >> 5);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        store_quad<TO>(wrow + 8 * g, acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+                        store_quad<TO>(wrow + 32 + 8 * g, acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (pp + 1 < npair) mma_pair(pair_ct(pp + 1), pair_ct(pp + 1) + 1 < ready);
+                    constexpr int PPR = 64 / CFG::VECO;           // 16-B pieces per staged row (64 columns)
+                    constexpr int ITERS = 32 * PPR / 64;
+                    const int j0 = ct0 * 32;
+                    const int jlim = (ct0 + 1 < ready ? ct0 + 2 : ct0 + 1) * 32;      // a lone tile stores 32 columns only
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int q = it * 64 + lane;
+                        const int rr = q / PPR, pc = q - rr * PPR;
+                        const int i = i0 + rr;
+                        const int j = j0 + pc * CFG::VECO;
+                        const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
+                        if (i < w && j < w && j < jlim && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            done = ready;
+        }
+        return;
     }
 
     for (int c = 0; c < nchunks; ++c) {
@@ -252,6 +329,14 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 template <typename CFG, typename T, typename TO>
+static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st);
+
+// pipelined variant of a configuration (same tiling, PIPE = true) where it exists: all four token rounds resident in registers
+template <typename CFG> struct PipeOf { using type = void; };
+template <typename T, typename TO, int C, int NWCAP>
+struct PipeOf<LnCorrCfg<T, TO, C, NWCAP, 4, true, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, 4, true, true>; };
+
+template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st) {
     auto kern = ln_corr_kernel<CFG, T, TO>;
     static bool attr_done = false;                       // per instantiation
@@ -269,6 +354,13 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     if (force_nstrip > 0 && (tiles + force_nstrip - 1) / force_nstrip <= CFG::NWMAX) nstrip = force_nstrip;
     const int nw = (tiles + nstrip - 1) / nstrip;
     const int nblocks = B * h * nstrip;
+    if constexpr (!CFG::PIPE && !std::is_void<typename PipeOf<CFG>::type>::value) {
+        // measured (tools/k1_ab.py, c3 fp16): 24.2 us pipelined vs 21.3 us plain -- the extra barriers and the smaller store bursts cost
+        // more than the overlap returns, so the pipelined variant stays an opt-in experiment
+        static const bool pipe = getenv("S2M2_LNCORR_PIPE") != nullptr;
+        if (nstrip == 1 && pipe)                                  // whole rows per block: overlap the row's stores with its own loads
+            return launch_ln_corr<typename PipeOf<CFG>::type, T, TO>(feat, g, bta, cv, B, h, w, st);
+    }
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
                        static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip);
     return check_launch("ln_corr");
