@@ -561,28 +561,39 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
         __builtin_amdgcn_s_barrier();                            // plain barrier: no fence, the DMA ring is tracked by hand
         request(kt + NS - 1, slot_i);
         const unsigned stage = ring_addr + (unsigned)slot_c * CFG::STAGE_BYTES;
-#pragma unroll
-        for (int pl = 0; pl < KP; ++pl) {
+        // fragment reads run one k16 step ahead of the MFMAs (two register sets): the LDS latency of step s+1 hides under the
+        // MFMAs of step s; lgkmcnt is counted (LDS returns in order), never 0 while a younger step is in flight
+        constexpr int NSTEP = KP * CFG::PSTEPS;
+        constexpr int RPS = (CFG::MT + CFG::NTL) * (sizeof(T) == 2 ? 1 : 2);      // ds_read_b128 per step
+        RawFrag<T> xr[2][CFG::MT], wr[2][CFG::NTL];
+        auto issue_step = [&](int s, int set) __attribute__((always_inline)) {
+            const int pl = s / CFG::PSTEPS, st = s % CFG::PSTEPS;
             const unsigned plane = stage + (unsigned)pl * CFG::PLANE_BYTES;
             const unsigned a = plane + (unsigned)(wm * CFG::WM + l31) * 64;
             const unsigned b = plane + (unsigned)(BM + wn * CFG::WN + l31) * 64;
 #pragma unroll
-            for (int st = 0; st < CFG::PSTEPS; ++st) {
-                RawFrag<T> xr[CFG::MT], wr[CFG::NTL];
+            for (int i = 0; i < CFG::MT; ++i) issue_frag(xr[set][i], a + (unsigned)i * 32 * 64, st, hi, sw);
 #pragma unroll
-                for (int i = 0; i < CFG::MT; ++i) issue_frag(xr[i], a + (unsigned)i * 32 * 64, st, hi, sw);
+            for (int j = 0; j < CFG::NTL; ++j) issue_frag(wr[set][j], b + (unsigned)j * 32 * 64, st, hi, sw);
+        };
+        issue_step(0, 0);
 #pragma unroll
-                for (int j = 0; j < CFG::NTL; ++j) issue_frag(wr[j], b + (unsigned)j * 32 * 64, st, hi, sw);
+        for (int s = 0; s < NSTEP; ++s) {
+            const int set = s & 1;
+            if (s + 1 < NSTEP) {
+                issue_step(s + 1, set ^ 1);
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(RPS) : "memory");
+            } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int i = 0; i < CFG::MT; ++i) settle(xr[i]);
-#pragma unroll
-                for (int j = 0; j < CFG::NTL; ++j) settle(wr[j]);
-#pragma unroll
-                for (int i = 0; i < CFG::MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], to_frag(wr[j]), to_frag(xr[i]));    // D[cout][pixel]
             }
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i) settle(xr[set][i]);
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j) settle(wr[set][j]);
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], to_frag(wr[set][j]), to_frag(xr[set][i]));    // D[cout][pixel]
         }
         slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
         slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
@@ -593,6 +604,213 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
     stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
     __syncthreads();
     store_tile<CFG, T>(p, Cs, tid, m0, n0, M);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v3 "halo" kernel for spatial kernels (3x3, 3x1, 1x3, stride 1): the block owns a PATCH of 4 rows x 32 columns of output
+// pixels.  v1/v2 re-gather the input for each of the KH*KW taps (im2col through the texture path: at 128x128 tiles the
+// vector-memory pipe is as busy as the MFMA pipe).  Here the patch plus its halo ((4+KH-1) x (32+KW-1) pixels, 64 bytes ... 128
+// bytes of channels per pixel) is loaded ONCE per 128-byte channel chunk; every tap then reads its MFMA operand from the same
+// LDS tile at a constant row offset (a 32-pixel MFMA tile is one image row segment = 32 consecutive LDS rows: conflict-free).
+// Input traffic through the memory pipe drops from KH*KW x 16 KB to 26-30 KB per chunk; the weight tile (BN x 128 bytes per tap)
+// is double buffered exactly as in v1.  K order of the loop: (chunk, ky, kx) -- the packed weight stays (Cout, KH, KW, Cin).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BN_>
+struct ConvCfgH {
+    static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = 2, WGN = 2;
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int BK = 8 * VEC;                   // channels per chunk (128 bytes)
+    static constexpr int RS = BK + VEC;                  // LDS row stride (elements): 144 bytes
+    static constexpr int KSTEPS = BK / 16;
+    static constexpr int WM = 64, WN = BN / 2, MT = 2, NTL = WN / 32;
+    static constexpr int MAXHALO = (PH + 2) * (PW + 2);  // 204 halo pixels for 3x3
+    static constexpr int A_IT = (MAXHALO * 8 + 255) / 256;       // 16-byte pieces per thread and chunk (7)
+    static constexpr int B_IT = BN / 32;
+    static constexpr int CRS = BN + VEC;
+    static constexpr size_t A_BYTES = (size_t)MAXHALO * RS * sizeof(T);
+    static constexpr size_t B_BYTES = (size_t)2 * BN * RS * sizeof(T);
+    static constexpr size_t STAGE_BYTES = (size_t)BM * CRS * sizeof(T);
+    static constexpr size_t TILE_BYTES = A_BYTES + B_BYTES;
+    static constexpr size_t LDS_BYTES = TILE_BYTES > STAGE_BYTES ? TILE_BYTES : STAGE_BYTES;
+};
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x, int tiles_y) {
+    constexpr int BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, BK = CFG::BK, PH = CFG::PH, PW = CFG::PW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ah = reinterpret_cast<T*>(smem);                          // [halo pixels][RS]
+    T* Bs = reinterpret_cast<T*>(smem + CFG::A_BYTES);           // [2][BN][RS]
+    T* Cs = reinterpret_cast<T*>(smem);                          // [128][CRS]  (after the K loop)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv & 1, wn = wv >> 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    // patch of this block
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int n = bx / tiles_y;
+    const int y0 = ty * PH, x0 = tx * PW;
+    const int n0 = blockIdx.y * BN;
+    const int HW_ = p.KW + PW - 1, HH_ = p.KH + PH - 1;          // halo extent
+    const int nhalo = HW_ * HH_;
+    const int ph = p.KH / 2, pw = p.KW / 2;
+    const int ntap = p.KH * p.KW;
+    const int nchunk = (p.Cin + BK - 1) / BK;
+    const int nkt = nchunk * ntap;
+    const int Ktot = ntap * p.Cin;
+
+    // ---- loader state
+    const int pc = tid & 7;
+    int apix[CFG::A_IT];                                          // input pixel index of this thread's halo pixels, -1: outside / unused
+#pragma unroll
+    for (int it = 0; it < CFG::A_IT; ++it) {
+        const int hp = (tid >> 3) + 32 * it;
+        apix[it] = -1;
+        if (hp < nhalo) {
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int yy = y0 - ph + hy, xx = x0 - pw + hx;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) apix[it] = (n * p.H + yy) * p.W + xx;
+        }
+    }
+    const T* wrow[CFG::B_IT];
+    {
+        const T* wp = static_cast<const T*>(p.weight);
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) {
+            const int co = n0 + (tid >> 3) + 32 * it;
+            wrow[it] = co < p.Cout ? wp + (size_t)co * Ktot + pc * VEC : nullptr;
+        }
+    }
+    const T* zp = static_cast<const T*>(p.zero);
+    const T* const s0 = static_cast<const T*>(p.src[0]);
+    const T* const s1 = static_cast<const T*>(p.src[1]);
+    const T* const s2 = static_cast<const T*>(p.src[2]);
+    const T* const s3 = static_cast<const T*>(p.src[3]);
+    const int st0 = p.src_stride[0], st1 = p.src_stride[1], st2 = p.src_stride[2], st3 = p.src_stride[3];
+    const int c0n = p.src_c[0], c1n = c0n + p.src_c[1], c2n = c1n + p.src_c[2];
+
+    raw16_t ra[CFG::A_IT], rb[CFG::B_IT];
+    auto fetch_a = [&](int chunk) __attribute__((always_inline)) {            // halo tile of one channel chunk -> registers
+        const int kc = chunk * BK + pc * VEC;
+        const bool cvalid = kc < p.Cin;
+        const T* sp = s0;
+        unsigned ss = (unsigned)st0, c = (unsigned)kc;
+        if (p.nsrc > 1) {
+            const bool g0 = kc >= c0n, g1 = kc >= c1n, g2 = kc >= c2n;
+            const long long d1 = (const char*)s1 - (const char*)s0, d2 = (const char*)s2 - (const char*)s1, d3 = (const char*)s3 - (const char*)s2;
+            sp = reinterpret_cast<const T*>((const char*)s0 + ((g0 ? d1 : 0) + (g1 ? d2 : 0) + (g2 ? d3 : 0)));
+            ss = (unsigned)(st0 + (g0 ? st1 - st0 : 0) + (g1 ? st2 - st1 : 0) + (g2 ? st3 - st2 : 0));
+            c = (unsigned)(kc - ((g0 ? c0n : 0) + (g1 ? c1n - c0n : 0) + (g2 ? c2n - c1n : 0)));
+        }
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const unsigned e = __umul24((unsigned)apix[it], ss) + c;
+            const T* src = (cvalid && apix[it] >= 0) ? sp + e : zp;
+            ra[it] = global_load16(src);
+        }
+    };
+    auto stash_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const int hp = (tid >> 3) + 32 * it;
+            if (hp < CFG::MAXHALO) *reinterpret_cast<raw16_t*>(Ah + (size_t)hp * RS + pc * VEC) = ra[it];
+        }
+    };
+    auto fetch_b = [&](int kt) __attribute__((always_inline)) {               // weight tile of K tile kt = (chunk, tap)
+        const int chunk = kt / ntap, tap = kt - chunk * ntap;
+        const bool cvalid = chunk * BK + pc * VEC < p.Cin;
+        const int koff = tap * p.Cin + chunk * BK;
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) {
+            const T* src = (cvalid && wrow[it]) ? wrow[it] + koff : zp;
+            rb[it] = global_load16(src);
+        }
+    };
+    auto stash_b = [&](int buf) __attribute__((always_inline)) {
+        T* b = Bs + (size_t)buf * BN * RS;
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) *reinterpret_cast<raw16_t*>(b + (size_t)((tid >> 3) + 32 * it) * RS + pc * VEC) = rb[it];
+    };
+
+    float16_t acc[CFG::MT][CFG::NTL];
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    fetch_a(0);
+    fetch_b(0);
+    stash_a();
+    stash_b(0);
+    __syncthreads();
+    int tap = 0, chunk = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < nkt;
+        const bool last_tap = tap == ntap - 1;
+        const bool next_chunk = last_tap && chunk + 1 < nchunk;
+        if (more) fetch_b(kt + 1);                                // in flight under the MFMAs
+        if (tap == 0 && chunk + 1 < nchunk) fetch_a(chunk + 1);   // next halo tile: requested now, parked in registers until the last tap
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+        const T* a = Ah + (size_t)((wm * 2 + ky) * HW_ + l31 + kx) * RS + hi * 8;
+        const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + l31) * RS + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+            Frag<T> xf[CFG::MT], wf[CFG::NTL];
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * HW_ * RS + kk * 16);
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], b + (size_t)j * 32 * RS + kk * 16);
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
+        }
+        if (more) stash_b(buf ^ 1);
+        if (next_chunk) {
+            __syncthreads();                                      // every wave is done with this chunk's halo tile
+            stash_a();
+        }
+        __syncthreads();
+        if (last_tap) { tap = 0; ++chunk; } else ++tap;
+    }
+
+    // ---- epilogues: staging rows r = patch row * 32 + column (the same wm*64 + i*32 + lane map as the linear kernels)
+    stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+    __syncthreads();
+    constexpr int PCR = BN / VEC;
+    T* outp = static_cast<T*>(p.out);
+#pragma unroll 2
+    for (int q = tid; q < 128 * PCR; q += 256) {
+        const int r = q / PCR, pcc = q - r * PCR;
+        const int yy = y0 + (r >> 5), xx = x0 + (r & 31);
+        const int co = n0 + pcc * VEC;
+        if (yy >= p.H || xx >= p.W || co >= p.Cout) continue;
+        const long long m = ((long long)n * p.H + yy) * p.W + xx;
+        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
+        if (p.epi != S2M2_EPI_NONE) {
+            const Vec16<T> a0 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux0) + m * p.aux0_stride + co);
+            Vec16<T> a1 = a0;
+            if (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX)
+                a1 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux1) + m * p.aux1_stride + co);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float x = to_f32(v.v[e]), u = to_f32(a0.v[e]), w = to_f32(a1.v[e]);
+                float o;
+                if (p.epi == S2M2_EPI_ADD) o = x + u;
+                else if (p.epi == S2M2_EPI_MUL) o = x * u;
+                else if (p.epi == S2M2_EPI_GRU) o = (1.0f - u) * w + u * x;
+                else { const float gte = fminf(fmaxf(x, 0.01f), 0.99f); o = gte * u + (1.0f - gte) * w; }
+                v.v[e] = from_f32<T>(o);
+            }
+        }
+        *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + co) = v;
+    }
 }
 
 // 256 zero bytes, allocated on the first call (before any graph capture: the engine warms up eagerly)
@@ -638,12 +856,32 @@ static int launch_conv2(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
+template <typename T, int BN>
+static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
+    using CFG = ConvCfgH<T, BN>;
+    auto kern = conv_halo_kernel<CFG, T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)CFG::LDS_BYTES) != hipSuccess)
+            return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
+        attr_done = true;
+    }
+    if (a.stride != 1 || a.shuffle2 || a.korder || a.KH > 3 || a.KW > 3) return set_error("conv2d: the halo tile needs a stride-1 kernel of at most 3x3 taps in K order 0");
+    const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
+    dim3 grid((unsigned)(a.N * tx * ty), (unsigned)((a.Cout + BN - 1) / BN));
+    hipLaunchKernelGGL(kern, grid, dim3(256), CFG::LDS_BYTES, st, a, tx, ty);
+    return check_launch("conv2d");
+}
+
 template <typename T>
 static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     const long long M = (long long)a.N * a.Ho * a.Wo;
     if (tile == 0) {                                              // measured on MI355X (tools/convbench.py, profiles/r01)
         const int Ktot = a.KH * a.KW * a.Cin;
-        if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
+        if (a.KH * a.KW > 1 && a.KH <= 3 && a.KW <= 3 && a.stride == 1 && !a.shuffle2 && !a.korder)
+            tile = (a.Cout >= 128 && M >= 150000) ? 12 : 13;     // spatial kernels: halo tile (input gathered once per channel chunk)
+        else if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
         else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 5;   // 128x128, 64-byte K rows, 3 blocks/CU
         else tile = Ktot <= 512 ? 6 : 2;                          // 64x64 with 64- / 128-byte K rows
     }
@@ -659,6 +897,8 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         case 9: return launch_conv2<T, 128, 128, 2, 3>(a, st);     // v2: 96 KB, 2 tiles ahead
         case 10: return launch_conv2<T, 64, 64, 2, 4>(a, st);      // v2: 64x64, 64 KB
         case 11: return launch_conv2<T, 64, 64, 1, 4>(a, st);      // v2: 64x64, 32 KB
+        case 12: return launch_conv_halo<T, 128>(a, st);           // v3 halo tile, 4x32 pixel patch x 128 couts
+        case 13: return launch_conv_halo<T, 64>(a, st);            // v3 halo tile, x 64 couts
         default: return set_error("conv2d: unknown tile id %d", tile);
     }
 }
