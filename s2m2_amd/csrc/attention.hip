@@ -387,6 +387,7 @@ static int dispatch_attn(const AttnArgs& a, hipStream_t st) {
         switch (dp) {
             case 192: return launch_attn<T, 192, false>(a, st);
             case 256: return launch_attn<T, 256, false>(a, st);
+            case 384: return launch_attn<T, 384, false>(a, st);
             default: break;
         }
     }

@@ -48,8 +48,9 @@ struct ConvArgs {
     const void* zero;           // 256 zero bytes in global memory (what out-of-range pieces read)
 };
 
-template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8>
+template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8, int NPF_ = 1>
 struct ConvCfg {
+    static constexpr int NPF = NPF_;                     // K tiles requested ahead, in registers (short-K layers: the whole K at once)
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_;
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int PPR = PPR_;                     // 16-byte pieces per K-tile row (8: 128-byte rows, 4: 64-byte rows)
@@ -230,7 +231,7 @@ struct ConvLoader {
     KCursor<4 * VEC> cur;                      // K position of this thread's piece: channel within the tap, tap coordinates
     const T *s0, *s1, *s2, *s3;                // sources / strides / cumulative channel counts as named scalars
     int st0, st1, st2, st3, c0n, c1n, c2n;
-    raw16_t ra[CFG::A_IT], rb[CFG::B_IT];
+    raw16_t ra[CFG::NPF][CFG::A_IT], rb[CFG::NPF][CFG::B_IT];
 
     __device__ __forceinline__ void init(const ConvArgs& p, int tid, long long m0, int n0, long long M, int Ktot_) {
         pc = tid % CFG::PPR; lrow = tid / CFG::PPR; Ktot = Ktot_;
@@ -270,7 +271,7 @@ struct ConvLoader {
     }
 
     // issue the loads of K tile kt (element k = kt*BK + pc*VEC -> (tap, channel)), then advance to the next tile
-    __device__ __forceinline__ void fetch(const ConvArgs& p, int kt) {
+    __device__ __forceinline__ void fetch(const ConvArgs& p, int kt, int slot) {
         const T* zp = static_cast<const T*>(p.zero);
         const bool kvalid = kt * BK + pc * VEC < Ktot;
         const int kc = cur.kc, ky = cur.ky, kx = cur.kx;
@@ -289,27 +290,27 @@ struct ConvLoader {
         for (int it = 0; it < CFG::A_IT; ++it) {
             const unsigned e = __umul24((unsigned)(apix[it] + tapoff), ss) + c;      // pixel < 2^24, stride < 2^24, numel < 2^31
             const T* src = (tapmask[it] & tapbit) ? sp + e : zp;
-            ra[it] = global_load16(src);
+            ra[slot][it] = global_load16(src);
         }
         const int koff = kt * BK;
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
             const T* src = (kvalid && wrow[it]) ? wrow[it] + koff : zp;
-            rb[it] = global_load16(src);
+            rb[slot][it] = global_load16(src);
         }
         cur.template advance<BK>(p);
     }
 
-    __device__ __forceinline__ void stash(T* a, T* b) const {
+    __device__ __forceinline__ void stash(T* a, T* b, int slot) const {
 #pragma unroll
         for (int it = 0; it < CFG::A_IT; ++it) {
             const int r = lrow + CFG::RPI * it;
-            if (r < CFG::BM) *reinterpret_cast<raw16_t*>(a + (size_t)r * RS + pc * VEC) = ra[it];
+            if (r < CFG::BM) *reinterpret_cast<raw16_t*>(a + (size_t)r * RS + pc * VEC) = ra[slot][it];
         }
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
             const int r = lrow + CFG::RPI * it;
-            if (r < BN) *reinterpret_cast<raw16_t*>(b + (size_t)r * RS + pc * VEC) = rb[it];
+            if (r < BN) *reinterpret_cast<raw16_t*>(b + (size_t)r * RS + pc * VEC) = rb[slot][it];
         }
     }
 };
@@ -342,35 +343,47 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    ld.fetch(p, 0);
-    ld.stash(As, Bs);
+    // K tiles are requested NPF ahead into a ring of register slots (slot = tile % NPF, static after unrolling): for the short-K
+    // layers (1x1, K <= NPF tiles) the whole K of the block is in flight at once -- one memory latency per block instead of one per tile
+    constexpr int NPF = CFG::NPF;
+#pragma unroll
+    for (int f = 0; f < NPF; ++f)
+        if (f < nkt) ld.fetch(p, f, f);
+    ld.stash(As, Bs, 0);
     __syncthreads();
-    for (int kt = 0; kt < ((S2M2_CONV_DBG & 64) ? 0 : nkt); ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt && !(S2M2_CONV_DBG & 1)) ld.fetch(p, kt + 1);   // global loads in flight under the MFMAs
-        const T* a = As + (size_t)buf * BM * RS + (size_t)(wm * CFG::WM + (lane & 31)) * RS + (lane >> 5) * 8;
-        const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + (lane & 31)) * RS + (lane >> 5) * 8;
+    const int nkt_run = (S2M2_CONV_DBG & 64) ? 0 : nkt;
+    for (int kt0 = 0; kt0 < nkt_run; kt0 += NPF) {
 #pragma unroll
-        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-            Frag<T> xf[CFG::MT], wf[CFG::NTL];
+        for (int f = 0; f < NPF; ++f) {
+            const int kt = kt0 + f;
+            if (kt >= nkt_run) break;
+            const int buf = kt & 1;
+            if (kt + NPF < nkt && !(S2M2_CONV_DBG & 1)) ld.fetch(p, kt + NPF, f);     // slot f was stashed one iteration ago: refill
+            const T* a = As + (size_t)buf * BM * RS + (size_t)(wm * CFG::WM + (lane & 31)) * RS + (lane >> 5) * 8;
+            const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + (lane & 31)) * RS + (lane >> 5) * 8;
 #pragma unroll
-            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], (S2M2_CONV_DBG & 8) ? a : a + (size_t)i * 32 * RS + kk * 16);
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                Frag<T> xf[CFG::MT], wf[CFG::NTL];
 #pragma unroll
-            for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], (S2M2_CONV_DBG & 8) ? b : b + (size_t)j * 32 * RS + kk * 16);
-            if (!(S2M2_CONV_DBG & 2)) {
+                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], (S2M2_CONV_DBG & 8) ? a : a + (size_t)i * 32 * RS + kk * 16);
 #pragma unroll
-                for (int i = 0; i < CFG::MT; ++i)
+                for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], (S2M2_CONV_DBG & 8) ? b : b + (size_t)j * 32 * RS + kk * 16);
+                if (!(S2M2_CONV_DBG & 2)) {
 #pragma unroll
-                    for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
-            } else {
+                    for (int i = 0; i < CFG::MT; ++i)
 #pragma unroll
-                for (int i = 0; i < CFG::MT; ++i)
+                        for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
+                } else {
 #pragma unroll
-                    for (int j = 0; j < CFG::NTL; ++j) acc[i][j][0] += to_f32(wf[j].v[0]) + to_f32(xf[i].v[0]);
+                    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < CFG::NTL; ++j) acc[i][j][0] += to_f32(wf[j].v[0]) + to_f32(xf[i].v[0]);
+                }
             }
+            if (kt + 1 < nkt && !(S2M2_CONV_DBG & 4))
+                ld.stash(As + (size_t)(buf ^ 1) * BM * RS, Bs + (size_t)(buf ^ 1) * BN * RS, (f + 1) % NPF);
+            __syncthreads();
         }
-        if (kt + 1 < nkt && !(S2M2_CONV_DBG & 4)) ld.stash(As + (size_t)(buf ^ 1) * BM * RS, Bs + (size_t)(buf ^ 1) * BN * RS);
-        __syncthreads();
     }
 
     // ---- epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]
@@ -813,6 +826,148 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v4 "pointwise" kernel for 1x1 convolutions / linear layers (K = Cin <= 512): these are streaming, HBM-bound GEMMs (M ~ 10^5
+// pixels, K and N a few hundred) where the tiled kernels spend most of their time in per-block prologues: every 64x64 tile
+// re-loads its weight slice and drains its two-tile pipeline.  Here a PERSISTENT block keeps the weight slice of its BN output
+// channels in LDS for its whole life and walks over pixel tiles of 64: the activation stream (64 px x 128 bytes per step, double
+// buffered through registers) never stops at tile boundaries, the epilogue of tile i (staging tile separate from the ring) runs
+// under the loads of tile i+1, and the memory pipe carries activations only.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BN_>
+struct ConvCfgP {
+    static constexpr int BM = 64, BN = BN_, WGM = 2, WGN = 2;
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int BK = 8 * VEC;                   // K elements per step (128 bytes)
+    static constexpr int RS = BK + VEC;                  // activation row stride in LDS (elements)
+    static constexpr int KSTEPS = BK / 16;
+    static constexpr int WM = 32, WN = BN / 2, MT = 1, NTL = WN / 32;
+    static constexpr int A_IT = 2;                       // 64 rows x 8 pieces / 256 threads
+    static constexpr int CRS = BN + VEC;
+    static constexpr size_t A_BYTES = (size_t)2 * BM * RS * sizeof(T);
+    static constexpr size_t C_BYTES = (size_t)BM * CRS * sizeof(T);
+    static size_t w_bytes(int K) { return (size_t)BN * (K + VEC) * sizeof(T); }
+    static size_t lds_bytes(int K) { return A_BYTES + C_BYTES + w_bytes(K); }
+};
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(256) void conv_pw_kernel(ConvArgs p, int ntiles) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, BK = CFG::BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* As = reinterpret_cast<T*>(smem);                                  // [2][BM][RS]
+    T* Cs = reinterpret_cast<T*>(smem + CFG::A_BYTES);                   // [BM][CRS]
+    T* Ws = reinterpret_cast<T*>(smem + CFG::A_BYTES + CFG::C_BYTES);    // [BN][K + VEC]
+    const int K = p.Cin;
+    const int WRS = K + VEC;
+    const int nchunk = (K + BK - 1) / BK;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv & 1, wn = wv >> 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const long long M = (long long)p.N * p.H * p.W;
+    const int n0 = blockIdx.y * BN;
+    const T* zp = static_cast<const T*>(p.zero);
+
+    // ---- weight slice -> LDS once (rows past Cout are zero)
+    {
+        const T* wp = static_cast<const T*>(p.weight);
+        const int ppr = K / VEC;                                          // pieces per weight row
+        for (int q = tid; q < BN * ppr; q += 256) {
+            const int r = q / ppr, pc = q - r * ppr;
+            const int co = n0 + r;
+            const T* src = co < p.Cout ? wp + (size_t)co * K + pc * VEC : zp;
+            *reinterpret_cast<raw16_t*>(Ws + (size_t)r * WRS + pc * VEC) = global_load16(src);
+        }
+    }
+    // ---- activation loader: piece column pc of rows lrow, lrow + 32 of the current pixel tile
+    const int pc = tid & 7, lrow = tid >> 3;
+    const T* const s0 = static_cast<const T*>(p.src[0]);
+    const T* const s1 = static_cast<const T*>(p.src[1]);
+    const T* const s2 = static_cast<const T*>(p.src[2]);
+    const T* const s3 = static_cast<const T*>(p.src[3]);
+    const int st0 = p.src_stride[0], st1 = p.src_stride[1], st2 = p.src_stride[2], st3 = p.src_stride[3];
+    const int c0n = p.src_c[0], c1n = c0n + p.src_c[1], c2n = c1n + p.src_c[2];
+    raw16_t ra[CFG::A_IT];
+    auto fetch = [&](long long m0, int chunk) __attribute__((always_inline)) {
+        const int kc = chunk * BK + pc * VEC;
+        const bool cvalid = kc < K;
+        const T* sp = s0;
+        unsigned ss = (unsigned)st0, c = (unsigned)kc;
+        if (p.nsrc > 1) {
+            const bool g0 = kc >= c0n, g1 = kc >= c1n, g2 = kc >= c2n;
+            const long long d1 = (const char*)s1 - (const char*)s0, d2 = (const char*)s2 - (const char*)s1, d3 = (const char*)s3 - (const char*)s2;
+            sp = reinterpret_cast<const T*>((const char*)s0 + ((g0 ? d1 : 0) + (g1 ? d2 : 0) + (g2 ? d3 : 0)));
+            ss = (unsigned)(st0 + (g0 ? st1 - st0 : 0) + (g1 ? st2 - st1 : 0) + (g2 ? st3 - st2 : 0));
+            c = (unsigned)(kc - ((g0 ? c0n : 0) + (g1 ? c1n - c0n : 0) + (g2 ? c2n - c1n : 0)));
+        }
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const long long m = m0 + lrow + 32 * it;
+            const T* src = (cvalid && m < M) ? sp + (unsigned)m * ss + c : zp;
+            ra[it] = global_load16(src);
+        }
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {
+        T* a = As + (size_t)buf * BM * RS;
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) *reinterpret_cast<raw16_t*>(a + (size_t)(lrow + 32 * it) * RS + pc * VEC) = ra[it];
+    };
+
+    float16_t acc[CFG::MT][CFG::NTL];
+#pragma unroll
+    for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    // flat walk over (tile, chunk): step s -> tile blockIdx.x + (s / nchunk) * gridDim.x
+    const int mytiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nstep = mytiles * nchunk;
+    if (nstep <= 0) return;
+    long long mt_cur = blockIdx.x;                                        // tile of the step being multiplied
+    int chunk_cur = 0;
+    long long mt_nxt = blockIdx.x;                                        // tile / chunk of the step being fetched
+    int chunk_nxt = 0;
+    fetch(mt_nxt * BM, chunk_nxt);
+    stash(0);
+    __syncthreads();                                                      // also publishes the weight slice
+#pragma unroll 1
+    for (int s = 0; s < nstep; ++s) {
+        const int buf = s & 1;
+        if (++chunk_nxt == nchunk) { chunk_nxt = 0; mt_nxt += gridDim.x; }
+        const bool more = s + 1 < nstep;
+        if (more) fetch(mt_nxt * BM, chunk_nxt);                          // in flight under the MFMAs and the epilogue
+        const T* a = As + (size_t)buf * BM * RS + (size_t)(wm * 32 + l31) * RS + hi * 8;
+        const T* b = Ws + (size_t)(wn * CFG::WN + l31) * WRS + chunk_cur * BK + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+            Frag<T> xf, wf[CFG::NTL];
+            load_frag(xf, a + kk * 16);
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], b + (size_t)j * 32 * WRS + kk * 16);
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j) mma32(acc[0][j], wf[j], xf);      // D[cout][pixel]
+        }
+        if (chunk_cur == nchunk - 1) {
+            // ---- tile finished: epilogue (Cs is separate from the ring; the k-step barriers order its reuse)
+            stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            store_tile<CFG, T>(p, Cs, tid, mt_cur * BM, n0, M);
+            mt_cur += gridDim.x;
+            chunk_cur = 0;
+        } else {
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            ++chunk_cur;
+        }
+    }
+}
+
 // 256 zero bytes, allocated on the first call (before any graph capture: the engine warms up eagerly)
 static const void* zero_page() {
     static void* z = nullptr;
@@ -822,9 +977,9 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BM, int BN, int WGM, int PPR = 8>
+template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    using CFG = ConvCfg<T, BM, BN, WGM, PPR>;
+    using CFG = ConvCfg<T, BM, BN, WGM, PPR, NPF>;
     auto kern = conv_igemm_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -874,6 +1029,30 @@ static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
+template <typename T, int BN>
+static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
+    using CFG = ConvCfgP<T, BN>;
+    auto kern = conv_pw_kernel<CFG, T>;
+    if (a.KH != 1 || a.KW != 1 || a.stride != 1) return set_error("conv2d: the pointwise kernel needs a 1x1 stride-1 layer");
+    const size_t lds = CFG::lds_bytes(a.Cin);
+    if (lds > 160 * 1024) return set_error("conv2d: pointwise kernel: Cin=%d needs %zu bytes of LDS", a.Cin, lds);
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return set_error("conv2d: cannot reserve %zu bytes of LDS", lds);
+        attr_bytes = lds;
+    }
+    const long long M = (long long)a.N * a.H * a.W;
+    const int ntiles = (int)((M + CFG::BM - 1) / CFG::BM);
+    const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;      // co-resident blocks per CU
+    const int ny = (a.Cout + BN - 1) / BN;
+    int gx = 256 * per_cu / ny;                                   // persistent grid: one wave of blocks over the chip
+    gx = gx < 1 ? 1 : gx;
+    gx = gx > ntiles ? ntiles : gx;
+    hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(256), lds, st, a, ntiles);
+    return check_launch("conv2d");
+}
+
 template <typename T>
 static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     const long long M = (long long)a.N * a.Ho * a.Wo;
@@ -899,6 +1078,11 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         case 11: return launch_conv2<T, 64, 64, 1, 4>(a, st);      // v2: 64x64, 32 KB
         case 12: return launch_conv_halo<T, 128>(a, st);           // v3 halo tile, 4x32 pixel patch x 128 couts
         case 13: return launch_conv_halo<T, 64>(a, st);            // v3 halo tile, x 64 couts
+        case 14: return launch_conv_pw<T, 128>(a, st);             // v4 persistent pointwise, 128 couts per block
+        case 15: return launch_conv_pw<T, 64>(a, st);              // v4 persistent pointwise, 64 couts per block
+        case 16: return launch_conv<T, 64, 64, 2, 4, 4>(a, st);    // 64x64, 64-byte K rows, 4 K tiles in flight
+        case 17: return launch_conv<T, 64, 64, 2, 8, 4>(a, st);    // 64x64, 128-byte K rows, 4 K tiles in flight
+        case 18: return launch_conv<T, 128, 128, 2, 4, 4>(a, st);  // 128x128, 64-byte K rows, 4 K tiles in flight
         default: return set_error("conv2d: unknown tile id %d", tile);
     }
 }

@@ -90,11 +90,12 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     const long long p0 = (long long)blockIdx.x * pix_per_block;
     const long long p1 = p0 + pix_per_block < HW ? p0 + pix_per_block : HW;
     const T* xn = x + (long long)n * HW * C;
-    // a thread always visits the same piece column (256 % P == 0 is required) -> one group per thread
+    // a thread always visits the same piece column -> one group per thread: the (256 / P) * P lowest threads stride by that count
+    const int nact = (256 / P) * P;
     const int pi = threadIdx.x % P;
     const int g = pi * VEC / cpg;
     float s = 0.f, ss = 0.f;
-    for (long long q = p0 * P + threadIdx.x; q < p1 * P; q += 256) {
+    for (long long q = p0 * P + threadIdx.x; q < p1 * P && (int)threadIdx.x < nact; q += nact) {
         const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(xn + q * VEC);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { const float f = to_f32(v.v[e]); s += f; ss = __builtin_fmaf(f, f, ss); }
@@ -183,7 +184,7 @@ extern "C" int s2m2_groupnorm_nhwc(const void* x, void* y, const float* gamma, c
     const int vec = dtype == S2M2_F16 ? 8 : 4;
     S2M2_REQUIRE(N > 0 && HW > 0 && G > 0 && G <= 32 && C % G == 0 && (C / G) % vec == 0,
                  "groupnorm: N=%d HW=%lld C=%d G=%d (C/G must be a multiple of %d, G <= 32)", N, HW, C, G, vec);
-    S2M2_REQUIRE(256 % (C / vec) == 0, "groupnorm: C/%d = %d must divide 256", vec, C / vec);
+    S2M2_REQUIRE(C / vec <= 256, "groupnorm: C=%d too wide", C);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == S2M2_F16) return run_groupnorm<half_t>(x, y, gamma, beta, static_cast<double*>(workspace), N, HW, C, G, eps, st);
     if (dtype == S2M2_F32) return run_groupnorm<float>(x, y, gamma, beta, static_cast<double*>(workspace), N, HW, C, G, eps, st);

@@ -55,15 +55,22 @@ CASES = [
 ]
 # every block-tile variant (v1 with 64-byte K rows: 5, 6; v2 LDS-direct ring: 7..11) on shapes with M / K / Cout tails,
 # multi-source concatenation and zero padding
-for _t in (5, 6, 7, 8, 9, 10, 11, 12, 13):
+for _t in (5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 18):
     CASES += [(1, 17, 23, [128], 128, 3, 3, 1, _t), (2, 13, 21, [96, 64, 64, 160], 256, 1, 1, 1, _t), (1, 20, 28, [2, 128], 136, 3, 3, 3, _t),
               (1, 33, 19, [128, 128], 128, 3, 1, 4, _t), (1, 9, 11, [8], 96, 3, 3, 1, _t), (2, 19, 70, [128, 128], 128, 1, 3, 0, _t)]
+
+# v4 persistent pointwise kernel (1x1 only): pixel-count tails, Cout tails, concatenated sources, three K chunks
+for _t in (14, 15):
+    CASES += [(2, 37, 53, [128], 128, 1, 1, 1, _t), (1, 40, 56, [96, 64, 64, 160], 256, 1, 1, 3, _t), (1, 64, 70, [256], 136, 1, 1, 0, _t),
+              (3, 16, 16, [128, 128], 72, 1, 1, 4, _t)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("case", CASES)
 def test_conv_vs_torch(hip, case, dtype):
     N, H, W, cs, Cout, KH, KW, act, tile = case
+    if tile == 14 and dtype == torch.float32 and sum(cs) >= 256:
+        pytest.skip("weight slice of 128 fp32 output channels x 384 does not fit the LDS (the dispatcher never picks it)")
     g = torch.Generator(device="cuda").manual_seed(CASES.index(case))
     srcs_real = [torch.randn(N, H, W, c, device="cuda", generator=g).to(dtype) for c in cs]
     cin = sum(cs)

@@ -30,7 +30,7 @@ def test_layernorm_rows(hip, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("shape", [(2, 24, 40, 128, 8), (1, 33, 17, 128, 8), (2, 16, 16, 256, 8)])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 128, 8), (1, 33, 17, 128, 8), (2, 16, 16, 256, 8), (1, 20, 28, 192, 8), (1, 12, 20, 384, 8)])
 def test_groupnorm_nhwc(hip, dtype, shape):
     N, H, W, C, G = shape
     g = torch.Generator(device="cuda").manual_seed(H)

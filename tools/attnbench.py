@@ -6,7 +6,8 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from s2m2_amd import hip
 from s2m2_amd.engine import pe_tables
-from tools.kbench import timeit
+from tools.kbench import timeit_graph
+timeit = lambda fn, n: timeit_graph(fn, 20, 3)
 SHAPES = [("L0 self 1-D", 512, 1, 304, 128, False, None), ("L0 cross 1-D", 512, 1, 304, 128, True, None), ("L1 1-D", 256, 2, 152, 64, False, None),
           ("L2 1-D", 128, 4, 76, 64, False, None), ("L3 2-D self", 2, 8, 1216, 32, False, None), ("L3 2-D cross", 2, 8, 1216, 32, True, None),
           ("refiner 2-D", 1, 8, 1216, 32, False, None), ("global ref 2-D", 1, 8, 1216, 16, False, None), ("pyramid PE", 2, 8, 1216, 32, False, (32, 38))]

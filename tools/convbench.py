@@ -11,7 +11,11 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from s2m2_amd import hip, pack  # noqa: E402
-from tools.kbench import timeit  # noqa: E402
+from tools.kbench import timeit_graph  # noqa: E402
+
+
+def timeit(fn, iters):
+    return timeit_graph(fn, 20, 3)
 
 SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
     ("1/4 3x3 128->128", 1, 256, 304, 128, 128, 3, 3),
@@ -48,7 +52,7 @@ def main():
         t_ref = timeit(lambda: F.gelu(F.conv2d(xn, wcl, bh, padding=(kh // 2, kw // 2))), a.iters)
         line = f"{name:24s} torch conv+gelu {t_ref:8.1f} us ({fl / t_ref / 1e6:6.1f} TF/s) |"
         wk = pack.pack_conv(w, torch.float16, korder=1) if ci % 32 == 0 else None
-        for tile in (2, 5, 8, 12, 13):
+        for tile in ((2, 5, 6, 16, 17, 18) if kh * kw == 1 else (12, 13, 16)):
             t = timeit(lambda: hip.conv2d([x], wp, bp, kh, kw, wp.shape[0], act=hip.ACT_GELU, tile=tile), a.iters)
             line += f" t{tile} {t:8.1f} us ({fl / t / 1e6:6.1f})"
             if wk is not None and kw > 1 and tile < 12:

@@ -15,6 +15,33 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from s2m2_amd import hip  # noqa: E402
 
 
+def timeit_graph(fn, iters=20, reps=5):
+    """GPU time per call with the host out of the loop: `iters` launches captured in one hipGraph, replayed `reps` times.
+    (Eager back-to-back launches through ctypes cost ~10 us of host time each, more than many of the kernels.)"""
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        fn()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(iters):
+                fn()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        g.replay()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / (iters * reps)
+
+
 def timeit(fn, iters, warmup=5):
     for _ in range(warmup):
         fn()
