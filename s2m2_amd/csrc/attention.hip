@@ -33,8 +33,9 @@ struct AttnArgs {
     const float* px; const float* py; void* pe_out; long long spe; int gw, gh;
 };
 
-template <typename T, int DP_, bool PE_, int MINW_ = 4>
+template <typename T, int DP_, bool PE_, int MINW_ = 4, bool KSPLIT_ = false>
 struct AttnCfg {
+    static constexpr bool KSPLIT = KSPLIT_;              // the 4 waves of a block share ONE 32-query tile and split its keys (few, long rows)
     static constexpr int MINW = MINW_;                   // fewest waves a block is launched with (sizes the staging registers)
     static constexpr int DP = DP_;                       // head dim rounded up to a multiple of 16
     static constexpr bool PE = PE_;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     const int bh = blockIdx.y;
     const int b = bh / a.heads, hd = bh - b * a.heads;
     const int bkv = a.swap ? (b + a.nb / 2) % a.nb : b;
-    const int q0 = (blockIdx.x * NW + wv) * 32;
+    const int q0 = CFG::KSPLIT ? blockIdx.x * 32 : (blockIdx.x * NW + wv) * 32;
     const bool wave_active = q0 < a.Nq;
 
     const T* qb = static_cast<const T*>(a.q) + (long long)b * a.Nq * a.sq + hd * a.D;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
         if (t + 1 < nstage) fetch((t + 1) * KVT);                 // in flight under this stage's MFMAs
         if (wave_active) {
 #pragma unroll 1
-            for (int sub = 0; sub < CFG::KT; ++sub) {
+            for (int sub = CFG::KSPLIT ? wv : 0; sub < (CFG::KSPLIT ? wv + 1 : CFG::KT); ++sub) {
                 const int kv0 = t * KVT + sub * 32;
                 if (kv0 >= a.Nk) break;
                 // ---- S^T = K . Q^T
@@ -295,6 +296,64 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
         }
     }
 
+    if constexpr (CFG::KSPLIT) {
+        // ---- the four waves hold partial (max, sum, O, pe) over disjoint key subsets of the SAME 32 queries: merge through LDS
+        static_assert(CFG::KT == 4, "key split uses one 32-key sub-tile per wave and stage");
+        __syncthreads();                                          // K/V staging (and the PE tables) are dead: reuse the space
+        float* mm = reinterpret_cast<float*>(smem);               // [4][32] running max
+        float* ml = mm + 128;                                     // [4][32] running sum
+        float* mo = ml + 128;                                     // [4][32][DPO] partial O (DPO = ND*32 + 1: odd stride, conflict-free)
+        constexpr int DPO = ND * 32 + 1;
+        float* mp = mo + 4 * 32 * DPO;                            // [4][32][33] partial pe (PE only)
+        const float lw = l_run + __shfl_xor(l_run, 32, 64);
+        if (hi == 0) { mm[wv * 32 + l31] = m_run; ml[wv * 32 + l31] = lw; }
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mo[(wv * 32 + l31) * DPO + dt * 32 + acc_row(r, lane)] = oacc[dt][r];
+        if constexpr (CFG::PE) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) pe_acc[c] += __shfl_xor(pe_acc[c], 32, 64);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) mp[(wv * 32 + l31) * 33 + 16 * hi + c] = hi ? pe_acc[16 + c] : pe_acc[c];
+        }
+        __syncthreads();
+        // thread t: query t & 31, channel group t >> 5 (8 groups)
+        const int q = tid & 31, grp = tid >> 5;
+        const int qi = q0 + q;
+        float mx = fmaxf(fmaxf(mm[q], mm[32 + q]), fmaxf(mm[64 + q], mm[96 + q]));
+        float f[4], lsum = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) { f[w4] = expf(mm[w4 * 32 + q] - mx); lsum += f[w4] * ml[w4 * 32 + q]; }   // exp(-inf) = 0: idle wave
+        const float inv = 1.0f / lsum;
+        if (qi < a.Nq) {
+            T* op = static_cast<T*>(a.out) + ((long long)b * a.Nq + qi) * a.so + hd * a.D;
+            for (int d0 = grp * 4; d0 < a.D; d0 += 32) {
+                Quad<T> qd;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) v += f[w4] * mo[(w4 * 32 + q) * DPO + d0 + e];
+                    qd.v[e] = from_f32<T>(v * inv);
+                }
+                *reinterpret_cast<Quad<T>*>(op + d0) = qd;
+            }
+            if constexpr (CFG::PE) {
+                T* pp = static_cast<T*>(a.pe_out) + ((long long)b * a.Nq + qi) * a.spe + hd * 32 + grp * 4;
+                Quad<T> qd;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) v += f[w4] * mp[(w4 * 32 + q) * 33 + grp * 4 + e];
+                    qd.v[e] = from_f32<T>(0.5f * v * inv);
+                }
+                *reinterpret_cast<Quad<T>*>(pp) = qd;
+            }
+        }
+        return;
+    }
     if (!wave_active) return;
     // ---- normalise and store: lane owns query q0 + l31, d = 32*dt + 8*g + 4*hi + 0..3
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -336,12 +395,16 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     }
 }
 
-template <typename T, int DP, bool PE, int MINW>
+template <typename T, int DP, bool PE, int MINW, bool KSPLIT = false>
 static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
-    using CFG = AttnCfg<T, DP, PE, MINW>;
+    using CFG = AttnCfg<T, DP, PE, MINW, KSPLIT>;
     auto kern = attention_kernel<CFG, T>;
     size_t lds = CFG::K_BYTES + CFG::V_BYTES;
     if (PE) lds += (size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 * sizeof(float);
+    if (KSPLIT) {
+        const size_t merge = (size_t)(256 + 4 * 32 * (CFG::ND * 32 + 1) + (PE ? 4 * 32 * 33 : 0)) * sizeof(float);
+        lds = lds > merge ? lds : merge;
+    }
     if (lds > 160 * 1024) return set_error("attention: %zu bytes of LDS needed", lds);
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
@@ -350,7 +413,7 @@ static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
         attr_bytes = lds;
     }
     const int ntq = (a.Nq + 31) / 32;
-    const int nblk = (ntq + nw - 1) / nw;
+    const int nblk = KSPLIT ? ntq : (ntq + nw - 1) / nw;
     hipLaunchKernelGGL(kern, dim3(nblk, a.nb * a.heads), dim3(nw * 64), lds, st, a);
     return check_launch("attention");
 }
@@ -363,6 +426,10 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     int nblk = (ntq + MAXW - 1) / MAXW;
     int nw = (ntq + nblk - 1) / nblk;                              // <= MAXW waves per block, minimal idle tail
     if constexpr (DP <= 64) {
+        // few, long rows (the 2-D global blocks at 1/32: 8-16 (batch, head) pairs x 1216 tokens): a wave per query tile would leave
+        // three quarters of the chip idle and walk all keys serially -> four waves per query tile, each taking every fourth 32-key
+        // sub-tile, partial softmax states merged through LDS
+        if ((long long)ntq * bh < 2048 && a.Nk >= 256) return launch_attn_w<T, DP, PE, 4, true>(a, 4, st);
         // few (batch, head) pairs (the 2-D global blocks at 1/32): smaller blocks until the grid covers the chip; every block
         // re-stages K/V from L2, which is cheap next to an idle GPU
         while (nw > 2 && (long long)((ntq + nw - 1) / nw) * bh < 512) nw = (nw + 1) / 2;
