@@ -203,6 +203,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
         for (int c = 0; c < 32; ++c) pe_acc[c] = 0.f;
     }
     float m_run = -INFINITY, l_run = 0.f;
+    const float scale2 = a.scale * 1.44269504088896340736f;
     // query grid coordinates (PE)
     int qi_pe = q0 + l31;
     qi_pe = qi_pe < a.Nq ? qi_pe : a.Nq - 1;
@@ -232,26 +233,29 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                     mma32(sacc, kf, qf[kk]);
                 }
                 // ---- online softmax (lane: one query, keys crow(r, hi) of this sub-tile)
+                // scores in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 = 2^x): m_run, m_new are log2-domain maxima
                 float p[16];
                 float mloc = -INFINITY;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int kv = kv0 + acc_row(r, lane);
-                    p[r] = kv < a.Nk ? sacc[r] * a.scale : -INFINITY;
+                    p[r] = kv < a.Nk ? sacc[r] * scale2 : -INFINITY;
                     mloc = fmaxf(mloc, p[r]);
                 }
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
                 const float m_new = fmaxf(m_run, mloc);           // finite: every sub-tile has at least one valid key
-                const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 2^(-inf) = 0 on the first tile
                 float lsum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = expf(p[r] - m_new); lsum += p[r]; }
+                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - m_new); lsum += p[r]; }
                 l_run = l_run * alpha + lsum;
                 m_run = m_new;
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {                 // the running maximum rarely moves after the first tiles
 #pragma unroll
-                for (int dt = 0; dt < ND; ++dt)
+                    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                }
                 // ---- O^T += Vt . P^T
                 Frag<T> pf[2];
                 make_pfrag<T>(pf[0], p);
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
         float mx = fmaxf(fmaxf(mm[q], mm[32 + q]), fmaxf(mm[64 + q], mm[96 + q]));
         float f[4], lsum = 0.f;
 #pragma unroll
-        for (int w4 = 0; w4 < 4; ++w4) { f[w4] = expf(mm[w4 * 32 + q] - mx); lsum += f[w4] * ml[w4 * 32 + q]; }   // exp(-inf) = 0: idle wave
+        for (int w4 = 0; w4 < 4; ++w4) { f[w4] = __builtin_amdgcn_exp2f(mm[w4 * 32 + q] - mx); lsum += f[w4] * ml[w4 * 32 + q]; }   // log2 domain; 2^(-inf) = 0: idle wave
         const float inv = 1.0f / lsum;
         if (qi < a.Nq) {
             T* op = static_cast<T*>(a.out) + ((long long)b * a.Nq + qi) * a.so + hd * a.D;
