@@ -427,8 +427,10 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int MAXW = AttnCfg<T, DP, PE>::MAXW;
     const int ntq = (a.Nq + 31) / 32;
     const int bh = a.nb * a.heads;
-    int nblk = (ntq + MAXW - 1) / MAXW;
-    int nw = (ntq + nblk - 1) / nblk;                              // <= MAXW waves per block, minimal idle tail
+    // register-heavy head dims (d >= 96: ~190-250 VGPRs = 8 waves per CU): blocks of at most 4 waves so that two are co-resident
+    const int maxw = (DP >= 96 && MAXW > 4) ? 4 : MAXW;
+    int nblk = (ntq + maxw - 1) / maxw;
+    int nw = (ntq + nblk - 1) / nblk;                              // <= maxw waves per block, minimal idle tail
     if constexpr (DP <= 64) {
         // few, long rows (the 2-D global blocks at 1/32: 8-16 (batch, head) pairs x 1216 tokens): a wave per query tile would leave
         // three quarters of the chip idle and walk all keys serially -> four waves per query tile, each taking every fourth 32-key
