@@ -193,6 +193,14 @@ int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf
                        int dtype, void* stream);
 int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream);
 
+/*
+ * [8f-1] image_pad of the reference driver (src/s2m2/core/utils/image_utils.py:27-71), on the device: (B,C,H,W) planar image
+ *   (img_dtype S2M2_F32 / S2M2_F16 / 2 = uint8) -> out (B,C,Hn,Wn) fp32, Hn/Wn = H/W rounded up to multiples of `factor`, the
+ *   original image centred (offset (Hn-H)/2, (Wn-W)/2); the border = bilinear (align_corners=False) upsampling of the adaptive
+ *   average pooling of the zero-padded image to (H/factor, W/factor).  pooled: scratch (B,C,H/factor,W/factor) fp32.
+ */
+int s2m2_image_pad(const void* img, float* pooled, float* out, int B, int C, int H, int W, int factor, int img_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,3 +164,78 @@ extern "C" int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* s
     else return set_error("tanh: unsupported dtype %d", dtype);
     return check_launch("tanh");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// image_pad (reference src/s2m2/core/utils/image_utils.py:27-71): pad (B,C,H,W) to multiples of `factor` -- the border is NOT
+// zero: it is a bilinear (align_corners=False) upsampling of the adaptive average pooling of the ZERO-padded image to
+// (H/factor, W/factor), and the original image is pasted back in the middle.  Two small launches: pooling, then fill + paste.
+// ---------------------------------------------------------------------------------------------------------------
+namespace s2m2 {
+
+template <typename TI>
+__global__ __launch_bounds__(256) void pad_pool_kernel(const TI* __restrict__ img, float* __restrict__ pooled, int BC, int H, int W,
+                                                       int Hn, int Wn, int Ho, int Wo, int hs, int ws) {
+    // one wave per output bin: adaptive_avg_pool2d bins [floor(i*Hn/Ho), ceil((i+1)*Hn/Ho)) of the zero-padded image
+    const int lane = threadIdx.x & 63;
+    const long long bin = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (bin >= (long long)BC * Ho * Wo) return;
+    const int ox = (int)(bin % Wo);
+    const long long t = bin / Wo;
+    const int oy = (int)(t % Ho);
+    const long long bc = t / Ho;
+    const int y0 = (int)(((long long)oy * Hn) / Ho), y1 = (int)((((long long)oy + 1) * Hn + Ho - 1) / Ho);
+    const int x0 = (int)(((long long)ox * Wn) / Wo), x1 = (int)((((long long)ox + 1) * Wn + Wo - 1) / Wo);
+    const int bw = x1 - x0, n = (y1 - y0) * bw;
+    const TI* src = img + bc * (long long)H * W;
+    float s = 0.f;
+    for (int k = lane; k < n; k += 64) {
+        const int yy = y0 + k / bw - hs, xx = x0 + k % bw - ws;       // coordinates in the original image
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += (float)src[(long long)yy * W + xx];
+    }
+    s = wave_sum(s);
+    if (lane == 0) pooled[bin] = s / (float)n;
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void pad_fill_kernel(const TI* __restrict__ img, const float* __restrict__ pooled, float* __restrict__ out,
+                                                       int BC, int H, int W, int Hn, int Wn, int Ho, int Wo, int hs, int ws) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)BC * Hn * Wn) return;
+    const int X = (int)(gid % Wn);
+    const long long t = gid / Wn;
+    const int Y = (int)(t % Hn);
+    const long long bc = t / Hn;
+    const int yy = Y - hs, xx = X - ws;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) { out[gid] = (float)img[(bc * H + yy) * (long long)W + xx]; return; }
+    // F.interpolate(mode='bilinear', align_corners=False): src = max((dst + 0.5) * in/out - 0.5, 0)
+    const float sy = fmaxf(((float)Y + 0.5f) * ((float)Ho / (float)Hn) - 0.5f, 0.f);
+    const float sx = fmaxf(((float)X + 0.5f) * ((float)Wo / (float)Wn) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Ho - 1), x1 = x0 + (x0 < Wo - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float* pp = pooled + bc * (long long)Ho * Wo;
+    out[gid] = (1.f - ly) * ((1.f - lx) * pp[y0 * Wo + x0] + lx * pp[y0 * Wo + x1]) + ly * ((1.f - lx) * pp[y1 * Wo + x0] + lx * pp[y1 * Wo + x1]);
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_image_pad(const void* img, float* pooled, float* out, int B, int C, int H, int W, int factor, int img_dtype,
+                              void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(img && pooled && out && B > 0 && C > 0 && factor > 0 && H >= factor && W >= factor, "image_pad: bad arguments");
+    const int Hn = (H + factor - 1) / factor * factor, Wn = (W + factor - 1) / factor * factor;
+    const int Ho = H / factor, Wo = W / factor;
+    const int hs = (Hn - H) / 2, ws = (Wn - W) / 2;
+    const int BC = B * C;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long bins = (long long)BC * Ho * Wo, pix = (long long)BC * Hn * Wn;
+    #define S2M2_PAD(TI) do { \
+        hipLaunchKernelGGL((pad_pool_kernel<TI>), grid1(bins * 64), dim3(256), 0, st, (const TI*)img, pooled, BC, H, W, Hn, Wn, Ho, Wo, hs, ws); \
+        hipLaunchKernelGGL((pad_fill_kernel<TI>), grid1(pix), dim3(256), 0, st, (const TI*)img, pooled, out, BC, H, W, Hn, Wn, Ho, Wo, hs, ws); } while (0)
+    if (img_dtype == S2M2_F32) S2M2_PAD(float);
+    else if (img_dtype == S2M2_F16) S2M2_PAD(half_t);
+    else if (img_dtype == 2) S2M2_PAD(unsigned char);
+    else return set_error("image_pad: unsupported image dtype %d", img_dtype);
+    #undef S2M2_PAD
+    return check_launch("image_pad");
+}

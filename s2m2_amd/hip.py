@@ -53,6 +53,7 @@ SIGNATURES = {
     "s2m2_global_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_refine_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "s2m2_tanh": (_i, [_vp, _vp, _ll, _i, _vp]),
+    "s2m2_image_pad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "s2m2_layernorm": (_i, [_vp, _vp, _ll, _i, _ll, _ll, _i, _vp]),
     "s2m2_groupnorm_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
     "s2m2_groupnorm_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, ctypes.c_float, _i, _vp]),
@@ -350,3 +351,18 @@ def tanh(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(x)
     _check(load().s2m2_tanh(x.data_ptr(), y.data_ptr(), x.numel(), _DT[x.dtype], _stream()), "s2m2_tanh")
     return y
+
+
+def image_pad(img: torch.Tensor, factor: int = 32) -> torch.Tensor:
+    """Reference image_pad (image_utils.py:27-71) on the device: (B,C,H,W) fp32/fp16/uint8 -> (B,C,Hn,Wn) fp32."""
+    if img.dtype not in _IMG_DT:
+        img = img.float()
+    img = img.contiguous()
+    _dev(img)
+    B, C, H, W = img.shape
+    Hn, Wn = -(-H // factor) * factor, -(-W // factor) * factor
+    pooled = torch.empty((B, C, H // factor, W // factor), device=img.device, dtype=torch.float32)
+    out = torch.empty((B, C, Hn, Wn), device=img.device, dtype=torch.float32)
+    _check(load().s2m2_image_pad(img.data_ptr(), pooled.data_ptr(), out.data_ptr(), B, C, H, W, factor, _IMG_DT[img.dtype], _stream()),
+           "s2m2_image_pad")
+    return out

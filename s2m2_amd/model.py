@@ -94,7 +94,7 @@ class S2M2(nn.Module):
         p0 = next(self.parameters())
         if p0.device != img0.device:
             raise RuntimeError(f"model parameters on {p0.device}, images on {img0.device}")
-        if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16:
+        if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16:
             dtype = torch.float16
         else:
             dtype = torch.float16 if p0.dtype == torch.float16 else torch.float32
