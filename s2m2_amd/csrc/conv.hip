@@ -17,6 +17,7 @@
 //            pieces of whole pixel rows (NHWC: channels contiguous) for the aux epilogue and fully coalesced stores.
 // fp16: v_mfma_f32_32x32x16_f16, fp32 accumulate.  fp32 (parity mode): exact v_mfma_f32_32x32x2_f32.
 #include "common.h"
+#include <stdlib.h>
 
 // compile-time ablation switches (tools/conv_ablate.py; never set in the shipped library):
 // 1 no global loads inside the K loop, 2 no MFMA, 4 no LDS stash inside the loop, 8 no fragment reads,
@@ -628,17 +629,19 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
 // Input traffic through the memory pipe drops from KH*KW x 16 KB to 26-30 KB per chunk; the weight tile (BN x 128 bytes per tap)
 // is double buffered exactly as in v1.  K order of the loop: (chunk, ky, kx) -- the packed weight stays (Cout, KH, KW, Cin).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BN_>
+template <typename T, int BN_, int NWAVES_ = 4>
 struct ConvCfgH {
-    static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = 2, WGN = 2;
+    static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = 2, WGN = NWAVES_ / 2;
+    static constexpr int NT = 64 * NWAVES_;              // threads per block (4 or 8 waves)
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int BK = 8 * VEC;                   // channels per chunk (128 bytes)
     static constexpr int RS = BK + VEC;                  // LDS row stride (elements): 144 bytes
     static constexpr int KSTEPS = BK / 16;
-    static constexpr int WM = 64, WN = BN / 2, MT = 2, NTL = WN / 32;
+    static constexpr int WM = 64, WN = BN / WGN, MT = 2, NTL = WN / 32;
     static constexpr int MAXHALO = (PH + 2) * (PW + 2);  // 204 halo pixels for 3x3
-    static constexpr int A_IT = (MAXHALO * 8 + 255) / 256;       // 16-byte pieces per thread and chunk (7)
-    static constexpr int B_IT = BN / 32;
+    static constexpr int RPI = NT / 8;                   // tile rows covered by one pass of the loader threads
+    static constexpr int A_IT = (MAXHALO + RPI - 1) / RPI;        // 16-byte pieces per thread and chunk
+    static constexpr int B_IT = (BN + RPI - 1) / RPI;
     static constexpr int CRS = BN + VEC;
     static constexpr size_t A_BYTES = (size_t)MAXHALO * RS * sizeof(T);
     static constexpr size_t B_BYTES = (size_t)2 * BN * RS * sizeof(T);
@@ -648,7 +651,7 @@ struct ConvCfgH {
 };
 
 template <typename CFG, typename T>
-__global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tiles_x, int tiles_y) {
     constexpr int BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, BK = CFG::BK, PH = CFG::PH, PW = CFG::PW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ah = reinterpret_cast<T*>(smem);                          // [halo pixels][RS]
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x,
     int apix[CFG::A_IT];                                          // input pixel index of this thread's halo pixels, -1: outside / unused
 #pragma unroll
     for (int it = 0; it < CFG::A_IT; ++it) {
-        const int hp = (tid >> 3) + 32 * it;
+        const int hp = (tid >> 3) + CFG::RPI * it;
         apix[it] = -1;
         if (hp < nhalo) {
             const int hy = hp / HW_, hx = hp - hy * HW_;
@@ -692,8 +695,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x,
         const T* wp = static_cast<const T*>(p.weight);
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
-            const int co = n0 + (tid >> 3) + 32 * it;
-            wrow[it] = co < p.Cout ? wp + (size_t)co * Ktot + pc * VEC : nullptr;
+            const int br = (tid >> 3) + CFG::RPI * it;
+            const int co = n0 + br;
+            wrow[it] = (br < BN && co < p.Cout) ? wp + (size_t)co * Ktot + pc * VEC : nullptr;
         }
     }
     const T* zp = static_cast<const T*>(p.zero);
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x,
     auto stash_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < CFG::A_IT; ++it) {
-            const int hp = (tid >> 3) + 32 * it;
+            const int hp = (tid >> 3) + CFG::RPI * it;
             if (hp < CFG::MAXHALO) *reinterpret_cast<raw16_t*>(Ah + (size_t)hp * RS + pc * VEC) = ra[it];
         }
     };
@@ -744,7 +748,10 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x,
     auto stash_b = [&](int buf) __attribute__((always_inline)) {
         T* b = Bs + (size_t)buf * BN * RS;
 #pragma unroll
-        for (int it = 0; it < CFG::B_IT; ++it) *reinterpret_cast<raw16_t*>(b + (size_t)((tid >> 3) + 32 * it) * RS + pc * VEC) = rb[it];
+        for (int it = 0; it < CFG::B_IT; ++it) {
+            const int br = (tid >> 3) + CFG::RPI * it;
+            if (br < BN) *reinterpret_cast<raw16_t*>(b + (size_t)br * RS + pc * VEC) = rb[it];
+        }
     };
 
     float16_t acc[CFG::MT][CFG::NTL];
@@ -799,7 +806,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(ConvArgs p, int tiles_x,
     constexpr int PCR = BN / VEC;
     T* outp = static_cast<T*>(p.out);
 #pragma unroll 2
-    for (int q = tid; q < 128 * PCR; q += 256) {
+    for (int q = tid; q < 128 * PCR; q += CFG::NT) {
         const int r = q / PCR, pcc = q - r * PCR;
         const int yy = y0 + (r >> 5), xx = x0 + (r & 31);
         const int co = n0 + pcc * VEC;
@@ -1011,9 +1018,9 @@ static int launch_conv2(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
-template <typename T, int BN>
+template <typename T, int BN, int NWAVES = 4>
 static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
-    using CFG = ConvCfgH<T, BN>;
+    using CFG = ConvCfgH<T, BN, NWAVES>;
     auto kern = conv_halo_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1025,7 +1032,7 @@ static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     if (a.stride != 1 || a.shuffle2 || a.korder || a.KH > 3 || a.KW > 3) return set_error("conv2d: the halo tile needs a stride-1 kernel of at most 3x3 taps in K order 0");
     const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
     dim3 grid((unsigned)(a.N * tx * ty), (unsigned)((a.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256), CFG::LDS_BYTES, st, a, tx, ty);
+    hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty);
     return check_launch("conv2d");
 }
 
@@ -1058,8 +1065,10 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     const long long M = (long long)a.N * a.Ho * a.Wo;
     if (tile == 0) {                                              // measured on MI355X (tools/convbench.py, profiles/r01)
         const int Ktot = a.KH * a.KW * a.Cin;
-        if (a.KH * a.KW > 1 && a.KH <= 3 && a.KW <= 3 && a.stride == 1 && !a.shuffle2 && !a.korder)
-            tile = (a.Cout >= 128 && M >= 150000) ? 12 : 13;     // spatial kernels: halo tile (input gathered once per channel chunk)
+        if (a.KH * a.KW > 1 && a.KH <= 3 && a.KW <= 3 && a.stride == 1 && !a.shuffle2 && !a.korder) {
+            static const bool no8 = getenv("S2M2_CONV_NO_HALO8") != nullptr;    // A/B switch
+            tile = (a.Cout >= 128 && M >= 30000 && !no8) ? 19 : 13;
+        }      // spatial kernels: halo tile; 8 waves x 128 couts when there is enough work
         else if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
         else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 5;   // 128x128, 64-byte K rows, 3 blocks/CU
         else tile = Ktot <= 512 ? 6 : 2;                          // 64x64 with 64- / 128-byte K rows
@@ -1083,6 +1092,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         case 16: return launch_conv<T, 64, 64, 2, 4, 4>(a, st);    // 64x64, 64-byte K rows, 4 K tiles in flight
         case 17: return launch_conv<T, 64, 64, 2, 8, 4>(a, st);    // 64x64, 128-byte K rows, 4 K tiles in flight
         case 18: return launch_conv<T, 128, 128, 2, 4, 4>(a, st);  // 128x128, 64-byte K rows, 4 K tiles in flight
+        case 19: return launch_conv_halo<T, 128, 8>(a, st);        // v3 halo tile, 128 couts, 8 waves (32 couts per wave)
         default: return set_error("conv2d: unknown tile id %d", tile);
     }
 }
