@@ -49,13 +49,14 @@ struct ConvArgs {
     const void* zero;           // 256 zero bytes in global memory (what out-of-range pieces read)
 };
 
-template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8, int NPF_ = 1>
+template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8, int NPF_ = 1, int NWAVES_ = 4>
 struct ConvCfg {
+    static constexpr int NT = 64 * NWAVES_;              // threads per block
     static constexpr int NPF = NPF_;                     // K tiles requested ahead, in registers (short-K layers: the whole K at once)
-    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_;
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = NWAVES_ / WGM_;
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int PPR = PPR_;                     // 16-byte pieces per K-tile row (8: 128-byte rows, 4: 64-byte rows)
-    static constexpr int RPI = 256 / PPR;                // tile rows covered by one pass of the 256 loader threads
+    static constexpr int RPI = NT / PPR;                 // tile rows covered by one pass of the loader threads
     static constexpr int BK = PPR * VEC;                 // 64 fp16 / 32 fp32
     static constexpr int RS = BK + VEC;                  // LDS row stride (elements)
     static constexpr int KSTEPS = BK / 16;               // k16 fragments per tile
@@ -141,7 +142,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int t
     constexpr int TOTAL = BM * PCR;
     T* outp = static_cast<T*>(p.out);
 #pragma unroll 2
-    for (int q = tid; q < TOTAL; q += 256) {
+    for (int q = tid; q < TOTAL; q += CFG::NT) {
         const int r = q / PCR, pcc = q - r * PCR;
         const long long m = m0 + r;
         const int co = n0 + pcc * VEC;
@@ -317,7 +318,7 @@ struct ConvLoader {
 };
 
 template <typename CFG, typename T>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+__global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = CFG::BM, BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, BK = CFG::BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* As = reinterpret_cast<T*>(smem);                          // [2][BM][RS]
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int BM_, int BN_, int KP_, int NS_>
 struct ConvCfg2 {
-    static constexpr int BM = BM_, BN = BN_, KP = KP_, NS = NS_, WGM = 2, WGN = 2;
+    static constexpr int BM = BM_, BN = BN_, KP = KP_, NS = NS_, WGM = 2, WGN = 2, NT = 256;
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int PBK = 4 * VEC;                  // K elements per plane (64 bytes)
     static constexpr int BK = KP * PBK;
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int BN_>
 struct ConvCfgP {
-    static constexpr int BM = 64, BN = BN_, WGM = 2, WGN = 2;
+    static constexpr int BM = 64, BN = BN_, WGM = 2, WGN = 2, NT = 256;
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int BK = 8 * VEC;                   // K elements per step (128 bytes)
     static constexpr int RS = BK + VEC;                  // activation row stride in LDS (elements)
@@ -984,9 +985,9 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1>
+template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1, int NWAVES = 4>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
-    using CFG = ConvCfg<T, BM, BN, WGM, PPR, NPF>;
+    using CFG = ConvCfg<T, BM, BN, WGM, PPR, NPF, NWAVES>;
     auto kern = conv_igemm_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -997,7 +998,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
     }
     const long long M = (long long)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
-    hipLaunchKernelGGL(kern, grid, dim3(256), CFG::LDS_BYTES, st, a);
+    hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a);
     return check_launch("conv2d");
 }
 
@@ -1070,7 +1071,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
             tile = (a.Cout >= 128 && M >= 30000 && !no8) ? 19 : 13;
         }      // spatial kernels: halo tile; 8 waves x 128 couts when there is enough work
         else if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
-        else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 5;   // 128x128, 64-byte K rows, 3 blocks/CU
+        else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 20;  // 128x128, 64-byte K rows, 8 waves
         else tile = Ktot <= 512 ? 6 : 2;                          // 64x64 with 64- / 128-byte K rows
     }
     switch (tile) {
@@ -1093,6 +1094,9 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         case 17: return launch_conv<T, 64, 64, 2, 8, 4>(a, st);    // 64x64, 128-byte K rows, 4 K tiles in flight
         case 18: return launch_conv<T, 128, 128, 2, 4, 4>(a, st);  // 128x128, 64-byte K rows, 4 K tiles in flight
         case 19: return launch_conv_halo<T, 128, 8>(a, st);        // v3 halo tile, 128 couts, 8 waves (32 couts per wave)
+        case 20: return launch_conv<T, 128, 128, 2, 4, 1, 8>(a, st);   // 128x128, 64-byte K rows, 8 waves (64 px x 32 couts each)
+        case 21: return launch_conv<T, 128, 128, 2, 8, 1, 8>(a, st);   // 128x128, 128-byte K rows, 8 waves
+        case 22: return launch_conv<T, 64, 128, 2, 4, 1, 8>(a, st);    // 64x128, 64-byte K rows, 8 waves (32 px x 32 couts each)
         default: return set_error("conv2d: unknown tile id %d", tile);
     }
 }
