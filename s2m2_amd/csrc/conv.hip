@@ -630,15 +630,15 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
 // Input traffic through the memory pipe drops from KH*KW x 16 KB to 26-30 KB per chunk; the weight tile (BN x 128 bytes per tap)
 // is double buffered exactly as in v1.  K order of the loop: (chunk, ky, kx) -- the packed weight stays (Cout, KH, KW, Cin).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BN_, int NWAVES_ = 4>
+template <typename T, int BN_, int NWAVES_ = 4, int WGM_ = 2>
 struct ConvCfgH {
-    static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = 2, WGN = NWAVES_ / 2;
+    static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = WGM_, WGN = NWAVES_ / WGM_;
     static constexpr int NT = 64 * NWAVES_;              // threads per block (4 or 8 waves)
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int BK = 8 * VEC;                   // channels per chunk (128 bytes)
     static constexpr int RS = BK + VEC;                  // LDS row stride (elements): 144 bytes
     static constexpr int KSTEPS = BK / 16;
-    static constexpr int WM = 64, WN = BN / WGN, MT = 2, NTL = WN / 32;
+    static constexpr int WM = BM / WGM, WN = BN / WGN, MT = WM / 32, NTL = WN / 32;
     static constexpr int MAXHALO = (PH + 2) * (PW + 2);  // 204 halo pixels for 3x3
     static constexpr int RPI = NT / 8;                   // tile rows covered by one pass of the loader threads
     static constexpr int A_IT = (MAXHALO + RPI - 1) / RPI;        // 16-byte pieces per thread and chunk
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv & 1, wn = wv >> 1;
+    const int wm = wv % CFG::WGM, wn = wv / CFG::WGM;
     const int hi = lane >> 5, l31 = lane & 31;
     // patch of this block
     int bx = blockIdx.x;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
         if (more) fetch_b(kt + 1);                                // in flight under the MFMAs
         if (tap == 0 && chunk + 1 < nchunk) fetch_a(chunk + 1);   // next halo tile: requested now, parked in registers until the last tap
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const T* a = Ah + (size_t)((wm * 2 + ky) * HW_ + l31 + kx) * RS + hi * 8;
+        const T* a = Ah + (size_t)((wm * CFG::MT + ky) * HW_ + l31 + kx) * RS + hi * 8;
         const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + l31) * RS + hi * 8;
 #pragma unroll
         for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
@@ -1019,9 +1019,9 @@ static int launch_conv2(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
-template <typename T, int BN, int NWAVES = 4>
+template <typename T, int BN, int NWAVES = 4, int WGM = 2>
 static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
-    using CFG = ConvCfgH<T, BN, NWAVES>;
+    using CFG = ConvCfgH<T, BN, NWAVES, WGM>;
     auto kern = conv_halo_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1068,7 +1068,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         const int Ktot = a.KH * a.KW * a.Cin;
         if (a.KH * a.KW > 1 && a.KH <= 3 && a.KW <= 3 && a.stride == 1 && !a.shuffle2 && !a.korder) {
             static const bool no8 = getenv("S2M2_CONV_NO_HALO8") != nullptr;    // A/B switch
-            tile = (a.Cout >= 128 && M >= 30000 && !no8) ? 19 : 13;
+            tile = (a.Cout >= 128 && !no8) ? (M >= 30000 ? 19 : 23) : 13;
         }      // spatial kernels: halo tile; 8 waves x 128 couts when there is enough work
         else if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
         else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 20;  // 128x128, 64-byte K rows, 8 waves
@@ -1097,6 +1097,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         case 20: return launch_conv<T, 128, 128, 2, 4, 1, 8>(a, st);   // 128x128, 64-byte K rows, 8 waves (64 px x 32 couts each)
         case 21: return launch_conv<T, 128, 128, 2, 8, 1, 8>(a, st);   // 128x128, 128-byte K rows, 8 waves
         case 22: return launch_conv<T, 64, 128, 2, 4, 1, 8>(a, st);    // 64x128, 64-byte K rows, 8 waves (32 px x 32 couts each)
+        case 23: return launch_conv_halo<T, 64, 8, 4>(a, st);      // v3 halo tile, 64 couts, 8 waves (one patch row x 32 couts each)
         default: return set_error("conv2d: unknown tile id %d", tile);
     }
 }
