@@ -116,6 +116,12 @@ typedef struct s2m2_conv_desc {
     int korder;             /* K order of the packed weight: 0 = (Cout, KH, KW, Cin); 1 = (Cout, KH, Cin/CH, KW, CH) with CH = 64 bytes of
                                channels (32 fp16 / 16 fp32; Cin % CH == 0): horizontal taps become consecutive K tiles -> L1 reuse */
     int stride;             /* 1 or 2: out[y,x] is centred on in[y*stride, x*stride]; output (N, ceil(H/stride), ceil(W/stride), Cout) */
+    const float* ln_wsum;   /* non-NULL: the layer is LayerNorm(Cin, elementwise_affine=False, eps=ln_eps) followed by this 1x1 layer
+                               (the pre-norm of attentions.py:117,148,182,213,243 feeding its Linear): `in` holds the RAW rows, the kernel
+                               computes W.((x-mean)*rstd)+b as rstd*(W.x - mean*ln_wsum)+b with the row statistics taken inside the GEMM;
+                               ln_wsum[co] = sum_k weight[co,k] (fp32, Cout entries, summed from the packed weight).
+                               Needs KH = KW = 1, stride 1, no shuffle2, Cin with no padding channels, act NONE or GELU. */
+    float ln_eps;
 } s2m2_conv_desc;
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
 

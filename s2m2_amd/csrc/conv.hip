@@ -47,6 +47,8 @@ struct ConvArgs {
     int shuffle2;
     int korder;                 // 0: K = (ky, kx, c);  1: K = (ky, c / CH, kx, c % CH), CH = 64 bytes of channels (L1 reuse along kx)
     const void* zero;           // 256 zero bytes in global memory (what out-of-range pieces read)
+    const float* ln_wsum;       // non-null: pre-LayerNorm (no affine) of the input rows folded into the GEMM, see LnStats
+    float ln_eps;
 };
 
 template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8, int NPF_ = 1, int NWAVES_ = 4>
@@ -96,9 +98,34 @@ template <int ACT> __device__ __forceinline__ float activate(float x) {
 
 // epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]; ACT is a compile-time constant here (a
 // runtime switch per element made the compiler evaluate every activation and select)
-template <typename CFG, typename T, int ACT>
+// Pre-LayerNorm folded into a 1x1 layer (reference attentions.py:117,148,182,213,243: LayerNorm without affine feeding a Linear):
+//   W . ((x - mean) * rstd) + b  =  rstd * (W . x  -  mean * rowsum(W)) + b
+// The GEMM runs on the raw rows; mean / rstd of a row come from the A fragments the wave reads anyway (a lane owns one pixel
+// and half of every k16 step: sum and sum of squares in fp32, one cross-half exchange at the end); rowsum(W) is packed once.
+struct LnRow { float mean, rstd; };
+
+// fp16 rows: products and sums are exact-ish in fp32 (error ~1e-7 * (mean/std)^2 relative to the variance, far below the fp16
+// rounding of the operands).  fp32 rows: sums are taken about the row's first element, so a mean much larger than the spread
+// does not cancel in q/C - mean^2.
+__device__ __forceinline__ void ln_accumulate(const Frag<half_t>& f, float& s, float& q, float) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const h2 v = {f.v[2 * e], f.v[2 * e + 1]};
+        s = __builtin_amdgcn_fdot2(v, one, s, false);
+        q = __builtin_amdgcn_fdot2(v, v, q, false);
+    }
+}
+__device__ __forceinline__ void ln_accumulate(const Frag<float>& f, float& s, float& q, float shift) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = f.v[e] - shift; s += d; q = __builtin_fmaf(d, d, q); }
+}
+
+template <typename CFG, typename T, int ACT, bool LN = false>
 __device__ __forceinline__ void stage_tile(const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, const float* __restrict__ bias, int Cout,
-                                           float out_scale, int n0, int wm, int wn, int lane) {
+                                           float out_scale, int n0, int wm, int wn, int lane, const LnRow* ln = nullptr,
+                                           const float* __restrict__ wsum = nullptr) {
     const int hi = lane >> 5;
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i) {
@@ -112,9 +139,17 @@ __device__ __forceinline__ void stage_tile(const float16_t (&acc)[CFG::MT][CFG::
                 float4_t bv = {0.f, 0.f, 0.f, 0.f};
                 if (bias && co < Cout) bv = *reinterpret_cast<const float4_t*>(bias + co);
                 float v[4];
+                if constexpr (LN) {
+                    float4_t ws = {0.f, 0.f, 0.f, 0.f};
+                    if (co < Cout) ws = *reinterpret_cast<const float4_t*>(wsum + co);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = (S2M2_CONV_DBG & 16) ? acc[i][j][4 * g + e] : activate<ACT>(acc[i][j][4 * g + e] + bv[e]) * out_scale;
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = activate<ACT>(ln[i].rstd * __builtin_fmaf(-ln[i].mean, ws[e], acc[i][j][4 * g + e]) + bv[e]) * out_scale;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (S2M2_CONV_DBG & 16) ? acc[i][j][4 * g + e] : activate<ACT>(acc[i][j][4 * g + e] + bv[e]) * out_scale;
+                }
                 if constexpr (sizeof(T) == 2) {
                     half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                     *reinterpret_cast<half4_t*>(crow + cl) = h;
@@ -177,6 +212,14 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int t
         }
         if (!(S2M2_CONV_DBG & 32)) *reinterpret_cast<Vec16<T>*>(outp + opix * p.out_stride + oc) = v;
     }
+}
+
+// the pre-LN layers of the model are the QKV projections (no activation) and the first FFN layer (GELU)
+template <typename CFG, typename T>
+__device__ __forceinline__ void stage_tile_ln(const ConvArgs& p, const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, int n0, int wm, int wn, int lane,
+                                              const LnRow* ln) {
+    if (p.act == S2M2_ACT_GELU) stage_tile<CFG, T, S2M2_ACT_GELU, true>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane, ln, p.ln_wsum);
+    else stage_tile<CFG, T, S2M2_ACT_NONE, true>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane, ln, p.ln_wsum);
 }
 
 template <typename CFG, typename T, int UNUSED = 0>
@@ -317,7 +360,7 @@ struct ConvLoader {
     }
 };
 
-template <typename CFG, typename T>
+template <typename CFG, typename T, bool LN = false>
 __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     constexpr int BM = CFG::BM, BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, BK = CFG::BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -344,6 +387,9 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
         for (int j = 0; j < CFG::NTL; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float ln_s[CFG::MT], ln_q[CFG::MT], ln_shift[CFG::MT];
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i) ln_s[i] = ln_q[i] = ln_shift[i] = 0.f;
 
     // K tiles are requested NPF ahead into a ring of register slots (slot = tile % NPF, static after unrolling): for the short-K
     // layers (1x1, K <= NPF tiles) the whole K of the block is in flight at once -- one memory latency per block instead of one per tile
@@ -353,6 +399,10 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
         if (f < nkt) ld.fetch(p, f, f);
     ld.stash(As, Bs, 0);
     __syncthreads();
+    if constexpr (LN && sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i) ln_shift[i] = to_f32(As[(size_t)(wm * CFG::WM + i * 32 + (lane & 31)) * RS]);
+    }
     const int nkt_run = (S2M2_CONV_DBG & 64) ? 0 : nkt;
     for (int kt0 = 0; kt0 < nkt_run; kt0 += NPF) {
 #pragma unroll
@@ -370,6 +420,10 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
                 for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], (S2M2_CONV_DBG & 8) ? a : a + (size_t)i * 32 * RS + kk * 16);
 #pragma unroll
                 for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], (S2M2_CONV_DBG & 8) ? b : b + (size_t)j * 32 * RS + kk * 16);
+                if constexpr (LN) {
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
+                }
                 if (!(S2M2_CONV_DBG & 2)) {
 #pragma unroll
                     for (int i = 0; i < CFG::MT; ++i)
@@ -389,7 +443,20 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     }
 
     // ---- epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]
-    stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+    if constexpr (LN) {
+        LnRow ln[CFG::MT];
+        const float inv = 1.0f / (float)Ktot;
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i) {
+            const float s = ln_s[i] + __shfl_xor(ln_s[i], 32), q = ln_q[i] + __shfl_xor(ln_q[i], 32);
+            const float mean = s * inv;                            // relative to ln_shift (0 for fp16 rows)
+            ln[i].mean = mean + ln_shift[i];
+            ln[i].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
+        }
+        stage_tile_ln<CFG, T>(p, acc, Cs, n0, wm, wn, lane, ln);
+    } else {
+        stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+    }
     __syncthreads();
 
     store_tile<CFG, T>(p, Cs, tid, m0, n0, M);
@@ -985,10 +1052,10 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1, int NWAVES = 4>
+template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1, int NWAVES = 4, bool LN = false>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfg<T, BM, BN, WGM, PPR, NPF, NWAVES>;
-    auto kern = conv_igemm_kernel<CFG, T>;
+    auto kern = conv_igemm_kernel<CFG, T, LN>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1074,6 +1141,15 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 20;  // 128x128, 64-byte K rows, 8 waves
         else tile = Ktot <= 512 ? 6 : 2;                          // 64x64 with 64- / 128-byte K rows
     }
+    if (a.ln_wsum) {                                              // pre-LN folded in: the v1 tiles the heuristic picks for 1x1 layers
+        switch (tile) {
+            case 2: return launch_conv<T, 64, 64, 2, 8, 1, 4, true>(a, st);
+            case 3: return launch_conv<T, 128, 32, 4, 8, 1, 4, true>(a, st);
+            case 6: return launch_conv<T, 64, 64, 2, 4, 1, 4, true>(a, st);
+            case 20: return launch_conv<T, 128, 128, 2, 4, 1, 8, true>(a, st);
+            default: return set_error("conv2d: tile %d has no pre-LayerNorm variant (2, 3, 6, 20 do)", tile);
+        }
+    }
     switch (tile) {
         case 1: return launch_conv<T, 128, 128, 2>(a, st);
         case 2: return launch_conv<T, 64, 64, 2>(a, st);
@@ -1146,6 +1222,11 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2; a.korder = d->korder;
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "conv2d: cannot allocate the zero page");
+    a.ln_wsum = d->ln_wsum; a.ln_eps = d->ln_eps;
+    if (d->ln_wsum)
+        S2M2_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && !d->shuffle2 && !d->korder && d->ln_eps > 0.f &&
+                     (d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_GELU),
+                     "conv2d: pre-LayerNorm needs a 1x1 stride-1 layer with act NONE or GELU and ln_eps > 0");
     a.stride = d->stride; a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
     S2M2_REQUIRE(d->korder == 0 || d->korder == 1, "conv2d: korder=%d (0 or 1)", d->korder);
     S2M2_REQUIRE(!d->korder || a.Cin % (d->dtype == S2M2_F16 ? 32 : 16) == 0, "conv2d: korder 1 needs Cin=%d to be a multiple of 64 bytes of channels", a.Cin);

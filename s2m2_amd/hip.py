@@ -31,7 +31,8 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("src", _vp * 4), ("src_c", _i * 4), ("src_stride", _i * 4), ("nsrc", _i), ("weight", _vp), ("bias", _vp),
                 ("out", _vp), ("out_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Cout", _i),
                 ("act", _i), ("epi", _i), ("aux0", _vp), ("aux1", _vp), ("aux0_stride", _i), ("aux1_stride", _i),
-                ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("korder", _i), ("stride", _i)]
+                ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("korder", _i), ("stride", _i),
+                ("ln_wsum", _vp), ("ln_eps", ctypes.c_float)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -152,10 +153,11 @@ def _nhwc(t: torch.Tensor):
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, act: int = ACT_NONE,
            epi: int = EPI_NONE, aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0,
-           stride: int = 1, korder: int = 0) -> torch.Tensor:
+           stride: int = 1, korder: int = 0, ln_wsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
     """Implicit-GEMM convolution / linear layer (s2m2_conv2d).  srcs: list of (N,H,W,Cs) tensors, concatenated along C;
     weight: packed (Cout, KH*KW*sum(Cs)) (see s2m2_amd.pack); bias fp32 (Cout) or None.  Returns (N,H,W,Cout), or
-    (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM."""
+    (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM.  ln_wsum (fp32 (Cout) row sums of the packed weight): the 1x1 layer
+    is preceded by LayerNorm(Cin, no affine, eps=ln_eps) of the raw input rows, folded into the kernel."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     d = ConvDesc()
@@ -198,6 +200,11 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
     d.tile = tile
     d.stride = stride
     d.korder = korder
+    if ln_wsum is not None:
+        if ln_wsum.dtype != torch.float32 or ln_wsum.numel() != Cout or not ln_wsum.is_contiguous():
+            raise ValueError("conv2d: ln_wsum must be fp32 (Cout)")
+        d.ln_wsum = ln_wsum.data_ptr()
+        d.ln_eps = ln_eps
     d.dtype = _DT[dt]
     _check(load().s2m2_conv2d(ctypes.byref(d), _stream()), "s2m2_conv2d")
     return out

@@ -29,11 +29,14 @@ def make():
         buf[..., off2:off2 + T] = c2.permute(0, 2, 3, 1).to(buf.dtype)
 
     def conv2d(srcs, weight, bias, KH, KW, Cout, act=0, epi=0, aux0=None, aux1=None, out=None, out_scale=1.0, shuffle2=0, tile=0,
-               stride=1):
+               stride=1, ln_wsum=None, ln_eps=1e-5):
         if isinstance(srcs, torch.Tensor):
             srcs = [srcs]
         x = torch.cat([s.float() for s in srcs], -1)
         n, h, w, cin = x.shape
+        if ln_wsum is not None:
+            assert KH == 1 and KW == 1 and torch.allclose(ln_wsum, weight.float().sum(1), atol=1e-4)
+            x = F.layer_norm(x, (cin,), eps=ln_eps)
         assert tuple(weight.shape) == (Cout, KH * KW * cin) and Cout % 8 == 0 and cin % 8 == 0
         wt = weight.float().reshape(Cout, KH, KW, cin).permute(0, 3, 1, 2)
         y = F.conv2d(x.permute(0, 3, 1, 2), wt, bias, stride=stride, padding=(KH // 2, KW // 2))

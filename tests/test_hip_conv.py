@@ -172,3 +172,34 @@ def test_linear_tokens_big(hip):
     out = hip.conv2d([x], pack.pack_conv(w, torch.float16), pack.pack_bias(b, 3 * C), 1, 1, 3 * C)
     ref = F.linear(x.float(), w.float(), b)
     assert float((out.float() - ref).abs().max()) < 2.5e-3 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("tile", [0, 2, 3, 6, 20])
+@pytest.mark.parametrize("shape", [(2, 32, 38, 256, 768, 0), (1, 64, 76, 128, 128, 1), (2, 9, 13, 384, 384, 1), (1, 50, 61, 128, 384, 0)])
+def test_pre_layernorm_folded_into_1x1(hip, dtype, tile, shape):
+    """LayerNorm (no affine) + Linear as one launch (attentions.py:117 pre-norm) == F.layer_norm -> F.linear -> act in fp32, on rows
+    with a mean several times their standard deviation (the subtraction rstd*(W.x - mean*rowsum(W)) must survive it)."""
+    n, h, w, cin, cout, act = shape
+    if tile == 3 and cout > 128:
+        pytest.skip("narrow-head tile")
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + tile)
+    x = (torch.randn(n, h, w, cin, device="cuda", generator=g) * (0.5 + torch.rand(n, h, w, 1, device="cuda", generator=g) * 3)
+         + torch.randn(n, h, w, 1, device="cuda", generator=g) * 4).to(dtype)
+    wt = (torch.randn(cout, cin, 1, 1, device="cuda", generator=g) / math.sqrt(cin)).to(dtype)
+    b = torch.randn(cout, device="cuda", generator=g)
+    wp, bp = pack.pack_conv(wt, dtype), pack.pack_bias(b, cout)
+    y = hip.conv2d([x], wp, bp, 1, 1, cout, act=act, tile=tile, ln_wsum=wp.float().sum(1).contiguous())
+    ref = _act(F.linear(F.layer_norm(x.float(), (cin,)), wt.float().reshape(cout, cin), b), act)
+    # reference path of the engine before the fusion: separate K6 LayerNorm (output rounded to the I/O dtype) + plain K5
+    y2 = hip.conv2d([hip.layernorm(x)], wp, bp, 1, 1, cout, act=act, tile=tile)
+    tol = 2e-4 if dtype == torch.float32 else 6e-3
+    assert float((y.float() - ref).abs().max()) < tol
+    assert float((y.float() - ref).abs().max()) <= max(2 * float((y2.float() - ref).abs().max()), tol / 4)
+
+
+def test_pre_layernorm_rejects_spatial_kernels(hip):
+    x = torch.randn(1, 8, 8, 128, device="cuda").half()
+    wp = torch.randn(128, 9 * 128, device="cuda").half()
+    with pytest.raises(RuntimeError, match="pre-LayerNorm"):
+        hip.conv2d([x], wp, None, 3, 3, 128, ln_wsum=torch.zeros(128, device="cuda"))
