@@ -126,6 +126,38 @@ typedef struct s2m2_conv_desc {
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
 
 /*
+ * K9 -- a chain of up to three 1x1 layers (nn.Linear / 1x1 nn.Conv2d, all C -> C) on token rows in ONE launch; the row tile
+ *   stays in LDS between the layers.  Replaces, per transformer block, the attention output projection + residual and the FFN
+ *   (reference attentions.py:311-321 GlobalAttnBlock.forward, :347-355 BasicAttnBlock.forward:  z = z + proj(o);
+ *   z = z + ffn(norm(z)) with ffn = Linear-GELU-Linear, attentions.py:239-241), and the 1x1 branch of ConvBlock2D
+ *   (attentions.py:269-275: Conv1x1-ReLU-Conv1x1).
+ *
+ *   t_0 = x rows;   y_s = act_s( W_s . (ln_wsum[s] ? LayerNorm(t_s) : t_s) + b_s );   if (s == res_stage) y_s += res rows;
+ *   if (carry && s == 2) y_2 += y_0;   t_{s+1} = y_s;   out = y_{nstage-1}
+ *   weight[s] packed (C, C) like s2m2_conv2d's 1x1 weight, bias fp32 (C) or NULL, ln_wsum[s] fp32 (C) row sums of weight[s]
+ *   (non-NULL: LayerNorm without affine, eps ln_eps, folded in as in s2m2_conv2d); act NONE / GELU / RELU.
+ *   Every y_s is rounded to the I/O dtype before it is used again, exactly as separate launches would store it.
+ *   C: 128 / 256 / 384 / 512 (fp16), 128 / 256 (fp32): ask s2m2_mlp_chain_supported; row strides in elements, multiples of 8.
+ */
+typedef struct s2m2_chain_desc {
+    const void* x;
+    const void* res;
+    void* out;
+    long long x_stride, res_stride, out_stride, rows;
+    int C, nstage;
+    const void* weight[3];
+    const float* bias[3];
+    const float* ln_wsum[3];
+    int act[3];
+    int res_stage;          /* -1: no residual rows */
+    int carry;
+    float ln_eps;
+    int dtype;
+} s2m2_chain_desc;
+int s2m2_mlp_chain_supported(int C, int dtype);
+int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
+
+/*
  * [A2,A3] pre-norm LayerNorm without affine over the channel axis (attentions.py:117,148,182,213,243; eps 1e-5, biased var).
  *   x, y: `rows` token rows of C channels, row strides x_stride / y_stride elements (multiples of 8); fp32 arithmetic.
  */

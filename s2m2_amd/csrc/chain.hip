@@ -1,0 +1,347 @@
+// K9 -- chains of 1x1 layers on token rows, one launch (s2m2_mlp_chain).
+//
+// The transformer blocks of the model (reference attentions.py:311-321 GlobalAttnBlock, :347-355 BasicAttnBlock) end every
+// attention with three row-local layers:   z' = z + proj(o);   out = z' + ffn.2(GELU(ffn.0(LayerNorm(z'))))
+// and ConvBlock2D (attentions.py:255-281) has the 1x1 branch  convs_1x.2(ReLU(convs_1x.0(z))).  As separate K5 launches
+// each of these layers is a 5-7 us dependent kernel at the coarse levels (1/16, 1/32: launch-latency bound, 100+ of them per
+// pair) and a full HBM round trip of the activation at 1/4 resolution.  Here a block owns BM rows for the WHOLE chain:
+//   * the row tile lives in LDS, ping-ponging between two [BM][C+pad] buffers (the output of a stage is the A operand of the
+//     next; the last stage is staged in place and stored with coalesced 16-byte pieces);
+//   * all weights of the chain are ONE stream of [C couts x 64 bytes of K] chunks: D = 4 chunks are always in flight in
+//     registers (global -> VGPR -> LDS double buffer), and the stream runs across stage boundaries, so the only exposed
+//     memory latency is the first chunk of the first stage;
+//   * MFMA roles as in K5 (D[cout][row]: a lane owns a row), 4 waves x (BM rows x C/4 couts);
+//   * pre-LayerNorm of a stage input = row statistics from the A fragments + rowsum(W) correction (epilogue.h);
+//   * residuals: `res` (global rows) is added to the output of stage res_stage with coalesced loads issued before the stage's
+//     K loop; `carry` adds the output of stage 0 (still in the other LDS buffer) to the last stage of a 3-stage chain.
+// Every intermediate is rounded to the I/O dtype exactly where the separate launches round it (tile in LDS instead of HBM).
+#include "common.h"
+#include "epilogue.h"
+
+namespace s2m2 {
+
+struct ChainArgs {
+    const void* x;
+    const void* res;
+    void* out;
+    long long x_stride, res_stride, out_stride, rows;
+    const void* w[3];
+    const float* b[3];
+    const float* wsum[3];
+    int act[3];
+    int res_stage, carry;
+    float ln_eps;
+    const void* zero;
+};
+
+template <typename T, int C_, int BM_, int NST_>
+struct ChainCfg {
+    static constexpr int C = C_, BM = BM_, NST = NST_, NT = 256, D = 4;
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int BK = 4 * VEC;                    // K elements per chunk: 64 bytes per weight row
+    static constexpr int RS = BK + VEC;                   // weight tile row stride in LDS (80 bytes: conflict-free b128 reads)
+    static constexpr int KSTEPS = BK / 16;
+    static constexpr int ARS = C + VEC;                   // activation tile row stride (16 bytes of padding)
+    static constexpr int CRS = ARS;                       // (name used by stage_tile)
+    static constexpr int WM = BM, MT = BM / 32, WN = C / 4, NTL = WN / 32;
+    static constexpr int CPS = C / BK;                    // chunks per stage
+    static constexpr int B_IT = C / 64;                   // 16-byte weight pieces per thread and chunk
+    static constexpr int PPR = C / VEC;                   // 16-byte pieces per activation row
+    static constexpr int X_IT = BM * PPR / NT;            // activation pieces per thread
+    static constexpr size_t A_BYTES = (size_t)BM * ARS * sizeof(T);
+    static constexpr size_t W_BYTES = (size_t)C * RS * sizeof(T);
+    static constexpr size_t LDS_BYTES = 2 * A_BYTES + 2 * W_BYTES;
+    static_assert(C % 128 == 0 && CPS % D == 0 && (BM * PPR) % NT == 0 && BM % 32 == 0, "unsupported chain tile");
+    static_assert(LDS_BYTES <= 160 * 1024, "chain tile does not fit the 160 KB LDS");
+};
+
+// the weight stream: chunk j of the chain = columns [ch*BK, ch*BK+BK) of the weight of stage j / CPS
+template <typename CFG, typename T>
+struct ChainStream {
+    raw16_t r[CFG::D][CFG::B_IT];
+    const T *w0, *w1, *w2;
+    int off, lrow, pc;
+
+    __device__ __forceinline__ void init(const ChainArgs& p, int tid) {
+        w0 = static_cast<const T*>(p.w[0]); w1 = static_cast<const T*>(p.w[1]); w2 = static_cast<const T*>(p.w[2]);
+        lrow = tid >> 2; pc = tid & 3;
+        off = lrow * CFG::C + pc * CFG::VEC;
+    }
+    __device__ __forceinline__ void fetch(int j, int SLOT) {                  // j is block-uniform; SLOT is static after unrolling
+        const int st = j / CFG::CPS, ch = j - st * CFG::CPS;
+        // masked telescoping sum instead of a select chain (the compiler folds chains into a scratch lookup table)
+        const long long d1 = (const char*)w1 - (const char*)w0, d2 = (const char*)w2 - (const char*)w1;
+        const T* wp = reinterpret_cast<const T*>((const char*)w0 + ((st >= 1 ? d1 : 0) + (st >= 2 ? d2 : 0)));
+        const T* q = wp + off + ch * CFG::BK;
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + (size_t)it * 64 * CFG::C);
+    }
+    __device__ __forceinline__ void stash(T* wb, int SLOT) const {
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it)
+            *reinterpret_cast<raw16_t*>(wb + (size_t)(lrow + 64 * it) * CFG::RS + pc * CFG::VEC) = r[SLOT][it];
+    }
+};
+
+template <typename CFG, typename T, bool LN>
+__device__ __forceinline__ void chain_stage_tile(int act, const float16_t (&acc)[CFG::MT][CFG::NTL], T* dst, const CoutRegs<CFG>& bias, int wn,
+                                                 int lane, const LnRow* ln, const CoutRegs<CFG>* wsum) {
+    switch (act) {                                                // block-uniform
+        case S2M2_ACT_GELU: stage_tile<CFG, T, S2M2_ACT_GELU, LN>(acc, dst, bias, 1.0f, 0, wn, lane, ln, wsum); break;
+        case S2M2_ACT_RELU: stage_tile<CFG, T, S2M2_ACT_RELU, LN>(acc, dst, bias, 1.0f, 0, wn, lane, ln, wsum); break;
+        default: stage_tile<CFG, T, S2M2_ACT_NONE, LN>(acc, dst, bias, 1.0f, 0, wn, lane, ln, wsum); break;
+    }
+}
+
+template <typename CFG, typename T, int S>
+struct ChainStage {
+    // one stage: K loop over the CPS chunks of stage S (stream positions S*CPS ...), then the epilogue
+    static __device__ __forceinline__ void run(const ChainArgs& p, ChainStream<CFG, T>& ws, T* A0, T* A1, T* W0, T* W1, int tid, long long m0) {
+        constexpr int C = CFG::C, BK = CFG::BK, RS = CFG::RS, ARS = CFG::ARS, D = CFG::D, CPS = CFG::CPS, VEC = CFG::VEC;
+        constexpr int TOTAL = CFG::NST * CPS;
+        constexpr bool LAST = S == CFG::NST - 1;
+        T* Ain = (S & 1) ? A1 : A0;
+        T* Aother = (S & 1) ? A0 : A1;
+        T* Aout = LAST ? Ain : Aother;
+        const int lane = tid & 63, wn = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+        const bool ln_on = p.wsum[S] != nullptr;
+        const bool res_on = p.res_stage == S;
+
+        // residual rows of this stage: requested now, consumed after the K loop
+        raw16_t rr[CFG::X_IT];
+        if (res_on) {
+#pragma unroll
+            for (int it = 0; it < CFG::X_IT; ++it) {
+                const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+                const long long m = m0 + row;
+                const T* src = m < p.rows ? static_cast<const T*>(p.res) + m * p.res_stride + pcx * VEC : static_cast<const T*>(p.zero);
+                rr[it] = global_load16(src);
+            }
+        }
+
+        CoutRegs<CFG> bias, wsum;                                  // per-cout vectors of this stage: requested now as well
+        bias.load(p.b[S], p.zero, C, 0, wn, lane);
+        if (ln_on) wsum.load(p.wsum[S], p.zero, C, 0, wn, lane);
+
+        float16_t acc[CFG::MT][CFG::NTL];
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float ln_s[CFG::MT], ln_q[CFG::MT], ln_shift[CFG::MT];
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i) {
+            ln_s[i] = ln_q[i] = 0.f;
+            ln_shift[i] = (sizeof(T) == 4 && ln_on) ? to_f32(Ain[(size_t)(i * 32 + l31) * ARS]) : 0.f;
+        }
+
+        const T* arow = Ain + (size_t)l31 * ARS + hi * 8;
+        const int brow = (wn * CFG::WN + l31) * RS + hi * 8;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CPS; c0 += D) {
+#pragma unroll
+            for (int f = 0; f < D; ++f) {
+                const int j = S * CPS + c0 + f;                   // stream position of this chunk
+                T* wb = (f & 1) ? W1 : W0;                        // CPS and D are even: the LDS buffer of chunk j is j & 1 = f & 1
+                T* wnext = (f & 1) ? W0 : W1;
+                if (j + D < TOTAL) ws.fetch(j + D, f);             // slot f was stashed one chunk ago: refill
+                const T* a = arow + (c0 + f) * BK;
+                const T* b = wb + brow;
+#pragma unroll
+                for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                    Frag<T> xf[CFG::MT], wf[CFG::NTL];
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * 32 * ARS + kk * 16);
+#pragma unroll
+                    for (int jn = 0; jn < CFG::NTL; ++jn) load_frag(wf[jn], b + (size_t)jn * 32 * RS + kk * 16);
+                    if (ln_on) {
+#pragma unroll
+                        for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < CFG::NTL; ++jn) mma32(acc[i][jn], wf[jn], xf[i]);   // D[cout][row]
+                }
+                if (j + 1 < TOTAL) ws.stash(wnext, (f + 1) % D);
+                __syncthreads();
+            }
+        }
+
+        // ---- epilogue: bias / folded LayerNorm / activation in registers -> Aout[row][cout]
+        if (ln_on) {
+            LnRow ln[CFG::MT];
+            const float inv = 1.0f / (float)C;
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i) {
+                const float s = ln_s[i] + __shfl_xor(ln_s[i], 32), q = ln_q[i] + __shfl_xor(ln_q[i], 32);
+                const float mean = s * inv;
+                ln[i].mean = mean + ln_shift[i];
+                ln[i].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
+            }
+            chain_stage_tile<CFG, T, true>(p.act[S], acc, Aout, bias, wn, lane, ln, &wsum);
+        } else {
+            chain_stage_tile<CFG, T, false>(p.act[S], acc, Aout, bias, wn, lane, nullptr, nullptr);
+        }
+        __syncthreads();
+
+        if constexpr (!LAST) {
+            if (res_on) {                                          // Aout += res (rounded like the separate launch: tile, then the sum)
+#pragma unroll
+                for (int it = 0; it < CFG::X_IT; ++it) {
+                    const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+                    Vec16<T>* q = reinterpret_cast<Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC);
+                    Vec16<T> v = *q;
+                    const Vec16<T> u = __builtin_bit_cast(Vec16<T>, rr[it]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
+                    *q = v;
+                }
+                __syncthreads();
+            }
+        } else {                                                   // coalesced store of the staged tile (+ carry, + res)
+            T* outp = static_cast<T*>(p.out);
+#pragma unroll
+            for (int it = 0; it < CFG::X_IT; ++it) {
+                const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+                const long long m = m0 + row;
+                Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC);
+                if (p.carry) {
+                    const Vec16<T> u = *reinterpret_cast<const Vec16<T>*>(Aother + (size_t)row * ARS + pcx * VEC);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
+                }
+                if (res_on) {
+                    const Vec16<T> u = __builtin_bit_cast(Vec16<T>, rr[it]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
+                }
+                if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + pcx * VEC) = v;
+            }
+        }
+    }
+};
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
+    constexpr int VEC = CFG::VEC, ARS = CFG::ARS, D = CFG::D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* A0 = reinterpret_cast<T*>(smem);
+    T* A1 = reinterpret_cast<T*>(smem + CFG::A_BYTES);
+    T* W0 = reinterpret_cast<T*>(smem + 2 * CFG::A_BYTES);
+    T* W1 = reinterpret_cast<T*>(smem + 2 * CFG::A_BYTES + CFG::W_BYTES);
+    const int tid = threadIdx.x;
+    const long long m0 = (long long)blockIdx.x * CFG::BM;
+
+    ChainStream<CFG, T> ws;
+    ws.init(p, tid);
+    // the first D chunks of the weight stream and the row tile are requested together
+    ws.fetch(0, 0);
+    raw16_t xr[CFG::X_IT];
+#pragma unroll
+    for (int it = 0; it < CFG::X_IT; ++it) {
+        const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+        const long long m = m0 + row;
+        const T* src = m < p.rows ? static_cast<const T*>(p.x) + m * p.x_stride + pcx * VEC : static_cast<const T*>(p.zero);
+        xr[it] = global_load16(src);
+    }
+    if (1 < CFG::NST * CFG::CPS) ws.fetch(1, 1);
+    if (2 < CFG::NST * CFG::CPS) ws.fetch(2, 2);
+    if (3 < CFG::NST * CFG::CPS) ws.fetch(3, 3);
+    static_assert(D == 4, "prologue written for 4 chunks in flight");
+    ws.stash(W0, 0);
+#pragma unroll
+    for (int it = 0; it < CFG::X_IT; ++it) {
+        const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+        *reinterpret_cast<raw16_t*>(A0 + (size_t)row * ARS + pcx * VEC) = xr[it];
+    }
+    __syncthreads();
+
+    ChainStage<CFG, T, 0>::run(p, ws, A0, A1, W0, W1, tid, m0);
+    if constexpr (CFG::NST > 1) ChainStage<CFG, T, 1>::run(p, ws, A0, A1, W0, W1, tid, m0);
+    if constexpr (CFG::NST > 2) ChainStage<CFG, T, 2>::run(p, ws, A0, A1, W0, W1, tid, m0);
+}
+
+static const void* chain_zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
+    }
+    return z;
+}
+
+template <typename T, int C, int BM, int NST>
+static int launch_chain(const ChainArgs& a, hipStream_t st) {
+    using CFG = ChainCfg<T, C, BM, NST>;
+    auto kern = mlp_chain_kernel<CFG, T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)CFG::LDS_BYTES) != hipSuccess)
+            return set_error("mlp_chain: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.rows + BM - 1) / BM)), dim3(CFG::NT), CFG::LDS_BYTES, st, a);
+    return check_launch("mlp_chain");
+}
+
+template <typename T, int C, int BM>
+static int launch_chain_n(const ChainArgs& a, int nst, hipStream_t st) {
+    if (nst == 1) return launch_chain<T, C, BM, 1>(a, st);
+    if (nst == 2) return launch_chain<T, C, BM, 2>(a, st);
+    return launch_chain<T, C, BM, 3>(a, st);
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_mlp_chain_supported(int C, int dtype) {
+    if (dtype == S2M2_F16) return C == 128 || C == 256 || C == 384 || C == 512;
+    if (dtype == S2M2_F32) return C == 128 || C == 256;
+    return 0;
+}
+
+extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(d, "mlp_chain: null descriptor");
+    S2M2_REQUIRE(d->x && d->out, "mlp_chain: null x/out");
+    S2M2_REQUIRE(d->nstage >= 1 && d->nstage <= 3, "mlp_chain: nstage=%d (1..3)", d->nstage);
+    S2M2_REQUIRE(s2m2_mlp_chain_supported(d->C, d->dtype), "mlp_chain: C=%d dtype=%d is not supported (fp16: 128/256/384/512, fp32: 128/256)", d->C, d->dtype);
+    S2M2_REQUIRE(d->rows > 0 && d->rows < (1LL << 31), "mlp_chain: rows=%lld", d->rows);
+    S2M2_REQUIRE(d->x_stride >= d->C && d->x_stride % 8 == 0 && d->out_stride >= d->C && d->out_stride % 8 == 0,
+                 "mlp_chain: row strides %lld/%lld must be multiples of 8 and at least C", d->x_stride, d->out_stride);
+    S2M2_REQUIRE(d->res_stage >= -1 && d->res_stage < d->nstage, "mlp_chain: res_stage=%d", d->res_stage);
+    if (d->res_stage >= 0) S2M2_REQUIRE(d->res && d->res_stride >= d->C && d->res_stride % 8 == 0, "mlp_chain: res_stage needs res rows (stride multiple of 8)");
+    S2M2_REQUIRE(!d->carry || d->nstage == 3, "mlp_chain: carry (output of stage 0 added to the last stage) needs 3 stages");
+    ChainArgs a;
+    a.x = d->x; a.res = d->res; a.out = d->out;
+    a.x_stride = d->x_stride; a.res_stride = d->res_stride; a.out_stride = d->out_stride; a.rows = d->rows;
+    bool any_ln = false;
+    for (int s = 0; s < 3; ++s) {
+        const bool on = s < d->nstage;
+        a.w[s] = on ? d->weight[s] : nullptr; a.b[s] = on ? d->bias[s] : nullptr; a.wsum[s] = on ? d->ln_wsum[s] : nullptr;
+        a.act[s] = on ? d->act[s] : 0;
+        if (on) {
+            S2M2_REQUIRE(d->weight[s], "mlp_chain: weight[%d] is null", s);
+            S2M2_REQUIRE(d->act[s] == S2M2_ACT_NONE || d->act[s] == S2M2_ACT_GELU || d->act[s] == S2M2_ACT_RELU,
+                         "mlp_chain: act[%d]=%d (NONE, GELU or RELU)", s, d->act[s]);
+            any_ln |= d->ln_wsum[s] != nullptr;
+        }
+    }
+    S2M2_REQUIRE(!any_ln || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
+    a.res_stage = d->res_stage; a.carry = d->carry; a.ln_eps = d->ln_eps;
+    a.zero = chain_zero_page();
+    S2M2_REQUIRE(a.zero, "mlp_chain: cannot allocate the zero page");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->dtype == S2M2_F16) {
+        switch (d->C) {
+            case 128: return launch_chain_n<half_t, 128, 64>(a, d->nstage, st);
+            case 256: return launch_chain_n<half_t, 256, 64>(a, d->nstage, st);
+            case 384: return launch_chain_n<half_t, 384, 32>(a, d->nstage, st);
+            default: return launch_chain_n<half_t, 512, 32>(a, d->nstage, st);
+        }
+    }
+    if (d->C == 128) return launch_chain_n<float, 128, 32>(a, d->nstage, st);
+    return launch_chain_n<float, 256, 32>(a, d->nstage, st);
+}

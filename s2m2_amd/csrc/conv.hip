@@ -25,6 +25,7 @@
 #ifndef S2M2_CONV_DBG
 #define S2M2_CONV_DBG 0
 #endif
+#include "epilogue.h"
 
 namespace s2m2 {
 
@@ -72,96 +73,6 @@ struct ConvCfg {
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be whole 32x32 MFMA tiles");
 };
 
-// Activations in the epilogue run on all BM*BN accumulators, so they must be a handful of VALU ops each: libm's erff / tanhf
-// (~100 instructions with divergent range splits) made the GELU epilogue as expensive as the whole K loop.
-//  erf: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 (below fp32 round-off of the surrounding arithmetic);
-//  exp: v_exp_f32 (1 ulp);  sigmoid / tanh from it.
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_erf(float x) {
-    const float ax = fabsf(x);
-    const float t = fast_rcp(__builtin_fmaf(0.3275911f, ax, 1.0f));
-    float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    pl = __builtin_fmaf(pl, t, 1.421413741f);
-    pl = __builtin_fmaf(pl, t, -0.284496736f);
-    pl = __builtin_fmaf(pl, t, 0.254829592f);
-    const float r = 1.0f - pl * t * fast_exp(-ax * ax);
-    return copysignf(r, x);
-}
-template <int ACT> __device__ __forceinline__ float activate(float x) {
-    if (ACT == S2M2_ACT_GELU) return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
-    if (ACT == S2M2_ACT_RELU) return fmaxf(x, 0.f);
-    if (ACT == S2M2_ACT_SIGMOID) return fast_rcp(1.0f + fast_exp(-x));
-    if (ACT == S2M2_ACT_TANH) return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x));
-    return x;
-}
-
-// epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]; ACT is a compile-time constant here (a
-// runtime switch per element made the compiler evaluate every activation and select)
-// Pre-LayerNorm folded into a 1x1 layer (reference attentions.py:117,148,182,213,243: LayerNorm without affine feeding a Linear):
-//   W . ((x - mean) * rstd) + b  =  rstd * (W . x  -  mean * rowsum(W)) + b
-// The GEMM runs on the raw rows; mean / rstd of a row come from the A fragments the wave reads anyway (a lane owns one pixel
-// and half of every k16 step: sum and sum of squares in fp32, one cross-half exchange at the end); rowsum(W) is packed once.
-struct LnRow { float mean, rstd; };
-
-// fp16 rows: products and sums are exact-ish in fp32 (error ~1e-7 * (mean/std)^2 relative to the variance, far below the fp16
-// rounding of the operands).  fp32 rows: sums are taken about the row's first element, so a mean much larger than the spread
-// does not cancel in q/C - mean^2.
-__device__ __forceinline__ void ln_accumulate(const Frag<half_t>& f, float& s, float& q, float) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const h2 v = {f.v[2 * e], f.v[2 * e + 1]};
-        s = __builtin_amdgcn_fdot2(v, one, s, false);
-        q = __builtin_amdgcn_fdot2(v, v, q, false);
-    }
-}
-__device__ __forceinline__ void ln_accumulate(const Frag<float>& f, float& s, float& q, float shift) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d = f.v[e] - shift; s += d; q = __builtin_fmaf(d, d, q); }
-}
-
-template <typename CFG, typename T, int ACT, bool LN = false>
-__device__ __forceinline__ void stage_tile(const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, const float* __restrict__ bias, int Cout,
-                                           float out_scale, int n0, int wm, int wn, int lane, const LnRow* ln = nullptr,
-                                           const float* __restrict__ wsum = nullptr) {
-    const int hi = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < CFG::MT; ++i) {
-        T* crow = Cs + (size_t)(wm * CFG::WM + i * 32 + (lane & 31)) * CFG::CRS;
-#pragma unroll
-        for (int j = 0; j < CFG::NTL; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int cl = wn * CFG::WN + j * 32 + 8 * g + 4 * hi;         // local cout of the quad
-                const int co = n0 + cl;
-                float4_t bv = {0.f, 0.f, 0.f, 0.f};
-                if (bias && co < Cout) bv = *reinterpret_cast<const float4_t*>(bias + co);
-                float v[4];
-                if constexpr (LN) {
-                    float4_t ws = {0.f, 0.f, 0.f, 0.f};
-                    if (co < Cout) ws = *reinterpret_cast<const float4_t*>(wsum + co);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = activate<ACT>(ln[i].rstd * __builtin_fmaf(-ln[i].mean, ws[e], acc[i][j][4 * g + e]) + bv[e]) * out_scale;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = (S2M2_CONV_DBG & 16) ? acc[i][j][4 * g + e] : activate<ACT>(acc[i][j][4 * g + e] + bv[e]) * out_scale;
-                }
-                if constexpr (sizeof(T) == 2) {
-                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<half4_t*>(crow + cl) = h;
-                } else {
-                    float4_t f = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<float4_t*>(crow + cl) = f;
-                }
-            }
-        }
-    }
-}
-
 template <typename T> __device__ __forceinline__ Vec16<T> zero_vec() {
     Vec16<T> z;
 #pragma unroll
@@ -169,35 +80,62 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero_vec() {
     return z;
 }
 
-// epilogue 2: the staged tile comes back as 16-byte pieces of whole pixel rows: aux combine, coalesced store
+// Aux tensors of the epilogue (residual / gate operands), one 16-byte piece per staged piece of this thread: requested right
+// after the K loop, so their latency runs under the activation math, the LDS staging and its barrier instead of in front of
+// every store.  Kept in registers only while that is cheap (at most 4 pieces per thread); larger tiles load inside the loop.
 template <typename CFG, typename T>
-__device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int tid, long long m0, int n0, long long M) {
-    constexpr int BM = CFG::BM, BN = CFG::BN, VEC = CFG::VEC;
-    constexpr int PCR = BN / VEC;                                 // pieces per staged row
-    constexpr int TOTAL = BM * PCR;
+struct AuxRegs {
+    static constexpr int PCR = CFG::BN / CFG::VEC;                // pieces per staged row
+    static constexpr int TOTAL = CFG::BM * PCR;
+    static constexpr int NP = (TOTAL + CFG::NT - 1) / CFG::NT;    // pieces per thread
+    static constexpr bool ON = NP <= 4;
+    raw16_t a0[ON ? NP : 1], a1[ON ? NP : 1];
+
+    // pix(r, m): global output pixel of staged row r (false: outside the image / past M)
+    template <typename PIX>
+    __device__ __forceinline__ void prefetch(const ConvArgs& p, int tid, int n0, PIX pix) {
+        if constexpr (ON) {
+            if (p.epi == S2M2_EPI_NONE) return;
+            const bool two = p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX;
+#pragma unroll
+            for (int it = 0; it < NP; ++it) {
+                const int q = tid + CFG::NT * it, r = q / PCR, pcc = q - r * PCR;
+                const int co = n0 + pcc * CFG::VEC;
+                long long m;
+                const bool ok = q < TOTAL && pix(r, m) && co < p.Cout;
+                a0[it] = global_load16(ok ? static_cast<const T*>(p.aux0) + m * p.aux0_stride + co : static_cast<const T*>(p.zero));
+                a1[it] = raw16_t{0.f, 0.f, 0.f, 0.f};             // (copying a0 here would wait for its load)
+                if (two) a1[it] = global_load16(ok ? static_cast<const T*>(p.aux1) + m * p.aux1_stride + co : static_cast<const T*>(p.zero));
+            }
+        }
+    }
+};
+
+// epilogue 2: the staged tile comes back as 16-byte pieces of whole pixel rows: aux combine, coalesced store
+template <typename CFG, typename T, typename PIX>
+__device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int tid, int n0, const AuxRegs<CFG, T>& aux, PIX pix) {
+    using AX = AuxRegs<CFG, T>;
+    constexpr int VEC = CFG::VEC, PCR = AX::PCR;
     T* outp = static_cast<T*>(p.out);
-#pragma unroll 2
-    for (int q = tid; q < TOTAL; q += CFG::NT) {
-        const int r = q / PCR, pcc = q - r * PCR;
-        const long long m = m0 + r;
+#pragma unroll
+    for (int it = 0; it < AX::NP; ++it) {
+        const int q = tid + CFG::NT * it, r = q / PCR, pcc = q - r * PCR;
         const int co = n0 + pcc * VEC;
-        if (m >= M || co >= p.Cout) continue;
+        long long m;
+        if (q >= AX::TOTAL || !pix(r, m) || co >= p.Cout) continue;
         Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
         if (p.epi != S2M2_EPI_NONE) {
-            const Vec16<T> a0 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux0) + m * p.aux0_stride + co);
-            Vec16<T> a1 = a0;
-            if (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX)
-                a1 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux1) + m * p.aux1_stride + co);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float x = to_f32(v.v[e]), u = to_f32(a0.v[e]), w = to_f32(a1.v[e]);
-                float o;
-                if (p.epi == S2M2_EPI_ADD) o = x + u;
-                else if (p.epi == S2M2_EPI_MUL) o = x * u;
-                else if (p.epi == S2M2_EPI_GRU) o = (1.0f - u) * w + u * x;                      // aux0 = z, aux1 = h, x = q
-                else { const float gte = fminf(fmaxf(x, 0.01f), 0.99f); o = gte * u + (1.0f - gte) * w; }   // x = gate
-                v.v[e] = from_f32<T>(o);
+            Vec16<T> a0, a1;
+            if constexpr (AX::ON) {
+                a0 = __builtin_bit_cast(Vec16<T>, aux.a0[it]);
+                a1 = __builtin_bit_cast(Vec16<T>, aux.a1[it]);
+            } else {
+                a0 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux0) + m * p.aux0_stride + co);
+                a1 = a0;
+                if (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX)
+                    a1 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux1) + m * p.aux1_stride + co);
             }
+            aux_combine(v, p.epi, a0, a1);
         }
         long long opix = m;
         int oc = co;
@@ -214,22 +152,38 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int t
     }
 }
 
+// staged row -> output pixel maps: linear kernels (row r of the tile is pixel m0 + r) ...
+struct LinearPix {
+    long long m0, M;
+    __device__ __forceinline__ bool operator()(int r, long long& m) const { m = m0 + r; return m < M; }
+};
+// ... and the halo kernel (row r = patch row * 32 + column)
+struct PatchPix {
+    int n, y0, x0, H, W;
+    __device__ __forceinline__ bool operator()(int r, long long& m) const {
+        const int yy = y0 + (r >> 5), xx = x0 + (r & 31);
+        m = ((long long)n * H + yy) * W + xx;
+        return yy < H && xx < W;
+    }
+};
+
 // the pre-LN layers of the model are the QKV projections (no activation) and the first FFN layer (GELU)
 template <typename CFG, typename T>
-__device__ __forceinline__ void stage_tile_ln(const ConvArgs& p, const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, int n0, int wm, int wn, int lane,
-                                              const LnRow* ln) {
-    if (p.act == S2M2_ACT_GELU) stage_tile<CFG, T, S2M2_ACT_GELU, true>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane, ln, p.ln_wsum);
-    else stage_tile<CFG, T, S2M2_ACT_NONE, true>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane, ln, p.ln_wsum);
+__device__ __forceinline__ void stage_tile_ln(const ConvArgs& p, const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, const CoutRegs<CFG>& bias,
+                                              int wm, int wn, int lane, const LnRow* ln, const CoutRegs<CFG>& wsum) {
+    if (p.act == S2M2_ACT_GELU) stage_tile<CFG, T, S2M2_ACT_GELU, true>(acc, Cs, bias, p.out_scale, wm, wn, lane, ln, &wsum);
+    else stage_tile<CFG, T, S2M2_ACT_NONE, true>(acc, Cs, bias, p.out_scale, wm, wn, lane, ln, &wsum);
 }
 
-template <typename CFG, typename T, int UNUSED = 0>
-__device__ __forceinline__ void stage_tile_act(const ConvArgs& p, const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, int n0, int wm, int wn, int lane) {
+template <typename CFG, typename T>
+__device__ __forceinline__ void stage_tile_act(const ConvArgs& p, const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, const CoutRegs<CFG>& bias,
+                                               int wm, int wn, int lane) {
     switch (p.act) {                                              // block-uniform
-        case S2M2_ACT_GELU: stage_tile<CFG, T, S2M2_ACT_GELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        case S2M2_ACT_RELU: stage_tile<CFG, T, S2M2_ACT_RELU>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        case S2M2_ACT_SIGMOID: stage_tile<CFG, T, S2M2_ACT_SIGMOID>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        case S2M2_ACT_TANH: stage_tile<CFG, T, S2M2_ACT_TANH>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
-        default: stage_tile<CFG, T, S2M2_ACT_NONE>(acc, Cs, p.bias, p.Cout, p.out_scale, n0, wm, wn, lane); break;
+        case S2M2_ACT_GELU: stage_tile<CFG, T, S2M2_ACT_GELU>(acc, Cs, bias, p.out_scale, wm, wn, lane); break;
+        case S2M2_ACT_RELU: stage_tile<CFG, T, S2M2_ACT_RELU>(acc, Cs, bias, p.out_scale, wm, wn, lane); break;
+        case S2M2_ACT_SIGMOID: stage_tile<CFG, T, S2M2_ACT_SIGMOID>(acc, Cs, bias, p.out_scale, wm, wn, lane); break;
+        case S2M2_ACT_TANH: stage_tile<CFG, T, S2M2_ACT_TANH>(acc, Cs, bias, p.out_scale, wm, wn, lane); break;
+        default: stage_tile<CFG, T, S2M2_ACT_NONE>(acc, Cs, bias, p.out_scale, wm, wn, lane); break;
     }
 }
 
@@ -390,6 +344,9 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     float ln_s[CFG::MT], ln_q[CFG::MT], ln_shift[CFG::MT];
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i) ln_s[i] = ln_q[i] = ln_shift[i] = 0.f;
+    CoutRegs<CFG> bias, wsum;                                     // requested now, used after the K loop
+    bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
+    if constexpr (LN) wsum.load(p.ln_wsum, p.zero, p.Cout, n0, wn, lane);
 
     // K tiles are requested NPF ahead into a ring of register slots (slot = tile % NPF, static after unrolling): for the short-K
     // layers (1x1, K <= NPF tiles) the whole K of the block is in flight at once -- one memory latency per block instead of one per tile
@@ -443,6 +400,9 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     }
 
     // ---- epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]
+    const LinearPix pix{m0, M};
+    AuxRegs<CFG, T> aux;
+    aux.prefetch(p, tid, n0, pix);
     if constexpr (LN) {
         LnRow ln[CFG::MT];
         const float inv = 1.0f / (float)Ktot;
@@ -453,13 +413,13 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
             ln[i].mean = mean + ln_shift[i];
             ln[i].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
         }
-        stage_tile_ln<CFG, T>(p, acc, Cs, n0, wm, wn, lane, ln);
+        stage_tile_ln<CFG, T>(p, acc, Cs, bias, wm, wn, lane, ln, wsum);
     } else {
-        stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+        stage_tile_act<CFG, T>(p, acc, Cs, bias, wm, wn, lane);
     }
     __syncthreads();
 
-    store_tile<CFG, T>(p, Cs, tid, m0, n0, M);
+    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -683,9 +643,14 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the tail requests (zero block) must land before LDS is reused
     __syncthreads();
 
-    stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+    CoutRegs<CFG> bias;
+    bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
+    const LinearPix pix{m0, M};
+    AuxRegs<CFG, T> aux;
+    aux.prefetch(p, tid, n0, pix);
+    stage_tile_act<CFG, T>(p, acc, Cs, bias, wm, wn, lane);
     __syncthreads();
-    store_tile<CFG, T>(p, Cs, tid, m0, n0, M);
+    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -822,6 +787,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
         }
     };
 
+    CoutRegs<CFG> bias;                                           // requested now, used after the K loop
+    bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
     float16_t acc[CFG::MT][CFG::NTL];
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i)
@@ -869,36 +836,12 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
     }
 
     // ---- epilogues: staging rows r = patch row * 32 + column (the same wm*64 + i*32 + lane map as the linear kernels)
-    stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+    const PatchPix pix{n, y0, x0, p.H, p.W};
+    AuxRegs<CFG, T> aux;
+    aux.prefetch(p, tid, n0, pix);
+    stage_tile_act<CFG, T>(p, acc, Cs, bias, wm, wn, lane);
     __syncthreads();
-    constexpr int PCR = BN / VEC;
-    T* outp = static_cast<T*>(p.out);
-#pragma unroll 2
-    for (int q = tid; q < 128 * PCR; q += CFG::NT) {
-        const int r = q / PCR, pcc = q - r * PCR;
-        const int yy = y0 + (r >> 5), xx = x0 + (r & 31);
-        const int co = n0 + pcc * VEC;
-        if (yy >= p.H || xx >= p.W || co >= p.Cout) continue;
-        const long long m = ((long long)n * p.H + yy) * p.W + xx;
-        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
-        if (p.epi != S2M2_EPI_NONE) {
-            const Vec16<T> a0 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux0) + m * p.aux0_stride + co);
-            Vec16<T> a1 = a0;
-            if (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX)
-                a1 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux1) + m * p.aux1_stride + co);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float x = to_f32(v.v[e]), u = to_f32(a0.v[e]), w = to_f32(a1.v[e]);
-                float o;
-                if (p.epi == S2M2_EPI_ADD) o = x + u;
-                else if (p.epi == S2M2_EPI_MUL) o = x * u;
-                else if (p.epi == S2M2_EPI_GRU) o = (1.0f - u) * w + u * x;
-                else { const float gte = fminf(fmaxf(x, 0.01f), 0.99f); o = gte * u + (1.0f - gte) * w; }
-                v.v[e] = from_f32<T>(o);
-            }
-        }
-        *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + co) = v;
-    }
+    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -942,6 +885,8 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvArgs p, int ntiles) {
     const int hi = lane >> 5, l31 = lane & 31;
     const long long M = (long long)p.N * p.H * p.W;
     const int n0 = blockIdx.y * BN;
+    CoutRegs<CFG> bias;                                           // the block keeps its cout slice for its whole life
+    bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
     const T* zp = static_cast<const T*>(p.zero);
 
     // ---- weight slice -> LDS once (rows past Cout are zero)
@@ -1025,14 +970,19 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvArgs p, int ntiles) {
         }
         if (chunk_cur == nchunk - 1) {
             // ---- tile finished: epilogue (Cs is separate from the ring; the k-step barriers order its reuse)
-            stage_tile_act<CFG, T>(p, acc, Cs, n0, wm, wn, lane);
+            stage_tile_act<CFG, T>(p, acc, Cs, bias, wm, wn, lane);
 #pragma unroll
             for (int j = 0; j < CFG::NTL; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
             if (more) stash(buf ^ 1);
             __syncthreads();
-            store_tile<CFG, T>(p, Cs, tid, mt_cur * BM, n0, M);
+            {
+                const LinearPix pix{mt_cur * BM, M};
+                AuxRegs<CFG, T> aux;
+                aux.prefetch(p, tid, n0, pix);
+                store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);
+            }
             mt_cur += gridDim.x;
             chunk_cur = 0;
         } else {

@@ -1,0 +1,132 @@
+// Epilogue math shared by the GEMM-shaped kernels (K5 conv.hip, K9 chain.hip): activations, folded pre-LayerNorm.
+#pragma once
+#include "common.h"
+
+#ifndef S2M2_CONV_DBG
+#define S2M2_CONV_DBG 0          // ablation switches of conv.hip (bit 16: skip bias/activation math)
+#endif
+
+namespace s2m2 {
+
+// Activations in the epilogue run on all BM*BN accumulators, so they must be a handful of VALU ops each: libm's erff / tanhf
+// (~100 instructions with divergent range splits) made the GELU epilogue as expensive as the whole K loop.
+//  erf: Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7 (below fp32 round-off of the surrounding arithmetic);
+//  exp: v_exp_f32 (1 ulp);  sigmoid / tanh from it.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_erf(float x) {
+    const float ax = fabsf(x);
+    const float t = fast_rcp(__builtin_fmaf(0.3275911f, ax, 1.0f));
+    float pl = __builtin_fmaf(1.061405429f, t, -1.453152027f);
+    pl = __builtin_fmaf(pl, t, 1.421413741f);
+    pl = __builtin_fmaf(pl, t, -0.284496736f);
+    pl = __builtin_fmaf(pl, t, 0.254829592f);
+    const float r = 1.0f - pl * t * fast_exp(-ax * ax);
+    return copysignf(r, x);
+}
+template <int ACT> __device__ __forceinline__ float activate(float x) {
+    if (ACT == S2M2_ACT_GELU) return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+    if (ACT == S2M2_ACT_RELU) return fmaxf(x, 0.f);
+    if (ACT == S2M2_ACT_SIGMOID) return fast_rcp(1.0f + fast_exp(-x));
+    if (ACT == S2M2_ACT_TANH) return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x));
+    return x;
+}
+
+// Pre-LayerNorm folded into a 1x1 layer (reference attentions.py:117,148,182,213,243: LayerNorm without affine feeding a Linear):
+//   W . ((x - mean) * rstd) + b  =  rstd * (W . x  -  mean * rowsum(W)) + b
+// The GEMM runs on the raw rows; mean / rstd of a row come from the A fragments the wave reads anyway (a lane owns one pixel
+// and half of every k16 step: sum and sum of squares in fp32, one cross-half exchange at the end); rowsum(W) is packed once.
+struct LnRow { float mean, rstd; };
+
+// fp16 rows: products and sums are exact-ish in fp32 (error ~1e-7 * (mean/std)^2 relative to the variance, far below the fp16
+// rounding of the operands).  fp32 rows: sums are taken about the row's first element, so a mean much larger than the spread
+// does not cancel in q/C - mean^2.
+__device__ __forceinline__ void ln_accumulate(const Frag<half_t>& f, float& s, float& q, float) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const h2 v = {f.v[2 * e], f.v[2 * e + 1]};
+        s = __builtin_amdgcn_fdot2(v, one, s, false);
+        q = __builtin_amdgcn_fdot2(v, v, q, false);
+    }
+}
+__device__ __forceinline__ void ln_accumulate(const Frag<float>& f, float& s, float& q, float shift) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = f.v[e] - shift; s += d; q = __builtin_fmaf(d, d, q); }
+}
+
+// Per-output-channel fp32 vectors (bias, rowsum(W)) in the accumulator layout of one wave: quad g of MFMA tile j holds couts
+// wn*WN + j*32 + 8g + 4hi .. +3.  They are requested BEFORE the K loop with unconditional loads (out-of-range quads and a null
+// source read the zero page): conditional loads inside the epilogue compile to one `s_waitcnt vmcnt(0)` per quad, i.e. 4*NTL
+// serial memory latencies at the end of every block -- on the short layers that was a third of the kernel.
+template <typename CFG>
+struct CoutRegs {
+    raw16_t v[CFG::NTL][4];
+    __device__ __forceinline__ void load(const float* src, const void* zero, int Cout, int n0, int wn, int lane) {
+        const int hi = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = n0 + wn * CFG::WN + j * 32 + 8 * g + 4 * hi;
+                const float* q = (src != nullptr && co < Cout) ? src + co : static_cast<const float*>(zero);
+                v[j][g] = global_load16(q);
+            }
+    }
+};
+
+// epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]; ACT is a compile-time constant here (a
+// runtime switch per element made the compiler evaluate every activation and select)
+template <typename CFG, typename T, int ACT, bool LN = false>
+__device__ __forceinline__ void stage_tile(const float16_t (&acc)[CFG::MT][CFG::NTL], T* Cs, const CoutRegs<CFG>& bias, float out_scale,
+                                           int wm, int wn, int lane, const LnRow* ln = nullptr, const CoutRegs<CFG>* wsum = nullptr) {
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i) {
+        T* crow = Cs + (size_t)(wm * CFG::WM + i * 32 + (lane & 31)) * CFG::CRS;
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = wn * CFG::WN + j * 32 + 8 * g + 4 * hi;         // local cout of the quad
+                const raw16_t bv = bias.v[j][g];
+                float v[4];
+                if constexpr (LN) {
+                    const raw16_t ws = wsum->v[j][g];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = activate<ACT>(ln[i].rstd * __builtin_fmaf(-ln[i].mean, ws[e], acc[i][j][4 * g + e]) + bv[e]) * out_scale;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = (S2M2_CONV_DBG & 16) ? acc[i][j][4 * g + e] : activate<ACT>(acc[i][j][4 * g + e] + bv[e]) * out_scale;
+                }
+                if constexpr (sizeof(T) == 2) {
+                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<half4_t*>(crow + cl) = h;
+                } else {
+                    float4_t f = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<float4_t*>(crow + cl) = f;
+                }
+            }
+        }
+    }
+}
+
+// epilogue 2 helper: combine one staged 16-byte piece with the aux tensors (S2M2_EPI_*)
+template <typename T>
+__device__ __forceinline__ void aux_combine(Vec16<T>& v, int epi, const Vec16<T>& a0, const Vec16<T>& a1) {
+#pragma unroll
+    for (int e = 0; e < (int)(16 / sizeof(T)); ++e) {
+        const float x = to_f32(v.v[e]), u = to_f32(a0.v[e]), w = to_f32(a1.v[e]);
+        float o;
+        if (epi == S2M2_EPI_ADD) o = x + u;
+        else if (epi == S2M2_EPI_MUL) o = x * u;
+        else if (epi == S2M2_EPI_GRU) o = (1.0f - u) * w + u * x;                                  // aux0 = z, aux1 = h, x = q
+        else { const float gte = fminf(fmaxf(x, 0.01f), 0.99f); o = gte * u + (1.0f - gte) * w; }   // x = gate
+        v.v[e] = from_f32<T>(o);
+    }
+}
+
+}  // namespace s2m2

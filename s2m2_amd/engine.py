@@ -60,6 +60,8 @@ class Engine:
         self._bufs: Dict[object, Tensor] = {}
         self._wsum: Dict[int, Tensor] = {}
         self.fuse_ln = os.environ.get("S2M2_FUSE_LN", "1") != "0"      # A/B switch: 0 = separate K6 LayerNorm launches
+        self.use_chain = os.environ.get("S2M2_CHAIN", "1") != "0"      # A/B switch: 0 = one K5 launch per 1x1 layer instead of K9 chains
+        self._chain_ok: Dict[int, bool] = {}
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
@@ -127,11 +129,7 @@ class Engine:
         the kernel -- needs the row sums of the packed weight, computed once per layer."""
         wp, bp, kh, kw_, cout = spec
         if ln:
-            ws = self._wsum.get(wp.data_ptr())
-            if ws is None:
-                ws = wp.float().sum(dim=1).contiguous()
-                self._wsum[wp.data_ptr()] = ws
-            kw["ln_wsum"] = ws
+            kw["ln_wsum"] = self.wsum(spec)
         return hip.conv2d(srcs, wp, bp, kh, kw_, cout, **kw)
 
     def zeros(self, key, shape, dtype=None) -> Tensor:
@@ -166,9 +164,14 @@ class Engine:
 
     def conv_block(self, p: str, z: Tensor) -> Tensor:
         """ConvBlock2D (attentions.py:255-281): conv3-GELU-conv3 + conv1-ReLU-conv1."""
+        c0, c2 = self.std(p + ".convs_1x.0"), self.std(p + ".convs_1x.2")
+        chain = self.use_chain and self.chain_ok(z.shape[-1]) and c0[4] == z.shape[-1] and c2[4] == z.shape[-1]
         with self.fork():                                         # 1x1 branch in parallel with the first 3x3
-            u = self.cconv(self.std(p + ".convs_1x.0"), [z], act=hip.ACT_RELU)
-            b = self.cconv(self.std(p + ".convs_1x.2"), [u])
+            if chain:
+                u = b = hip.mlp_chain(z, [(c0[0], c0[1], hip.ACT_RELU, None), (c2[0], c2[1], hip.ACT_NONE, None)])
+            else:
+                u = self.cconv(c0, [z], act=hip.ACT_RELU)
+                b = self.cconv(c2, [u])
         t = self.cconv(self.std(p + ".convs.0"), [z], act=hip.ACT_GELU)
         self.join(b, u)
         return self.cconv(self.std(p + ".convs.2"), [t], epi=hip.EPI_ADD, aux0=b)
@@ -196,7 +199,7 @@ class Engine:
         return self.cconv(spec, [x], ln=self.fuse_ln) if self.fuse_ln else self.cconv(spec, [hip.layernorm(x)])
 
     def attn_core(self, p: str, z: Tensor, nh: int, two_d: bool, cross: bool, use_pe: bool) -> Tensor:
-        """pre-LN -> fused QKV projection -> K4 -> output projection with the residual add as epilogue."""
+        """pre-LN -> fused QKV projection -> K4; returns the attention output BEFORE the output projection (see attn_ffn)."""
         n, h, w, c = z.shape
         qkv = self.qkv(p + ".attn", z)                       # pre-LN folded into the projection
         v3 = qkv.reshape(n, h * w, 3 * c) if two_d else qkv.reshape(n * h, w, 3 * c)
@@ -208,20 +211,43 @@ class Engine:
             o = self.cconv(self.std(p + ".attn.pe_proj"), [pes.reshape(1, 1, -1, 32)], epi=hip.EPI_ADD, aux0=o.reshape(1, 1, -1, d))
         else:
             o = hip.attention(q, k, v, nh, swap_halves=cross)
-        return self.cconv(self.std(p + ".attn.proj"), [o.reshape(n, h, w, c)], epi=hip.EPI_ADD, aux0=z)
+        return o.reshape(n, h, w, c)
 
-    def ffn(self, p: str, z: Tensor) -> Tensor:
+    def wsum(self, spec: Spec) -> Tensor:
+        """row sums of a packed weight (the pre-LayerNorm correction term of K5 / K9), computed once per layer"""
+        wp = spec[0]
+        ws = self._wsum.get(wp.data_ptr())
+        if ws is None:
+            ws = wp.float().sum(dim=1).contiguous()
+            self._wsum[wp.data_ptr()] = ws
+        return ws
+
+    def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor) -> Tensor:
+        """z' = z + proj(o);  z' + ffn.2(GELU(ffn.0(LayerNorm(z')))) (attentions.py:311-321,347-355): one K9 launch when the width
+        is supported, else three K5 launches (pre-LN folded into the first FFN layer)."""
+        c = z.shape[-1]
+        proj, f0, f2 = self.std(pa + ".attn.proj"), self.std(pf + ".ffn.0"), self.std(pf + ".ffn.2")
+        if self.use_chain and self.chain_ok(c):
+            return hip.mlp_chain(o, [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)),
+                                     (f2[0], f2[1], hip.ACT_NONE, None)], res=z, res_stage=0, carry=True)
+        z = self.cconv(proj, [o], epi=hip.EPI_ADD, aux0=z)
         if self.fuse_ln:
-            hdn = self.cconv(self.std(p + ".ffn.0"), [z], ln=True, act=hip.ACT_GELU)
+            hdn = self.cconv(f0, [z], ln=True, act=hip.ACT_GELU)
         else:
-            hdn = self.cconv(self.std(p + ".ffn.0"), [hip.layernorm(z)], act=hip.ACT_GELU)
-        return self.cconv(self.std(p + ".ffn.2"), [hdn], epi=hip.EPI_ADD, aux0=z)
+            hdn = self.cconv(f0, [hip.layernorm(z)], act=hip.ACT_GELU)
+        return self.cconv(f2, [hdn], epi=hip.EPI_ADD, aux0=z)
+
+    def chain_ok(self, c: int) -> bool:
+        ok = self._chain_ok.get(c)
+        if ok is None:
+            ok = self._chain_ok[c] = hip.mlp_chain_supported(c, self.dtype)
+        return ok
 
     def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False) -> Tensor:
         """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321)."""
         if (p + ".cross_attn.attn.q.weight") in self.p:
-            z = self.ffn(p + ".ffn_c", self.attn_core(p + ".cross_attn", z, nh, two_d, True, False))
-        return self.ffn(p + ".ffn", self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe))
+            z = self.attn_ffn(p + ".cross_attn", p + ".ffn_c", self.attn_core(p + ".cross_attn", z, nh, two_d, True, False), z)
+        return self.attn_ffn(p + ".self_attn", p + ".ffn", self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe), z)
 
     def _count(self, prefix: str) -> int:
         n = 0

@@ -35,6 +35,13 @@ class ConvDesc(ctypes.Structure):
                 ("ln_wsum", _vp), ("ln_eps", ctypes.c_float)]
 
 
+class ChainDesc(ctypes.Structure):
+    """mirror of s2m2_chain_desc (include/s2m2_hip.h)"""
+    _fields_ = [("x", _vp), ("res", _vp), ("out", _vp), ("x_stride", _ll), ("res_stride", _ll), ("out_stride", _ll), ("rows", _ll),
+                ("C", _i), ("nstage", _i), ("weight", _vp * 3), ("bias", _vp * 3), ("ln_wsum", _vp * 3), ("act", _i * 3),
+                ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
 SIGNATURES = {
     "s2m2_version": (_i, []),
@@ -45,6 +52,8 @@ SIGNATURES = {
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    "s2m2_mlp_chain_supported": (_i, [_i, _i]),
+    "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
     "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _ll, _i, _vp]),
     "s2m2_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _ll,
                             _i, _i, _i, _vp]),
@@ -207,6 +216,57 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
         d.ln_eps = ln_eps
     d.dtype = _DT[dt]
     _check(load().s2m2_conv2d(ctypes.byref(d), _stream()), "s2m2_conv2d")
+    return out
+
+
+def _token_rows(x: torch.Tensor, what: str):
+    """(rows, row stride) of a (..., C) tensor with contiguous channels and a uniform row stride"""
+    C = x.shape[-1]
+    if x.stride(-1) != 1:
+        raise ValueError(f"{what}: channels must be contiguous")
+    xs = x.stride(-2) if x.dim() > 1 else C
+    for d in range(x.dim() - 2):
+        if x.shape[d] > 1 and x.stride(d) != x.stride(d + 1) * x.shape[d + 1]:
+            raise ValueError(f"{what}: rows must have a uniform stride")
+    return x.numel() // C, xs
+
+
+def mlp_chain_supported(C: int, dtype: torch.dtype) -> bool:
+    return bool(load().s2m2_mlp_chain_supported(C, _DT[dtype]))
+
+
+def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
+              ln_eps: float = 1e-5) -> torch.Tensor:
+    """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
+    (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
+    res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages."""
+    C = x.shape[-1]
+    rows, xs = _token_rows(x, "mlp_chain")
+    d = ChainDesc()
+    d.x, d.x_stride, d.rows, d.C, d.nstage, d.dtype = x.data_ptr(), xs, rows, C, len(stages), _DT[x.dtype]
+    if not 1 <= len(stages) <= 3:
+        raise ValueError("mlp_chain: 1..3 stages")
+    keep = [x]
+    for i, (w, b, act, wsum) in enumerate(stages):
+        if w.dtype != x.dtype or tuple(w.shape) != (C, C) or not w.is_contiguous():
+            raise ValueError(f"mlp_chain: weight[{i}] must be a packed ({C}, {C}) {x.dtype} matrix, got {tuple(w.shape)} {w.dtype}")
+        for name, t in (("bias", b), ("ln_wsum", wsum)):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous()):
+                raise ValueError(f"mlp_chain: {name}[{i}] must be fp32 ({C})")
+        d.weight[i], d.act[i] = w.data_ptr(), act
+        d.bias[i] = b.data_ptr() if b is not None else None
+        d.ln_wsum[i] = wsum.data_ptr() if wsum is not None else None
+        keep += [w, b, wsum]
+    if not all(t.is_cuda for t in keep if t is not None):
+        raise ValueError("mlp_chain: tensors must live on the GPU")
+    d.res_stage, d.carry, d.ln_eps = res_stage, int(carry), ln_eps
+    if res_stage >= 0:
+        if res is None or res.dtype != x.dtype or tuple(res.shape) != tuple(x.shape):
+            raise ValueError("mlp_chain: res must match x")
+        d.res, d.res_stride = res.data_ptr(), _token_rows(res, "mlp_chain")[1]
+    out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    d.out, d.out_stride = out.data_ptr(), C
+    _check(load().s2m2_mlp_chain(ctypes.byref(d), _stream()), "s2m2_mlp_chain")
     return out
 
 

@@ -59,6 +59,24 @@ def make():
             return out
         return y.contiguous()
 
+    def mlp_chain_supported(C, dtype):
+        return C in (128, 256)
+
+    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5):
+        t, ys = x.float(), []
+        for s, (w, b, act, wsum) in enumerate(stages):
+            a = F.layer_norm(t, (t.shape[-1],), eps=ln_eps) if wsum is not None else t
+            if wsum is not None:
+                assert torch.allclose(wsum, w.float().sum(1), atol=1e-4)
+            y = ACTS[act](F.linear(a, w.float(), b))
+            if s == res_stage:
+                y = y + res.float()
+            if carry and s == 2:
+                y = y + ys[0]
+            ys.append(y)
+            t = y
+        return t.to(x.dtype)
+
     def layernorm(x, out=None):
         return F.layer_norm(x.float(), (x.shape[-1],)).to(x.dtype)
 
@@ -143,6 +161,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported):
         setattr(ns, f.__name__, f)
     return ns

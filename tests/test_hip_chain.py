@@ -1,0 +1,115 @@
+"""GPU parity of K9 (s2m2_mlp_chain: chains of 1x1 layers with the row tile resident in LDS) against a plain PyTorch fp32
+reference of the same layers, rounding every stage output to the I/O dtype where the kernel does, and against the separate
+K5/K6 launches it replaces (reference attentions.py:311-321,347-355 -- proj + residual + pre-LN FFN; :269-275 -- 1x1 branch).
+
+Tolerances: fp32 -- exact-fp32 MFMA chain vs torch's summation order through up to three layers: 3e-4 absolute on O(1) values.
+fp16 -- every stage output is rounded to fp16 (rel 2^-11) and feeds the next GEMM: 1.5e-2 absolute on O(1-4) values."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from s2m2_amd import pack
+
+pytestmark = pytest.mark.gpu
+
+ACT = {0: lambda t: t, 1: F.gelu, 2: F.relu}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from s2m2_amd import hip as h
+    h.load()
+    return h
+
+
+def _make(C, nst, dtype, ln_stage, acts, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    raw, packed = [], []
+    for s in range(nst):
+        w = (torch.randn(C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+        b = torch.randn(C, device="cuda", generator=g) * 0.5 if s != 1 else None
+        wp = pack.pack_conv(w, dtype)
+        raw.append((w.reshape(C, C).float(), b, acts[s], s == ln_stage))
+        packed.append((wp, None if b is None else pack.pack_bias(b, C), acts[s], wp.float().sum(1).contiguous() if s == ln_stage else None))
+    return raw, packed
+
+
+def _ref(x, raw, res, res_stage, carry, dtype):
+    t, ys = x.float(), []
+    for s, (w, b, act, ln) in enumerate(raw):
+        a = F.layer_norm(t, (t.shape[-1],)) if ln else t
+        y = ACT[act](F.linear(a, w, b)).to(dtype).float()
+        if s == res_stage:
+            y = (y + res.float()).to(dtype).float()
+        if carry and s == 2:
+            y = (y + ys[0]).to(dtype).float()
+        ys.append(y)
+        t = y
+    return t
+
+
+CASES = [  # C, dtype, rows-shape, nstage, ln_stage, acts, res_stage, carry
+    (128, torch.float16, (2, 50, 61), 3, 1, (0, 1, 0), 0, True),          # proj + residual + pre-LN FFN
+    (256, torch.float16, (2, 32, 38), 3, 1, (0, 1, 0), 0, True),
+    (256, torch.float16, (1, 1, 1), 3, 1, (0, 1, 0), 0, True),
+    (128, torch.float16, (1, 37, 41), 2, -1, (2, 0), -1, False),          # ConvBlock2D 1x1 branch
+    (256, torch.float16, (1, 16, 19), 2, -1, (2, 0), -1, False),
+    (128, torch.float16, (3, 7, 9), 1, 0, (1,), 0, False),
+    (128, torch.float16, (1, 9, 30), 2, 0, (1, 0), 1, False),             # residual on the last stage
+    (384, torch.float16, (2, 16, 19), 3, 1, (0, 1, 0), 0, True),
+    (512, torch.float16, (2, 16, 19), 3, 1, (0, 1, 0), 0, True),
+    (512, torch.float16, (1, 5, 7), 2, -1, (2, 0), -1, False),
+    (128, torch.float32, (2, 20, 31), 3, 1, (0, 1, 0), 0, True),
+    (256, torch.float32, (2, 16, 19), 3, 1, (0, 1, 0), 0, True),
+    (256, torch.float32, (1, 6, 11), 2, -1, (2, 0), -1, False),
+    (128, torch.float32, (1, 9, 30), 2, 0, (1, 0), 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"C{c[0]}-{'h' if c[1] == torch.float16 else 'f'}-{'x'.join(map(str, c[2]))}-n{c[3]}")
+def test_chain_vs_torch(hip, case):
+    C, dtype, shp, nst, ln_stage, acts, res_stage, carry = case
+    assert hip.mlp_chain_supported(C, dtype)
+    g = torch.Generator(device="cuda").manual_seed(C + nst)
+    x = torch.randn(*shp, C, device="cuda", generator=g).to(dtype)
+    res = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 1).to(dtype) if res_stage >= 0 else None
+    raw, packed = _make(C, nst, dtype, ln_stage, acts, 7 * C + nst)
+    y = hip.mlp_chain(x, packed, res=res, res_stage=res_stage, carry=carry)
+    ref = _ref(x, raw, res, res_stage, carry, dtype)
+    assert y.shape == x.shape and y.dtype == dtype
+    tol = 3e-4 if dtype == torch.float32 else 1.5e-2
+    assert float((y.float() - ref).abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_chain_matches_separate_launches_and_strided_rows(hip, dtype):
+    """the launches K9 replaces: K5 proj with EPI_ADD, K5 pre-LN FFN layer with GELU, K5 with EPI_ADD -- on rows that are a
+    channel slice of a wider tensor (row stride 3C, like the q/k/v views)"""
+    C, shp = 128, (2, 24, 40)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    wide = torch.randn(*shp, 3 * C, device="cuda", generator=g).to(dtype)
+    o = wide[..., C:2 * C]
+    z = torch.randn(*shp, C, device="cuda", generator=g).to(dtype)
+    raw, st = _make(C, 3, dtype, 1, (0, 1, 0), 11)
+    y = hip.mlp_chain(o, st, res=z, res_stage=0, carry=True)
+    z1 = hip.conv2d([o.contiguous()], st[0][0], st[0][1], 1, 1, C, epi=hip.EPI_ADD, aux0=z)
+    h = hip.conv2d([z1], st[1][0], st[1][1], 1, 1, C, act=hip.ACT_GELU, ln_wsum=st[1][3])
+    y2 = hip.conv2d([h], st[2][0], st[2][1], 1, 1, C, epi=hip.EPI_ADD, aux0=z1)
+    assert float((y.float() - y2.float()).abs().max()) < (1e-4 if dtype == torch.float32 else 1.5e-2)
+
+
+def test_chain_rejects_bad_arguments(hip):
+    x = torch.randn(4, 192, device="cuda").half()
+    w = torch.randn(192, 192, device="cuda").half()
+    assert not hip.mlp_chain_supported(192, torch.float16)
+    assert not hip.mlp_chain_supported(512, torch.float32)
+    with pytest.raises(RuntimeError, match="not supported"):
+        hip.mlp_chain(x, [(w, None, 0, None)])
+    x = torch.randn(4, 128, device="cuda").half()
+    w = torch.randn(128, 128, device="cuda").half()
+    with pytest.raises(RuntimeError, match="carry"):
+        hip.mlp_chain(x, [(w, None, 0, None), (w, None, 0, None)], carry=True)
+    with pytest.raises(RuntimeError, match="act"):
+        hip.mlp_chain(x, [(w, None, 3, None)])

@@ -29,6 +29,12 @@ SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
     ("1/8 3x3 128->128", 1, 128, 152, 128, 128, 3, 3),
     ("1/16 3x3 256->256", 1, 64, 76, 256, 256, 3, 3),
     ("1/32 1x1 256->256", 1, 32, 38, 256, 256, 1, 1),
+    ("1/32 1x1 256->256 x2", 2, 32, 38, 256, 256, 1, 1),
+    ("1/32 1x1 256->768 x2", 2, 32, 38, 256, 768, 1, 1),
+    ("1/16 1x1 256->256 x2", 2, 64, 76, 256, 256, 1, 1),
+    ("1/16 1x1 512->768 x2", 2, 64, 76, 512, 768, 1, 1),
+    ("1/8 1x1 128->128 x2", 2, 128, 152, 128, 128, 1, 1),
+    ("1/8 1x1 256->384 x2", 2, 128, 152, 256, 384, 1, 1),
     ("1/2 3x3 128->128", 1, 512, 608, 128, 128, 3, 3),
     ("1/2 3x3 128->64", 1, 512, 608, 128, 64, 3, 3),
     ("1/1 3x3 48->48", 1, 1024, 1216, 48, 48, 3, 3),
@@ -39,8 +45,11 @@ SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
     for name, N, H, W, ci, co, kh, kw in SHAPES:
+        if a.only and a.only not in name:
+            continue
         x = torch.randn(N, H, W, ci, device="cuda").half()
         w = (torch.randn(co, ci, kh, kw, device="cuda") / math.sqrt(ci * kh * kw)).half()
         b = torch.randn(co, device="cuda")
@@ -52,7 +61,7 @@ def main():
         t_ref = timeit(lambda: F.gelu(F.conv2d(xn, wcl, bh, padding=(kh // 2, kw // 2))), a.iters)
         line = f"{name:24s} torch conv+gelu {t_ref:8.1f} us ({fl / t_ref / 1e6:6.1f} TF/s) |"
         wk = pack.pack_conv(w, torch.float16, korder=1) if ci % 32 == 0 else None
-        for tile in ((6, 20) if kh * kw == 1 else (13, 19, 23)):
+        for tile in ((6, 2, 16, 17, 22, 20) if kh * kw == 1 else (13, 19, 23)):
             t = timeit(lambda: hip.conv2d([x], wp, bp, kh, kw, wp.shape[0], act=hip.ACT_GELU, tile=tile), a.iters)
             line += f" t{tile} {t:8.1f} us ({fl / t / 1e6:6.1f})"
             if wk is not None and kw > 1 and tile < 12 and False:
