@@ -10,13 +10,16 @@
 //   * all weights of the chain are ONE stream of [C couts x 64 bytes of K] chunks: D = 4 chunks are always in flight in
 //     registers (global -> VGPR -> LDS double buffer), and the stream runs across stage boundaries, so the only exposed
 //     memory latency is the first chunk of the first stage;
-//   * MFMA roles as in K5 (D[cout][row]: a lane owns a row), 4 waves x (BM rows x C/4 couts);
+//   * MFMA roles as in K5 (D[cout][row]: a lane owns a row), NW waves x (BM rows x C/NW couts); long row counts run 64-row
+//     tiles, short ones (the 1/16 and 1/32 levels: a few thousand rows on 256 CUs) 32-row tiles so that more CUs take part
+//     and the per-wave epilogue (GELU on BM*C/NW/64 values per lane, nothing to overlap with at one block per CU) stays short;
 //   * pre-LayerNorm of a stage input = row statistics from the A fragments + rowsum(W) correction (epilogue.h);
 //   * residuals: `res` (global rows) is added to the output of stage res_stage with coalesced loads issued before the stage's
 //     K loop; `carry` adds the output of stage 0 (still in the other LDS buffer) to the last stage of a 3-stage chain.
 // Every intermediate is rounded to the I/O dtype exactly where the separate launches round it (tile in LDS instead of HBM).
 #include "common.h"
 #include "epilogue.h"
+#include <stdlib.h>
 
 namespace s2m2 {
 
@@ -34,24 +37,29 @@ struct ChainArgs {
     const void* zero;
 };
 
-template <typename T, int C_, int BM_, int NST_>
+template <typename T, int C_, int BM_, int NST_, int NW_>
 struct ChainCfg {
-    static constexpr int C = C_, BM = BM_, NST = NST_, NT = 256, D = 4;
+    static constexpr int C = C_, BM = BM_, NST = NST_, NW = NW_, NT = 64 * NW_;
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int BK = 4 * VEC;                    // K elements per chunk: 64 bytes per weight row
     static constexpr int RS = BK + VEC;                   // weight tile row stride in LDS (80 bytes: conflict-free b128 reads)
     static constexpr int KSTEPS = BK / 16;
     static constexpr int ARS = C + VEC;                   // activation tile row stride (16 bytes of padding)
     static constexpr int CRS = ARS;                       // (name used by stage_tile)
-    static constexpr int WM = BM, MT = BM / 32, WN = C / 4, NTL = WN / 32;
+    static constexpr int WM = BM, MT = BM / 32, WN = C / NW, NTL = WN / 32;   // every wave: all BM rows x C / NW couts
     static constexpr int CPS = C / BK;                    // chunks per stage
-    static constexpr int B_IT = C / 64;                   // 16-byte weight pieces per thread and chunk
+#ifndef S2M2_CHAIN_DEPTH8
+#define S2M2_CHAIN_DEPTH8 1
+#endif
+    static constexpr int D = (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;   // weight chunks in flight
+    static constexpr int WROWS = NT / 4;                  // weight rows covered by one pass of the loader threads (4 pieces per row)
+    static constexpr int B_IT = C / WROWS;                // 16-byte weight pieces per thread and chunk
     static constexpr int PPR = C / VEC;                   // 16-byte pieces per activation row
     static constexpr int X_IT = BM * PPR / NT;            // activation pieces per thread
     static constexpr size_t A_BYTES = (size_t)BM * ARS * sizeof(T);
     static constexpr size_t W_BYTES = (size_t)C * RS * sizeof(T);
     static constexpr size_t LDS_BYTES = 2 * A_BYTES + 2 * W_BYTES;
-    static_assert(C % 128 == 0 && CPS % D == 0 && (BM * PPR) % NT == 0 && BM % 32 == 0, "unsupported chain tile");
+    static_assert(C % 128 == 0 && CPS % D == 0 && (BM * PPR) % NT == 0 && BM % 32 == 0 && WN % 32 == 0 && C % WROWS == 0, "unsupported chain tile");
     static_assert(LDS_BYTES <= 160 * 1024, "chain tile does not fit the 160 KB LDS");
 };
 
@@ -74,12 +82,12 @@ struct ChainStream {
         const T* wp = reinterpret_cast<const T*>((const char*)w0 + ((st >= 1 ? d1 : 0) + (st >= 2 ? d2 : 0)));
         const T* q = wp + off + ch * CFG::BK;
 #pragma unroll
-        for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + (size_t)it * 64 * CFG::C);
+        for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + (size_t)it * CFG::WROWS * CFG::C);
     }
     __device__ __forceinline__ void stash(T* wb, int SLOT) const {
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it)
-            *reinterpret_cast<raw16_t*>(wb + (size_t)(lrow + 64 * it) * CFG::RS + pc * CFG::VEC) = r[SLOT][it];
+            *reinterpret_cast<raw16_t*>(wb + (size_t)(lrow + CFG::WROWS * it) * CFG::RS + pc * CFG::VEC) = r[SLOT][it];
     }
 };
 
@@ -103,7 +111,7 @@ struct ChainStage {
         T* Ain = (S & 1) ? A1 : A0;
         T* Aother = (S & 1) ? A0 : A1;
         T* Aout = LAST ? Ain : Aother;
-        const int lane = tid & 63, wn = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+        const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
         const bool ln_on = p.wsum[S] != nullptr;
         const bool res_on = p.res_stage == S;
 
@@ -247,10 +255,9 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
         const T* src = m < p.rows ? static_cast<const T*>(p.x) + m * p.x_stride + pcx * VEC : static_cast<const T*>(p.zero);
         xr[it] = global_load16(src);
     }
-    if (1 < CFG::NST * CFG::CPS) ws.fetch(1, 1);
-    if (2 < CFG::NST * CFG::CPS) ws.fetch(2, 2);
-    if (3 < CFG::NST * CFG::CPS) ws.fetch(3, 3);
-    static_assert(D == 4, "prologue written for 4 chunks in flight");
+#pragma unroll
+    for (int f = 1; f < D; ++f)
+        if (f < CFG::NST * CFG::CPS) ws.fetch(f, f);
     ws.stash(W0, 0);
 #pragma unroll
     for (int it = 0; it < CFG::X_IT; ++it) {
@@ -272,9 +279,9 @@ static const void* chain_zero_page() {
     return z;
 }
 
-template <typename T, int C, int BM, int NST>
+template <typename T, int C, int BM, int NST, int NW>
 static int launch_chain(const ChainArgs& a, hipStream_t st) {
-    using CFG = ChainCfg<T, C, BM, NST>;
+    using CFG = ChainCfg<T, C, BM, NST, NW>;
     auto kern = mlp_chain_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -287,11 +294,11 @@ static int launch_chain(const ChainArgs& a, hipStream_t st) {
     return check_launch("mlp_chain");
 }
 
-template <typename T, int C, int BM>
+template <typename T, int C, int BM, int NW>
 static int launch_chain_n(const ChainArgs& a, int nst, hipStream_t st) {
-    if (nst == 1) return launch_chain<T, C, BM, 1>(a, st);
-    if (nst == 2) return launch_chain<T, C, BM, 2>(a, st);
-    return launch_chain<T, C, BM, 3>(a, st);
+    if (nst == 1) return launch_chain<T, C, BM, 1, NW>(a, st);
+    if (nst == 2) return launch_chain<T, C, BM, 2, NW>(a, st);
+    return launch_chain<T, C, BM, 3, NW>(a, st);
 }
 
 }  // namespace s2m2
@@ -334,14 +341,18 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     a.zero = chain_zero_page();
     S2M2_REQUIRE(a.zero, "mlp_chain: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    static const char* force = getenv("S2M2_CHAIN_CFG");          // tuning only: "s" (32-row tiles) / "m" (64-row tiles)
+    char cfg = d->rows <= 8192 ? 's' : 'm';                       // at most one 32-row tile per CU: short tiles, more CUs busy (measured: tools/chainbench.py)
+    if (force && *force) cfg = *force;
     if (d->dtype == S2M2_F16) {
         switch (d->C) {
-            case 128: return launch_chain_n<half_t, 128, 64>(a, d->nstage, st);
-            case 256: return launch_chain_n<half_t, 256, 64>(a, d->nstage, st);
-            case 384: return launch_chain_n<half_t, 384, 32>(a, d->nstage, st);
-            default: return launch_chain_n<half_t, 512, 32>(a, d->nstage, st);
+            case 128: return cfg == 's' ? launch_chain_n<half_t, 128, 32, 4>(a, d->nstage, st) : launch_chain_n<half_t, 128, 64, 4>(a, d->nstage, st);
+            case 256: return cfg == 's' ? launch_chain_n<half_t, 256, 32, 8>(a, d->nstage, st)
+                                                : launch_chain_n<half_t, 256, 64, 8>(a, d->nstage, st);
+            case 384: return launch_chain_n<half_t, 384, 32, 4>(a, d->nstage, st);
+            default: return launch_chain_n<half_t, 512, 32, 8>(a, d->nstage, st);
         }
     }
-    if (d->C == 128) return launch_chain_n<float, 128, 32>(a, d->nstage, st);
-    return launch_chain_n<float, 256, 32>(a, d->nstage, st);
+    if (d->C == 128) return launch_chain_n<float, 128, 32, 4>(a, d->nstage, st);
+    return launch_chain_n<float, 256, 32, 8>(a, d->nstage, st);
 }

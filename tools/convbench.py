@@ -11,11 +11,14 @@ import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from s2m2_amd import hip, pack  # noqa: E402
-from tools.kbench import timeit_graph  # noqa: E402
+from tools.kbench import timeit_graph, timeit_graph_cold  # noqa: E402
+
+
+COLD = False
 
 
 def timeit(fn, iters):
-    return timeit_graph(fn, 20, 3)
+    return timeit_graph_cold(fn, 20, 3) if COLD else timeit_graph(fn, 20, 3)
 
 SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
     ("1/4 3x3 128->128", 1, 256, 304, 128, 128, 3, 3),
@@ -46,7 +49,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--only", default="")
+    ap.add_argument("--cold", action="store_true", help="evict the L2s before every call (the state inside the pipeline)")
+    ap.add_argument("--tiles", default="")
     a = ap.parse_args()
+    global COLD
+    COLD = a.cold
     for name, N, H, W, ci, co, kh, kw in SHAPES:
         if a.only and a.only not in name:
             continue
@@ -61,7 +68,7 @@ def main():
         t_ref = timeit(lambda: F.gelu(F.conv2d(xn, wcl, bh, padding=(kh // 2, kw // 2))), a.iters)
         line = f"{name:24s} torch conv+gelu {t_ref:8.1f} us ({fl / t_ref / 1e6:6.1f} TF/s) |"
         wk = pack.pack_conv(w, torch.float16, korder=1) if ci % 32 == 0 else None
-        for tile in ((6, 2, 16, 17, 22, 20) if kh * kw == 1 else (13, 19, 23)):
+        for tile in (tuple(int(t) for t in a.tiles.split(',')) if a.tiles else ((6, 2, 16, 17, 22, 20) if kh * kw == 1 else (13, 19, 23))):
             t = timeit(lambda: hip.conv2d([x], wp, bp, kh, kw, wp.shape[0], act=hip.ACT_GELU, tile=tile), a.iters)
             line += f" t{tile} {t:8.1f} us ({fl / t / 1e6:6.1f})"
             if wk is not None and kw > 1 and tile < 12 and False:

@@ -42,6 +42,16 @@ def timeit_graph(fn, iters=20, reps=5):
     return a.elapsed_time(b) * 1e3 / (iters * reps)
 
 
+def timeit_graph_cold(fn, iters=20, reps=5, mb=64):
+    """like timeit_graph, but every call is preceded by a `mb` MiB fill that evicts the 8 x 4 MiB L2s (the 256 MiB Infinity Cache
+    keeps the operands: that is the state a layer finds inside the real pipeline, where ~30 other layers ran since its last use);
+    returns (fill + fn) - fill."""
+    buf = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
+    t_f = timeit_graph(lambda: buf.zero_(), iters, reps)
+    t = timeit_graph(lambda: (buf.zero_(), fn()), iters, reps)
+    return t - t_f
+
+
 def timeit(fn, iters, warmup=5):
     for _ in range(warmup):
         fn()
