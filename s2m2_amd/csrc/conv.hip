@@ -662,8 +662,9 @@ __global__ __launch_bounds__(256) void conv_igemm2_kernel(ConvArgs p) {
 // Input traffic through the memory pipe drops from KH*KW x 16 KB to 26-30 KB per chunk; the weight tile (BN x 128 bytes per tap)
 // is double buffered exactly as in v1.  K order of the loop: (chunk, ky, kx) -- the packed weight stays (Cout, KH, KW, Cin).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BN_, int NWAVES_ = 4, int WGM_ = 2>
+template <typename T, int BN_, int NWAVES_ = 4, int WGM_ = 2, int DW_ = 1>
 struct ConvCfgH {
+    static constexpr int DW = DW_;                       // weight tiles in flight (register ring): short grids (one block per CU) need > 1
     static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = WGM_, WGN = NWAVES_ / WGM_;
     static constexpr int NT = 64 * NWAVES_;              // threads per block (4 or 8 waves)
     static constexpr int VEC = 16 / sizeof(T);
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
     const int st0 = p.src_stride[0], st1 = p.src_stride[1], st2 = p.src_stride[2], st3 = p.src_stride[3];
     const int c0n = p.src_c[0], c1n = c0n + p.src_c[1], c2n = c1n + p.src_c[2];
 
-    raw16_t ra[CFG::A_IT], rb[CFG::B_IT];
+    raw16_t ra[CFG::A_IT], rb[CFG::DW][CFG::B_IT];
     auto fetch_a = [&](int chunk) __attribute__((always_inline)) {            // halo tile of one channel chunk -> registers
         const int kc = chunk * BK + pc * VEC;
         const bool cvalid = kc < p.Cin;
@@ -768,22 +769,22 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
             if (hp < CFG::MAXHALO) *reinterpret_cast<raw16_t*>(Ah + (size_t)hp * RS + pc * VEC) = ra[it];
         }
     };
-    auto fetch_b = [&](int kt) __attribute__((always_inline)) {               // weight tile of K tile kt = (chunk, tap)
+    auto fetch_b = [&](int kt, int slot) __attribute__((always_inline)) {     // weight tile of K tile kt = (chunk, tap)
         const int chunk = kt / ntap, tap = kt - chunk * ntap;
         const bool cvalid = chunk * BK + pc * VEC < p.Cin;
         const int koff = tap * p.Cin + chunk * BK;
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
             const T* src = (cvalid && wrow[it]) ? wrow[it] + koff : zp;
-            rb[it] = global_load16(src);
+            rb[slot][it] = global_load16(src);
         }
     };
-    auto stash_b = [&](int buf) __attribute__((always_inline)) {
+    auto stash_b = [&](int buf, int slot) __attribute__((always_inline)) {
         T* b = Bs + (size_t)buf * BN * RS;
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
             const int br = (tid >> 3) + CFG::RPI * it;
-            if (br < BN) *reinterpret_cast<raw16_t*>(b + (size_t)br * RS + pc * VEC) = rb[it];
+            if (br < BN) *reinterpret_cast<raw16_t*>(b + (size_t)br * RS + pc * VEC) = rb[slot][it];
         }
     };
 
@@ -797,42 +798,52 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // weight tiles are requested DW ahead into a ring of register slots (slot = tile % DW, static after unrolling): with one block
+    // per CU (the 1/8 .. 1/32 levels) nothing else hides the memory latency of the next tile, and the K loop is 18-36 tiles long
+    constexpr int DW = CFG::DW;
     fetch_a(0);
-    fetch_b(0);
+#pragma unroll
+    for (int f = 0; f < DW; ++f)
+        if (f < nkt) fetch_b(f, f);
     stash_a();
-    stash_b(0);
+    stash_b(0, 0);
     __syncthreads();
     int tap = 0, chunk = 0;
 #pragma unroll 1
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nkt;
-        const bool last_tap = tap == ntap - 1;
-        const bool next_chunk = last_tap && chunk + 1 < nchunk;
-        if (more) fetch_b(kt + 1);                                // in flight under the MFMAs
-        if (tap == 0 && chunk + 1 < nchunk) fetch_a(chunk + 1);   // next halo tile: requested now, parked in registers until the last tap
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-        const T* a = Ah + (size_t)((wm * CFG::MT + ky) * HW_ + l31 + kx) * RS + hi * 8;
-        const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + l31) * RS + hi * 8;
+    for (int kt0 = 0; kt0 < nkt; kt0 += DW) {
 #pragma unroll
-        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-            Frag<T> xf[CFG::MT], wf[CFG::NTL];
+        for (int f = 0; f < DW; ++f) {
+            const int kt = kt0 + f;
+            if (kt >= nkt) break;
+            const int buf = kt & 1;
+            const bool more = kt + 1 < nkt;
+            const bool last_tap = tap == ntap - 1;
+            const bool next_chunk = last_tap && chunk + 1 < nchunk;
+            if (tap == 0 && chunk + 1 < nchunk) fetch_a(chunk + 1);   // next halo tile: requested now, parked in registers until the last tap
+            if (kt + DW < nkt) fetch_b(kt + DW, f);                   // slot f was stashed one tile ago: refill
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const T* a = Ah + (size_t)((wm * CFG::MT + ky) * HW_ + l31 + kx) * RS + hi * 8;
+            const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + l31) * RS + hi * 8;
 #pragma unroll
-            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * HW_ * RS + kk * 16);
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                Frag<T> xf[CFG::MT], wf[CFG::NTL];
 #pragma unroll
-            for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], b + (size_t)j * 32 * RS + kk * 16);
+                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * HW_ * RS + kk * 16);
 #pragma unroll
-            for (int i = 0; i < CFG::MT; ++i)
+                for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], b + (size_t)j * 32 * RS + kk * 16);
 #pragma unroll
-                for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
+                for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
+            }
+            if (more) stash_b(buf ^ 1, (f + 1) % DW);
+            if (next_chunk) {
+                __syncthreads();                                  // every wave is done with this chunk's halo tile
+                stash_a();
+            }
+            __syncthreads();
+            if (last_tap) { tap = 0; ++chunk; } else ++tap;
         }
-        if (more) stash_b(buf ^ 1);
-        if (next_chunk) {
-            __syncthreads();                                      // every wave is done with this chunk's halo tile
-            stash_a();
-        }
-        __syncthreads();
-        if (last_tap) { tap = 0; ++chunk; } else ++tap;
     }
 
     // ---- epilogues: staging rows r = patch row * 32 + column (the same wm*64 + i*32 + lane map as the linear kernels)
@@ -1036,9 +1047,9 @@ static int launch_conv2(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
-template <typename T, int BN, int NWAVES = 4, int WGM = 2>
+template <typename T, int BN, int NWAVES = 4, int WGM = 2, int DW = 1>
 static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
-    using CFG = ConvCfgH<T, BN, NWAVES, WGM>;
+    using CFG = ConvCfgH<T, BN, NWAVES, WGM, DW>;
     auto kern = conv_halo_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1085,7 +1096,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         const int Ktot = a.KH * a.KW * a.Cin;
         if (a.KH * a.KW > 1 && a.KH <= 3 && a.KW <= 3 && a.stride == 1 && !a.shuffle2 && !a.korder) {
             static const bool no8 = getenv("S2M2_CONV_NO_HALO8") != nullptr;    // A/B switch
-            tile = (a.Cout >= 128 && !no8) ? (M >= 30000 ? 19 : 23) : 13;
+            tile = (a.Cout >= 128 && !no8) ? (M >= 30000 ? 26 : 24) : 13;   // 8-wave tiles with 2 / 4 weight tiles in flight
         }      // spatial kernels: halo tile; 8 waves x 128 couts when there is enough work
         else if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
         else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 20;  // 128x128, 64-byte K rows, 8 waves
@@ -1124,6 +1135,9 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         case 21: return launch_conv<T, 128, 128, 2, 8, 1, 8>(a, st);   // 128x128, 128-byte K rows, 8 waves
         case 22: return launch_conv<T, 64, 128, 2, 4, 1, 8>(a, st);    // 64x128, 64-byte K rows, 8 waves (32 px x 32 couts each)
         case 23: return launch_conv_halo<T, 64, 8, 4>(a, st);      // v3 halo tile, 64 couts, 8 waves (one patch row x 32 couts each)
+        case 24: return launch_conv_halo<T, 64, 8, 4, 4>(a, st);   // t23 with 4 weight tiles in flight (short grids)
+        case 25: return launch_conv_halo<T, 64, 4, 2, 4>(a, st);   // t13 with 4 weight tiles in flight
+        case 26: return launch_conv_halo<T, 128, 8, 2, 2>(a, st);  // t19 with 2 weight tiles in flight
         default: return set_error("conv2d: unknown tile id %d", tile);
     }
 }

@@ -31,6 +31,8 @@ SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
     ("1/4 lin 128->384 x2", 2, 256, 304, 128, 384, 1, 1),
     ("1/8 3x3 128->128", 1, 128, 152, 128, 128, 3, 3),
     ("1/16 3x3 256->256", 1, 64, 76, 256, 256, 3, 3),
+    ("1/16 3x3 256->256 x2", 2, 64, 76, 256, 256, 3, 3),
+    ("1/8 3x3 128->128 x2", 2, 128, 152, 128, 128, 3, 3),
     ("1/32 1x1 256->256", 1, 32, 38, 256, 256, 1, 1),
     ("1/32 1x1 256->256 x2", 2, 32, 38, 256, 256, 1, 1),
     ("1/32 1x1 256->768 x2", 2, 32, 38, 256, 768, 1, 1),
