@@ -160,7 +160,13 @@ class Engine:
         return self.cconv(self.std(p + ".1"), [hip.resample2x(x, 0)])
 
     def up(self, p: str, x: Tensor) -> Tensor:
-        return self.cconv(self.std(p + ".1"), [hip.resample2x(x, 1)])
+        """nn.Upsample(bilinear x2) -> Conv2d 1x1 (unet.py:32-37, stacked_MRT.py:29-34).  A 1x1 layer commutes with the bilinear
+        resampling (per-pixel interpolation weights sum to 1, so the bias passes through too): the GEMM runs on the coarse grid
+        -- a quarter of the pixels -- and K7 resamples Cout channels instead of Cin."""
+        spec = self.std(p + ".1")
+        if spec[2] == 1 and spec[3] == 1:
+            return hip.resample2x(self.cconv(spec, [x]), 1)
+        return self.cconv(spec, [hip.resample2x(x, 1)])
 
     def conv_block(self, p: str, z: Tensor) -> Tensor:
         """ConvBlock2D (attentions.py:255-281): conv3-GELU-conv3 + conv1-ReLU-conv1."""
