@@ -49,6 +49,19 @@ __device__ __forceinline__ raw16_t global_load16(const void* p) {
     return *(const __attribute__((address_space(1))) raw16_t*)(p);
 }
 
+// Asynchronous 16-byte global load the compiler does NOT track: no automatic s_waitcnt.  The compiler's own vmcnt bookkeeping is
+// conservative across loop back edges and uniform branches -- in a register ring of loads it waits for the previous iteration's
+// load before it issues the next one, which turns an N-deep prefetch into depth 1.  Protocol for users:
+//   * every load issued with global_load16_async is consumed only after wait_vmcnt<N>() (N = loads issued after it that may still
+//     be in flight: loads return in order) followed by settle() on its register;
+//   * every such load IS consumed that way (or drained with wait_vmcnt<0>() + settle()): a destination register whose value is
+//     never used is free for the allocator while the load is still in flight.
+__device__ __forceinline__ void global_load16_async(raw16_t& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void settle(raw16_t& v) { asm volatile("" : "+v"(v)); }
+
 // 16-byte vector of T (8 halfs / 4 floats)
 template <typename T> struct Vec16;
 template <> struct alignas(16) Vec16<half_t> { half_t v[8]; };

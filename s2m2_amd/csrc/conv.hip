@@ -798,29 +798,23 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // weight tiles are requested DW ahead into a ring of register slots (slot = tile % DW, static after unrolling): with one block
-    // per CU (the 1/8 .. 1/32 levels) nothing else hides the memory latency of the next tile, and the K loop is 18-36 tiles long
     constexpr int DW = CFG::DW;
-    fetch_a(0);
-#pragma unroll
-    for (int f = 0; f < DW; ++f)
-        if (f < nkt) fetch_b(f, f);
-    stash_a();
-    stash_b(0, 0);
-    __syncthreads();
-    int tap = 0, chunk = 0;
+    if constexpr (DW == 1) {
+        // one weight tile ahead, compiler-tracked loads (the small 4-wave tiles: several blocks per CU cover each other's latency)
+        fetch_a(0);
+        fetch_b(0, 0);
+        stash_a();
+        stash_b(0, 0);
+        __syncthreads();
+        int tap = 0, chunk = 0;
 #pragma unroll 1
-    for (int kt0 = 0; kt0 < nkt; kt0 += DW) {
-#pragma unroll
-        for (int f = 0; f < DW; ++f) {
-            const int kt = kt0 + f;
-            if (kt >= nkt) break;
+        for (int kt = 0; kt < nkt; ++kt) {
             const int buf = kt & 1;
             const bool more = kt + 1 < nkt;
             const bool last_tap = tap == ntap - 1;
             const bool next_chunk = last_tap && chunk + 1 < nchunk;
+            if (more) fetch_b(kt + 1, 0);                             // in flight under the MFMAs
             if (tap == 0 && chunk + 1 < nchunk) fetch_a(chunk + 1);   // next halo tile: requested now, parked in registers until the last tap
-            if (kt + DW < nkt) fetch_b(kt + DW, f);                   // slot f was stashed one tile ago: refill
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
             const T* a = Ah + (size_t)((wm * CFG::MT + ky) * HW_ + l31 + kx) * RS + hi * 8;
             const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + l31) * RS + hi * 8;
@@ -836,14 +830,120 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 #pragma unroll
                     for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
             }
-            if (more) stash_b(buf ^ 1, (f + 1) % DW);
+            if (more) stash_b(buf ^ 1, 0);
             if (next_chunk) {
-                __syncthreads();                                  // every wave is done with this chunk's halo tile
+                __syncthreads();                                      // every wave is done with this chunk's halo tile
                 stash_a();
             }
             __syncthreads();
             if (last_tap) { tap = 0; ++chunk; } else ++tap;
         }
+    } else {
+        // DW weight tiles in flight in a ring of register slots (slot = tile % DW, static after unrolling), all loads of the loop
+        // UNTRACKED (global_load16_async, common.h) with counted waits: every iteration issues exactly B_IT weight loads (tiles past
+        // the end read the zero page) and stashes exactly one tile, so "tile kt+1 has landed" is `vmcnt <= (DW-1)*B_IT` -- plus A_IT
+        // while the halo loads of the next chunk (issued at tap 0, consumed at the last tap) are younger than that tile.
+        constexpr int NB = (DW - 1) * CFG::B_IT;
+        int f_tap = 0, f_chunk = 0;                                   // K position of the next weight tile to request
+        auto fetch_b_async = [&](int slot) __attribute__((always_inline)) {
+            const bool cvalid = f_chunk < nchunk && f_chunk * BK + pc * VEC < p.Cin;
+            const int koff = f_tap * p.Cin + f_chunk * BK;
+#pragma unroll
+            for (int it = 0; it < CFG::B_IT; ++it) {
+                const T* src = (cvalid && wrow[it]) ? wrow[it] + koff : zp;
+                global_load16_async(rb[slot][it], src);
+            }
+            if (++f_tap == ntap) { f_tap = 0; ++f_chunk; }
+        };
+        auto stash_b_async = [&](int buf, int slot) __attribute__((always_inline)) {
+            T* b = Bs + (size_t)buf * BN * RS;
+#pragma unroll
+            for (int it = 0; it < CFG::B_IT; ++it) {
+                settle(rb[slot][it]);
+                const int br = (tid >> 3) + CFG::RPI * it;
+                if (br < BN) *reinterpret_cast<raw16_t*>(b + (size_t)br * RS + pc * VEC) = rb[slot][it];
+            }
+        };
+        auto fetch_a_async = [&](int chunk) __attribute__((always_inline)) {
+            const int kc = chunk * BK + pc * VEC;
+            const bool cvalid = kc < p.Cin;
+            const T* sp = s0;
+            unsigned ss = (unsigned)st0, c = (unsigned)kc;
+            if (p.nsrc > 1) {
+                const bool g0 = kc >= c0n, g1 = kc >= c1n, g2 = kc >= c2n;
+                const long long d1 = (const char*)s1 - (const char*)s0, d2 = (const char*)s2 - (const char*)s1, d3 = (const char*)s3 - (const char*)s2;
+                sp = reinterpret_cast<const T*>((const char*)s0 + ((g0 ? d1 : 0) + (g1 ? d2 : 0) + (g2 ? d3 : 0)));
+                ss = (unsigned)(st0 + (g0 ? st1 - st0 : 0) + (g1 ? st2 - st1 : 0) + (g2 ? st3 - st2 : 0));
+                c = (unsigned)(kc - ((g0 ? c0n : 0) + (g1 ? c1n - c0n : 0) + (g2 ? c2n - c1n : 0)));
+            }
+#pragma unroll
+            for (int it = 0; it < CFG::A_IT; ++it) {
+                const unsigned e = __umul24((unsigned)apix[it], ss) + c;
+                const T* src = (cvalid && apix[it] >= 0) ? sp + e : zp;
+                global_load16_async(ra[it], src);
+            }
+        };
+        auto stash_a_async = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < CFG::A_IT; ++it) {
+                settle(ra[it]);
+                const int hp = (tid >> 3) + CFG::RPI * it;
+                if (hp < CFG::MAXHALO) *reinterpret_cast<raw16_t*>(Ah + (size_t)hp * RS + pc * VEC) = ra[it];
+            }
+        };
+
+        wait_vmcnt<0>();                                              // (the tracked bias loads: keep the counts below exact)
+        fetch_a_async(0);
+#pragma unroll
+        for (int f = 0; f < DW; ++f) fetch_b_async(f);
+        wait_vmcnt<DW * CFG::B_IT>();
+        stash_a_async();
+        wait_vmcnt<NB>();
+        stash_b_async(0, 0);
+        __syncthreads();
+        int tap = 0, chunk = 0, ky = 0, kx = 0;
+#pragma unroll 1
+        for (int kt0 = 0; kt0 < nkt; kt0 += DW) {
+#pragma unroll
+            for (int f = 0; f < DW; ++f) {
+                const int kt = kt0 + f;
+                if (kt >= nkt) break;
+                const int buf = kt & 1;
+                const bool last_tap = tap == ntap - 1;
+                const bool has_next = chunk + 1 < nchunk;
+                if (tap == 0 && has_next) fetch_a_async(chunk + 1);   // next halo tile: parked in registers until the last tap
+                fetch_b_async(f);                                     // tile kt + DW into the slot stashed one tile ago
+                const T* a = Ah + (size_t)((wm * CFG::MT + ky) * HW_ + l31 + kx) * RS + hi * 8;
+                const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + l31) * RS + hi * 8;
+#pragma unroll
+                for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                    Frag<T> xf[CFG::MT], wf[CFG::NTL];
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * HW_ * RS + kk * 16);
+#pragma unroll
+                    for (int j = 0; j < CFG::NTL; ++j) load_frag(wf[j], b + (size_t)j * 32 * RS + kk * 16);
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
+                }
+                if (has_next && tap <= DW - 2) wait_vmcnt<NB + CFG::A_IT>();   // the halo loads of the next chunk are younger than tile kt+1
+                else wait_vmcnt<NB>();
+                stash_b_async(buf ^ 1, (f + 1) % DW);                 // (past the end: a zero tile into the idle buffer)
+                if (last_tap && has_next) {
+                    __syncthreads();                                  // every wave is done with this chunk's halo tile
+                    stash_a_async();                                  // older than every load still allowed in flight (ntap >= DW - 1)
+                }
+                __syncthreads();
+                if (last_tap) { tap = 0; ky = 0; kx = 0; ++chunk; }
+                else { ++tap; if (++kx == p.KW) { kx = 0; ++ky; } }
+            }
+        }
+        wait_vmcnt<0>();                                              // drain the zero-page tail requests before their registers are reused
+#pragma unroll
+        for (int f = 0; f < DW; ++f)
+#pragma unroll
+            for (int it = 0; it < CFG::B_IT; ++it) settle(rb[f][it]);
     }
 
     // ---- epilogues: staging rows r = patch row * 32 + column (the same wm*64 + i*32 + lane map as the linear kernels)
