@@ -56,10 +56,14 @@ __device__ __forceinline__ raw16_t global_load16(const void* p) {
 //     be in flight: loads return in order) followed by settle() on its register;
 //   * every such load IS consumed that way (or drained with wait_vmcnt<0>() + settle()): a destination register whose value is
 //     never used is free for the allocator while the load is still in flight.
+template <bool ASYNC = true>
 __device__ __forceinline__ void global_load16_async(raw16_t& dst, const void* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+    if constexpr (ASYNC) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));   // no "memory" clobber: it would pin every LDS access around it
+    else dst = global_load16(p);                                  // tracked: the counted waits become no-ops
 }
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N, bool ASYNC = true> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (ASYNC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));   // ordered against the loads / settle() by volatility alone
+}
 __device__ __forceinline__ void settle(raw16_t& v) { asm volatile("" : "+v"(v)); }
 
 // 16-byte vector of T (8 halfs / 4 floats)

@@ -27,6 +27,11 @@
 #endif
 #include "epilogue.h"
 
+// which K loops use untracked loads + counted waits (common.h): bit 0 the halo kernel (ring variants), bit 1 the v1 kernel
+#ifndef S2M2_ASYNC_LOADS
+#define S2M2_ASYNC_LOADS 0      // measured neutral end to end on MI355X (same-box A/B, profiles/r01/async_loads_ab.txt): tracked loads stay the default
+#endif
+
 namespace s2m2 {
 
 struct ConvArgs {
@@ -222,6 +227,7 @@ struct KCursor {
 //    the per-lane source is picked with masked telescoping sums over scalars.
 template <typename CFG, typename T>
 struct ConvLoader {
+    static constexpr bool V1A = (S2M2_ASYNC_LOADS & 2) != 0;
     static constexpr int VEC = CFG::VEC, BK = CFG::BK, RS = CFG::RS, BN = CFG::BN;
     int pc, lrow, Ktot;
     int apix[CFG::A_IT];                       // input pixel (n*H + y)*W + x of the window centre
@@ -289,27 +295,43 @@ struct ConvLoader {
         for (int it = 0; it < CFG::A_IT; ++it) {
             const unsigned e = __umul24((unsigned)(apix[it] + tapoff), ss) + c;      // pixel < 2^24, stride < 2^24, numel < 2^31
             const T* src = (tapmask[it] & tapbit) ? sp + e : zp;
-            ra[slot][it] = global_load16(src);
+            global_load16_async<V1A>(ra[slot][it], src);
         }
         const int koff = kt * BK;
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
             const T* src = (kvalid && wrow[it]) ? wrow[it] + koff : zp;
-            rb[slot][it] = global_load16(src);
+            global_load16_async<V1A>(rb[slot][it], src);
         }
         cur.template advance<BK>(p);
     }
 
-    __device__ __forceinline__ void stash(T* a, T* b, int slot) const {
+    // the loads of a K tile are untracked (common.h: global_load16_async): every fetch issues exactly A_IT + B_IT of them (tiles past
+    // the end of K read the zero page), so "the tile in `slot` has landed" = at most (NPF-1) younger tiles outstanding
+    static constexpr int LOADS_PER_TILE = CFG::A_IT + CFG::B_IT;
+    __device__ __forceinline__ void stash(T* a, T* b, int slot) {
+        wait_vmcnt<(CFG::NPF - 1) * LOADS_PER_TILE, V1A>();
 #pragma unroll
         for (int it = 0; it < CFG::A_IT; ++it) {
+            settle(ra[slot][it]);
             const int r = lrow + CFG::RPI * it;
             if (r < CFG::BM) *reinterpret_cast<raw16_t*>(a + (size_t)r * RS + pc * VEC) = ra[slot][it];
         }
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
+            settle(rb[slot][it]);
             const int r = lrow + CFG::RPI * it;
             if (r < BN) *reinterpret_cast<raw16_t*>(b + (size_t)r * RS + pc * VEC) = rb[slot][it];
+        }
+    }
+    __device__ __forceinline__ void drain() {                     // tail requests (zero page): land before their registers are reused
+        wait_vmcnt<0, V1A>();
+#pragma unroll
+        for (int f = 0; f < CFG::NPF; ++f) {
+#pragma unroll
+            for (int it = 0; it < CFG::A_IT; ++it) settle(ra[f][it]);
+#pragma unroll
+            for (int it = 0; it < CFG::B_IT; ++it) settle(rb[f][it]);
         }
     }
 };
@@ -352,8 +374,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     // layers (1x1, K <= NPF tiles) the whole K of the block is in flight at once -- one memory latency per block instead of one per tile
     constexpr int NPF = CFG::NPF;
 #pragma unroll
-    for (int f = 0; f < NPF; ++f)
-        if (f < nkt) ld.fetch(p, f, f);
+    for (int f = 0; f < NPF; ++f) ld.fetch(p, f, f);
     ld.stash(As, Bs, 0);
     __syncthreads();
     if constexpr (LN && sizeof(T) == 4) {
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
             const int kt = kt0 + f;
             if (kt >= nkt_run) break;
             const int buf = kt & 1;
-            if (kt + NPF < nkt && !(S2M2_CONV_DBG & 1)) ld.fetch(p, kt + NPF, f);     // slot f was stashed one iteration ago: refill
+            ld.fetch(p, kt + NPF, f);                             // slot f was stashed one iteration ago: refill (zero page past the end)
             const T* a = As + (size_t)buf * BM * RS + (size_t)(wm * CFG::WM + (lane & 31)) * RS + (lane >> 5) * 8;
             const T* b = Bs + (size_t)buf * BN * RS + (size_t)(wn * CFG::WN + (lane & 31)) * RS + (lane >> 5) * 8;
 #pragma unroll
@@ -393,11 +414,11 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
                         for (int j = 0; j < CFG::NTL; ++j) acc[i][j][0] += to_f32(wf[j].v[0]) + to_f32(xf[i].v[0]);
                 }
             }
-            if (kt + 1 < nkt && !(S2M2_CONV_DBG & 4))
-                ld.stash(As + (size_t)(buf ^ 1) * BM * RS, Bs + (size_t)(buf ^ 1) * BN * RS, (f + 1) % NPF);
+            ld.stash(As + (size_t)(buf ^ 1) * BM * RS, Bs + (size_t)(buf ^ 1) * BN * RS, (f + 1) % NPF);   // (past the end: zeros, idle buffer)
             __syncthreads();
         }
     }
+    ld.drain();
 
     // ---- epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]
     const LinearPix pix{m0, M};
@@ -843,6 +864,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
         // UNTRACKED (global_load16_async, common.h) with counted waits: every iteration issues exactly B_IT weight loads (tiles past
         // the end read the zero page) and stashes exactly one tile, so "tile kt+1 has landed" is `vmcnt <= (DW-1)*B_IT` -- plus A_IT
         // while the halo loads of the next chunk (issued at tap 0, consumed at the last tap) are younger than that tile.
+        constexpr bool HA = (S2M2_ASYNC_LOADS & 1) != 0;
         constexpr int NB = (DW - 1) * CFG::B_IT;
         int f_tap = 0, f_chunk = 0;                                   // K position of the next weight tile to request
         auto fetch_b_async = [&](int slot) __attribute__((always_inline)) {
@@ -851,7 +873,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 #pragma unroll
             for (int it = 0; it < CFG::B_IT; ++it) {
                 const T* src = (cvalid && wrow[it]) ? wrow[it] + koff : zp;
-                global_load16_async(rb[slot][it], src);
+                global_load16_async<HA>(rb[slot][it], src);
             }
             if (++f_tap == ntap) { f_tap = 0; ++f_chunk; }
         };
@@ -880,7 +902,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
             for (int it = 0; it < CFG::A_IT; ++it) {
                 const unsigned e = __umul24((unsigned)apix[it], ss) + c;
                 const T* src = (cvalid && apix[it] >= 0) ? sp + e : zp;
-                global_load16_async(ra[it], src);
+                global_load16_async<HA>(ra[it], src);
             }
         };
         auto stash_a_async = [&]() __attribute__((always_inline)) {
@@ -892,13 +914,13 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
             }
         };
 
-        wait_vmcnt<0>();                                              // (the tracked bias loads: keep the counts below exact)
+        // (the tracked bias loads issued above are older than everything below: they only make the counted waits conservative)
         fetch_a_async(0);
 #pragma unroll
         for (int f = 0; f < DW; ++f) fetch_b_async(f);
-        wait_vmcnt<DW * CFG::B_IT>();
+        wait_vmcnt<DW * CFG::B_IT, HA>();
         stash_a_async();
-        wait_vmcnt<NB>();
+        wait_vmcnt<NB, HA>();
         stash_b_async(0, 0);
         __syncthreads();
         int tap = 0, chunk = 0, ky = 0, kx = 0;
@@ -927,8 +949,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 #pragma unroll
                         for (int j = 0; j < CFG::NTL; ++j) mma32(acc[i][j], wf[j], xf[i]);    // D[cout][pixel]
                 }
-                if (has_next && tap <= DW - 2) wait_vmcnt<NB + CFG::A_IT>();   // the halo loads of the next chunk are younger than tile kt+1
-                else wait_vmcnt<NB>();
+                if (has_next && tap <= DW - 2) wait_vmcnt<NB + CFG::A_IT, HA>();   // the halo loads of the next chunk are younger than tile kt+1
+                else wait_vmcnt<NB, HA>();
                 stash_b_async(buf ^ 1, (f + 1) % DW);                 // (past the end: a zero tile into the idle buffer)
                 if (last_tap && has_next) {
                     __syncthreads();                                  // every wave is done with this chunk's halo tile
@@ -939,7 +961,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
                 else { ++tap; if (++kx == p.KW) { kx = 0; ++ky; } }
             }
         }
-        wait_vmcnt<0>();                                              // drain the zero-page tail requests before their registers are reused
+        wait_vmcnt<0, HA>();                                              // drain the zero-page tail requests before their registers are reused
 #pragma unroll
         for (int f = 0; f < DW; ++f)
 #pragma unroll
@@ -1201,6 +1223,8 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         else if (a.Cout <= 32) tile = 3;                               // 128x32: narrow heads
         else if (a.Cout >= 128 && ((M + 127) / 128) * ((a.Cout + 127) / 128) >= 600) tile = 20;  // 128x128, 64-byte K rows, 8 waves
         else tile = Ktot <= 512 ? 6 : 2;                          // 64x64 with 64- / 128-byte K rows
+        static const bool deep = getenv("S2M2_CONV_NPF") != nullptr;  // A/B switch: 4 K tiles in flight for the v1 tiles
+        if (deep && !a.ln_wsum) tile = tile == 6 ? 16 : tile == 2 ? 17 : tile == 20 ? 27 : tile;
     }
     if (a.ln_wsum) {                                              // pre-LN folded in: the v1 tiles the heuristic picks for 1x1 layers
         switch (tile) {
@@ -1235,6 +1259,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         case 21: return launch_conv<T, 128, 128, 2, 8, 1, 8>(a, st);   // 128x128, 128-byte K rows, 8 waves
         case 22: return launch_conv<T, 64, 128, 2, 4, 1, 8>(a, st);    // 64x128, 64-byte K rows, 8 waves (32 px x 32 couts each)
         case 23: return launch_conv_halo<T, 64, 8, 4>(a, st);      // v3 halo tile, 64 couts, 8 waves (one patch row x 32 couts each)
+        case 27: return launch_conv<T, 128, 128, 2, 4, 4, 8>(a, st);   // t20 with 4 K tiles in flight
         case 24: return launch_conv_halo<T, 64, 8, 4, 4>(a, st);   // t23 with 4 weight tiles in flight (short grids)
         case 25: return launch_conv_halo<T, 64, 4, 2, 4>(a, st);   // t13 with 4 weight tiles in flight
         case 26: return launch_conv_halo<T, 128, 8, 2, 2>(a, st);  // t19 with 2 weight tiles in flight

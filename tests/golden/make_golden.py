@@ -205,9 +205,19 @@ def op_gru_upsample(name, C, h, w, B, seed):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1] if len(sys.argv) > 1 else ""                # python make_golden.py [substring]: regenerate matching files only
+    _all = e2e, op_dispinit, op_lookup, op_attention, op_gru_upsample
+    if only:
+        def _filtered(fn):
+            return lambda name, *a, **k: fn(name, *a, **k) if only in name else None
+        e2e, op_dispinit, op_lookup, op_attention, op_gru_upsample = [_filtered(f) for f in _all]
     e2e("e2e_S_64x96_pos_r2.npz", 128, 1, 64, 96, 1, True, 2, 8, 0)
     e2e("e2e_S_96x160_neg_r1_b2.npz", 128, 1, 96, 160, 2, False, 1, 12, 1, keep_features=False)
     e2e("e2e_S_64x64_pos_r1_up.npz", 128, 1, 64, 64, 1, True, 1, 4, 2, output_upsample=True, keep_features=False)
+    # the other published model sizes (README of the reference: M = 192 x 2 transformers, L = 256 x 3, XL = 384 x 3)
+    e2e("e2e_M_64x96_pos_r1.npz", 192, 2, 64, 96, 1, True, 1, 8, 3, keep_features=False)
+    e2e("e2e_L_64x96_pos_r2.npz", 256, 3, 64, 96, 1, True, 2, 6, 4, keep_features=False)
+    e2e("e2e_XL_64x64_pos_r1.npz", 384, 3, 64, 64, 1, True, 1, 5, 5, keep_features=False)
     op_dispinit("op_dispinit_pos.npz", 128, 6, 72, 2, True, 3)
     op_dispinit("op_dispinit_neg.npz", 64, 5, 40, 1, False, 4)
     op_lookup("op_lookup.npz", 5, 40, 2, 5)

@@ -17,7 +17,7 @@ from s2m2_amd.weights import seeded_state_dict
 from fake_hip import make as _fake_hip
 
 
-@pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_64x64_pos_r1_up"])
+@pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_64x64_pos_r1_up", "e2e_M_64x96_pos_r1"])
 def test_engine_wiring_matches_reference_golden(monkeypatch, name):
     monkeypatch.setattr(engine_mod, "hip", _fake_hip())
     g = load_golden(name + ".npz")

@@ -55,7 +55,7 @@ CASES = [
 ]
 # every block-tile variant (v1 with 64-byte K rows: 5, 6; v2 LDS-direct ring: 7..11) on shapes with M / K / Cout tails,
 # multi-source concatenation and zero padding
-for _t in (5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26):
+for _t in (5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27):
     CASES += [(1, 17, 23, [128], 128, 3, 3, 1, _t), (2, 13, 21, [96, 64, 64, 160], 256, 1, 1, 1, _t), (1, 20, 28, [2, 128], 136, 3, 3, 3, _t),
               (1, 33, 19, [128, 128], 128, 3, 1, 4, _t), (1, 9, 11, [8], 96, 3, 3, 1, _t), (2, 19, 70, [128, 128], 128, 1, 3, 0, _t)]
 

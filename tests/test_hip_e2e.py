@@ -21,7 +21,8 @@ def _model(C, ntr, pos, ri, up, seed):
     return m.cuda().eval()
 
 
-@pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_96x160_neg_r1_b2", "e2e_S_64x64_pos_r1_up"])
+@pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_96x160_neg_r1_b2", "e2e_S_64x64_pos_r1_up",
+                                  "e2e_M_64x96_pos_r1", "e2e_L_64x96_pos_r2", "e2e_XL_64x64_pos_r1"])
 def test_fp32_forward_vs_reference_golden(name):
     g = load_golden(name + ".npz")
     C, ntr, H, W, B, pos, ri, _, seed, up = [int(x) for x in g["cfg"]]

@@ -18,7 +18,8 @@ def _maxdiff(a, b):
     return float((a - T(b)).abs().max())
 
 
-@pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_96x160_neg_r1_b2", "e2e_S_64x64_pos_r1_up"])
+@pytest.mark.parametrize("name", ["e2e_S_64x96_pos_r2", "e2e_S_96x160_neg_r1_b2", "e2e_S_64x64_pos_r1_up",
+                                  "e2e_M_64x96_pos_r1", "e2e_L_64x96_pos_r2", "e2e_XL_64x64_pos_r1"])
 def test_end_to_end_against_reference(name):
     g = load_golden(name + ".npz")
     C, ntr, H, W, B, pos, ri, _, seed, up = [int(x) for x in g["cfg"]]
