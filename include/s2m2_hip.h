@@ -89,12 +89,15 @@ int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2,
  *   every channel count / stride is a multiple of 8 (callers zero-pad: weights of padded channels are zero)
  *   epi: ADD  v + aux0 | MUL  v * aux0 | GRU  (1-aux0)*aux1 + aux0*v  (aux0 = z, aux1 = h, v = q)
  *        GATEMIX  g = clamp(v, .01, .99); g*aux0 + (1-g)*aux1          (aux tensors NHWC at the output pixel/channel)
+ *        DUALMIX  two 1x1 layers on the same rows in one launch (the two heads of FeatureFusion, feature_fusion.py:15-31):
+ *                 weight rows = [W1 (Cout x ksplit) | W2 (Cout x (Cin - ksplit))] along K, act = SIGMOID;
+ *                 g = clamp(sigmoid(W1.in[:ksplit] + bias), .01, .99);  out = (W2.in[ksplit:] + bias2) + g*aux0 + (1-g)*aux1
  *   shuffle2 = C' > 0: the conv is the GEMM of a ConvTranspose2d(kernel 2, stride 2): KH = KW = 1, Cout = 4*C' ordered
  *        (dy, dx, c'), result stored to (N, 2H, 2W, C') with pixel stride out_stride.
  *   tile: 0 = automatic, 1..4 force a block tile (128x128, 64x64, 128x32, 128x64) -- tests and tuning only.
  */
 enum { S2M2_ACT_NONE = 0, S2M2_ACT_GELU = 1, S2M2_ACT_RELU = 2, S2M2_ACT_SIGMOID = 3, S2M2_ACT_TANH = 4 };
-enum { S2M2_EPI_NONE = 0, S2M2_EPI_ADD = 1, S2M2_EPI_MUL = 2, S2M2_EPI_GRU = 3, S2M2_EPI_GATEMIX = 4 };
+enum { S2M2_EPI_NONE = 0, S2M2_EPI_ADD = 1, S2M2_EPI_MUL = 2, S2M2_EPI_GRU = 3, S2M2_EPI_GATEMIX = 4, S2M2_EPI_DUALMIX = 5 };
 typedef struct s2m2_conv_desc {
     const void* src[4];
     int src_c[4];
@@ -122,6 +125,8 @@ typedef struct s2m2_conv_desc {
                                ln_wsum[co] = sum_k weight[co,k] (fp32, Cout entries, summed from the packed weight).
                                Needs KH = KW = 1, stride 1, no shuffle2, Cin with no padding channels, act NONE or GELU. */
     float ln_eps;
+    int ksplit;             /* S2M2_EPI_DUALMIX: first K index (channel of `in`) of the second layer; multiple of 64 */
+    const float* bias2;     /* S2M2_EPI_DUALMIX: bias of the second layer (fp32, Cout) or NULL */
 } s2m2_conv_desc;
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
 

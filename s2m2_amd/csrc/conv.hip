@@ -55,6 +55,8 @@ struct ConvArgs {
     const void* zero;           // 256 zero bytes in global memory (what out-of-range pieces read)
     const float* ln_wsum;       // non-null: pre-LayerNorm (no affine) of the input rows folded into the GEMM, see LnStats
     float ln_eps;
+    int ksplit;                 // S2M2_EPI_DUALMIX: K index where the second GEMM (second accumulator, bias2) starts
+    const float* bias2;
 };
 
 template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8, int NPF_ = 1, int NWAVES_ = 4>
@@ -101,7 +103,7 @@ struct AuxRegs {
     __device__ __forceinline__ void prefetch(const ConvArgs& p, int tid, int n0, PIX pix) {
         if constexpr (ON) {
             if (p.epi == S2M2_EPI_NONE) return;
-            const bool two = p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX;
+            const bool two = p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX || p.epi == S2M2_EPI_DUALMIX;
 #pragma unroll
             for (int it = 0; it < NP; ++it) {
                 const int q = tid + CFG::NT * it, r = q / PCR, pcc = q - r * PCR;
@@ -336,8 +338,11 @@ struct ConvLoader {
     }
 };
 
-template <typename CFG, typename T, bool LN = false>
+// MODE 0: plain; 1: pre-LayerNorm folded in (ln_wsum); 2: two GEMMs over consecutive K ranges of the same rows into two accumulators,
+// combined by the S2M2_EPI_DUALMIX epilogue (the gate and fusion heads of FeatureFusion in one launch)
+template <typename CFG, typename T, int MODE = 0>
 __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
+    constexpr bool LN = MODE == 1, DUAL = MODE == 2;
     constexpr int BM = CFG::BM, BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, BK = CFG::BK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* As = reinterpret_cast<T*>(smem);                          // [2][BM][RS]
@@ -363,12 +368,22 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
         for (int j = 0; j < CFG::NTL; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float16_t acc2[DUAL ? CFG::MT : 1][DUAL ? CFG::NTL : 1];     // second GEMM (K >= ksplit)
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
     float ln_s[CFG::MT], ln_q[CFG::MT], ln_shift[CFG::MT];
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i) ln_s[i] = ln_q[i] = ln_shift[i] = 0.f;
-    CoutRegs<CFG> bias, wsum;                                     // requested now, used after the K loop
+    CoutRegs<CFG> bias, wsum;                                     // requested now, used after the K loop (wsum: rowsum(W) or the second bias)
     bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
     if constexpr (LN) wsum.load(p.ln_wsum, p.zero, p.Cout, n0, wn, lane);
+    if constexpr (DUAL) wsum.load(p.bias2, p.zero, p.Cout, n0, wn, lane);
 
     // K tiles are requested NPF ahead into a ring of register slots (slot = tile % NPF, static after unrolling): for the short-K
     // layers (1x1, K <= NPF tiles) the whole K of the block is in flight at once -- one memory latency per block instead of one per tile
@@ -402,7 +417,14 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
                     for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
                 }
-                if (!(S2M2_CONV_DBG & 2)) {
+                if (DUAL && kt * BK >= p.ksplit) {                  // block-uniform: the K tile belongs to the second GEMM
+                    if constexpr (DUAL) {
+#pragma unroll
+                        for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < CFG::NTL; ++j) mma32(acc2[i][j], wf[j], xf[i]);
+                    }
+                } else if (!(S2M2_CONV_DBG & 2)) {
 #pragma unroll
                     for (int i = 0; i < CFG::MT; ++i)
 #pragma unroll
@@ -435,6 +457,35 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
             ln[i].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
         }
         stage_tile_ln<CFG, T>(p, acc, Cs, bias, wm, wn, lane, ln, wsum);
+    } else if constexpr (DUAL) {
+        // out = (acc2 + bias2) + mix(clamp(sigmoid(acc + bias)), aux0, aux1): both tiles go through the one staging buffer in turn,
+        // the mix of a thread's pieces waits in registers in between (rounded to T where the separate launches stored it)
+        using AX = AuxRegs<CFG, T>;
+        static_assert(AX::ON, "the dual-GEMM epilogue keeps the aux pieces of a thread in registers");
+        stage_tile<CFG, T, S2M2_ACT_SIGMOID>(acc, Cs, bias, 1.0f, wm, wn, lane);
+        __syncthreads();
+        Vec16<T> mix[AX::NP];
+#pragma unroll
+        for (int it = 0; it < AX::NP; ++it) {
+            const int q = tid + CFG::NT * it, r = q / AX::PCR, pcc = q - r * AX::PCR;
+            mix[it] = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)(q < AX::TOTAL ? r : 0) * CFG::CRS + pcc * VEC);
+            aux_combine(mix[it], S2M2_EPI_GATEMIX, __builtin_bit_cast(Vec16<T>, aux.a0[it]), __builtin_bit_cast(Vec16<T>, aux.a1[it]));
+        }
+        __syncthreads();
+        stage_tile<CFG, T, S2M2_ACT_NONE>(acc2, Cs, wsum, 1.0f, wm, wn, lane);
+        __syncthreads();
+        T* outp = static_cast<T*>(p.out);
+#pragma unroll
+        for (int it = 0; it < AX::NP; ++it) {
+            const int q = tid + CFG::NT * it, r = q / AX::PCR, pcc = q - r * AX::PCR;
+            const int co = n0 + pcc * VEC;
+            long long m;
+            if (q >= AX::TOTAL || !pix(r, m) || co >= p.Cout) continue;
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
+            aux_combine(v, S2M2_EPI_ADD, mix[it], mix[it]);
+            *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + co) = v;
+        }
+        return;
     } else {
         stage_tile_act<CFG, T>(p, acc, Cs, bias, wm, wn, lane);
     }
@@ -1135,10 +1186,10 @@ static const void* zero_page() {
     return z;
 }
 
-template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1, int NWAVES = 4, bool LN = false>
+template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1, int NWAVES = 4, int MODE = 0>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfg<T, BM, BN, WGM, PPR, NPF, NWAVES>;
-    auto kern = conv_igemm_kernel<CFG, T, LN>;
+    auto kern = conv_igemm_kernel<CFG, T, MODE>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1228,11 +1279,27 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     }
     if (a.ln_wsum) {                                              // pre-LN folded in: the v1 tiles the heuristic picks for 1x1 layers
         switch (tile) {
-            case 2: return launch_conv<T, 64, 64, 2, 8, 1, 4, true>(a, st);
-            case 3: return launch_conv<T, 128, 32, 4, 8, 1, 4, true>(a, st);
-            case 6: return launch_conv<T, 64, 64, 2, 4, 1, 4, true>(a, st);
-            case 20: return launch_conv<T, 128, 128, 2, 4, 1, 8, true>(a, st);
+            case 2: return launch_conv<T, 64, 64, 2, 8, 1, 4, 1>(a, st);
+            case 3: return launch_conv<T, 128, 32, 4, 8, 1, 4, 1>(a, st);
+            case 6: return launch_conv<T, 64, 64, 2, 4, 1, 4, 1>(a, st);
+            case 20: return launch_conv<T, 128, 128, 2, 4, 1, 8, 1>(a, st);
             default: return set_error("conv2d: tile %d has no pre-LayerNorm variant (2, 3, 6, 20 do)", tile);
+        }
+    }
+    if (a.epi == S2M2_EPI_DUALMIX) {                              // two GEMMs, one launch: the v1 tiles the heuristic picks for 1x1 layers
+        if constexpr (sizeof(T) == 2) {
+            switch (tile) {
+                case 2: return launch_conv<T, 64, 64, 2, 8, 1, 4, 2>(a, st);
+                case 6: return launch_conv<T, 64, 64, 2, 4, 1, 4, 2>(a, st);
+                case 20: return launch_conv<T, 128, 128, 2, 4, 1, 8, 2>(a, st);
+                default: return set_error("conv2d: tile %d has no dual-GEMM variant (2, 6, 20 do)", tile);
+            }
+        } else {
+            switch (tile) {                                       // fp32: 64x64 tiles only (4 staged pieces per thread)
+                case 2: case 20: return launch_conv<T, 64, 64, 2, 8, 1, 4, 2>(a, st);
+                case 6: return launch_conv<T, 64, 64, 2, 4, 1, 4, 2>(a, st);
+                default: return set_error("conv2d: tile %d has no dual-GEMM variant (2, 6, 20 do)", tile);
+            }
         }
     }
     switch (tile) {
@@ -1293,10 +1360,10 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
         }
     }
     S2M2_REQUIRE(d->act >= S2M2_ACT_NONE && d->act <= S2M2_ACT_TANH, "conv2d: unknown activation %d", d->act);
-    S2M2_REQUIRE(d->epi >= S2M2_EPI_NONE && d->epi <= S2M2_EPI_GATEMIX, "conv2d: unknown epilogue %d", d->epi);
+    S2M2_REQUIRE(d->epi >= S2M2_EPI_NONE && d->epi <= S2M2_EPI_DUALMIX, "conv2d: unknown epilogue %d", d->epi);
     if (d->epi != S2M2_EPI_NONE) {
         S2M2_REQUIRE(d->aux0 && d->aux0_stride % 8 == 0, "conv2d: epilogue %d needs aux0 (stride multiple of 8)", d->epi);
-        if (d->epi == S2M2_EPI_GRU || d->epi == S2M2_EPI_GATEMIX)
+        if (d->epi == S2M2_EPI_GRU || d->epi == S2M2_EPI_GATEMIX || d->epi == S2M2_EPI_DUALMIX)
             S2M2_REQUIRE(d->aux1 && d->aux1_stride % 8 == 0, "conv2d: epilogue %d needs aux1 (stride multiple of 8)", d->epi);
         S2M2_REQUIRE(!d->shuffle2, "conv2d: aux epilogues are not supported with shuffle2");
     }
@@ -1312,6 +1379,11 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "conv2d: cannot allocate the zero page");
     a.ln_wsum = d->ln_wsum; a.ln_eps = d->ln_eps;
+    a.ksplit = d->ksplit; a.bias2 = d->bias2;
+    if (d->epi == S2M2_EPI_DUALMIX)
+        S2M2_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && !d->shuffle2 && !d->korder && !d->ln_wsum && d->aux1 &&
+                     d->ksplit > 0 && d->ksplit < a.Cin && d->ksplit % 64 == 0 && d->act == S2M2_ACT_SIGMOID && d->out_scale == 1.0f,
+                     "conv2d: DUALMIX needs a 1x1 stride-1 layer, act SIGMOID, aux0/aux1, 0 < ksplit < Cin with ksplit a multiple of 64");
     if (d->ln_wsum)
         S2M2_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && !d->shuffle2 && !d->korder && d->ln_eps > 0.f &&
                      (d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_GELU),

@@ -62,6 +62,7 @@ class Engine:
         self.fuse_ln = os.environ.get("S2M2_FUSE_LN", "1") != "0"      # A/B switch: 0 = separate K6 LayerNorm launches
         self.use_chain = os.environ.get("S2M2_CHAIN", "1") != "0"      # A/B switch: 0 = one K5 launch per 1x1 layer instead of K9 chains
         self._chain_ok: Dict[int, bool] = {}
+        self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
@@ -189,6 +190,15 @@ class Engine:
         cg = self.p[p + ".feature_gate.0.weight"].shape[0]
         spec = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
         gf = self.cconv(spec, [z0, z1], act=hip.ACT_GELU)
+        if self.fuse_heads and cg % 64 == 0:
+            # both second layers in one launch: weight rows [gate.2 | fusion.2] along K (= the channel order of gf), two accumulators
+            key = p + "|gate.2+fusion.2"
+            dual = self._packed.get(key)
+            if dual is None:
+                g2, f2 = self.std(p + ".feature_gate.2"), self.std(p + ".feature_fusion.2")
+                dual = self._packed[key] = (torch.cat([g2[0], f2[0]], dim=1).contiguous(), g2[1], f2[1])
+            return hip.conv2d([gf], dual[0], dual[1], 1, 1, dual[0].shape[0], act=hip.ACT_SIGMOID, epi=hip.EPI_DUALMIX, aux0=z0, aux1=z1,
+                              ksplit=cg, bias2=dual[2])
         m = self.cconv(self.std(p + ".feature_gate.2"), [gf[..., :cg]], act=hip.ACT_SIGMOID, epi=hip.EPI_GATEMIX, aux0=z0, aux1=z1)
         return self.cconv(self.std(p + ".feature_fusion.2"), [gf[..., cg:]], epi=hip.EPI_ADD, aux0=m)
 

@@ -23,7 +23,7 @@ _lib: Optional[ctypes.CDLL] = None
 _vp, _i, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
-EPI_NONE, EPI_ADD, EPI_MUL, EPI_GRU, EPI_GATEMIX = 0, 1, 2, 3, 4
+EPI_NONE, EPI_ADD, EPI_MUL, EPI_GRU, EPI_GATEMIX, EPI_DUALMIX = 0, 1, 2, 3, 4, 5
 
 
 class ConvDesc(ctypes.Structure):
@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
                 ("out", _vp), ("out_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Cout", _i),
                 ("act", _i), ("epi", _i), ("aux0", _vp), ("aux1", _vp), ("aux0_stride", _i), ("aux1_stride", _i),
                 ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("korder", _i), ("stride", _i),
-                ("ln_wsum", _vp), ("ln_eps", ctypes.c_float)]
+                ("ln_wsum", _vp), ("ln_eps", ctypes.c_float), ("ksplit", _i), ("bias2", _vp)]
 
 
 class ChainDesc(ctypes.Structure):
@@ -162,7 +162,8 @@ def _nhwc(t: torch.Tensor):
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, act: int = ACT_NONE,
            epi: int = EPI_NONE, aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0,
-           stride: int = 1, korder: int = 0, ln_wsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5) -> torch.Tensor:
+           stride: int = 1, korder: int = 0, ln_wsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+           ksplit: int = 0, bias2: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Implicit-GEMM convolution / linear layer (s2m2_conv2d).  srcs: list of (N,H,W,Cs) tensors, concatenated along C;
     weight: packed (Cout, KH*KW*sum(Cs)) (see s2m2_amd.pack); bias fp32 (Cout) or None.  Returns (N,H,W,Cout), or
     (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM.  ln_wsum (fp32 (Cout) row sums of the packed weight): the 1x1 layer
@@ -214,6 +215,11 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
             raise ValueError("conv2d: ln_wsum must be fp32 (Cout)")
         d.ln_wsum = ln_wsum.data_ptr()
         d.ln_eps = ln_eps
+    if epi == EPI_DUALMIX:
+        if bias2 is not None and (bias2.dtype != torch.float32 or bias2.numel() != Cout or not bias2.is_contiguous()):
+            raise ValueError("conv2d: bias2 must be fp32 (Cout)")
+        d.ksplit = ksplit
+        d.bias2 = bias2.data_ptr() if bias2 is not None else None
     d.dtype = _DT[dt]
     _check(load().s2m2_conv2d(ctypes.byref(d), _stream()), "s2m2_conv2d")
     return out

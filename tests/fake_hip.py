@@ -13,7 +13,7 @@ ACTS = [lambda t: t, F.gelu, F.relu, torch.sigmoid, torch.tanh]
 
 def make():
     ns = types.SimpleNamespace(ACT_NONE=0, ACT_GELU=1, ACT_RELU=2, ACT_SIGMOID=3, ACT_TANH=4,
-                               EPI_NONE=0, EPI_ADD=1, EPI_MUL=2, EPI_GRU=3, EPI_GATEMIX=4, load=lambda: None)
+                               EPI_NONE=0, EPI_ADD=1, EPI_MUL=2, EPI_GRU=3, EPI_GATEMIX=4, EPI_DUALMIX=5, load=lambda: None)
 
     def ln_corr(tokens, g, b, cv_dtype=None, out=None):
         return O.ln_corr(tokens.permute(0, 3, 1, 2).float(), g, b)
@@ -29,11 +29,17 @@ def make():
         buf[..., off2:off2 + T] = c2.permute(0, 2, 3, 1).to(buf.dtype)
 
     def conv2d(srcs, weight, bias, KH, KW, Cout, act=0, epi=0, aux0=None, aux1=None, out=None, out_scale=1.0, shuffle2=0, tile=0,
-               stride=1, ln_wsum=None, ln_eps=1e-5):
+               stride=1, ln_wsum=None, ln_eps=1e-5, ksplit=0, bias2=None):
         if isinstance(srcs, torch.Tensor):
             srcs = [srcs]
         x = torch.cat([s.float() for s in srcs], -1)
         n, h, w, cin = x.shape
+        if epi == 5:                                                 # DUALMIX: two 1x1 layers over consecutive channel ranges
+            assert KH == 1 and KW == 1 and act == 3 and 0 < ksplit < cin
+            wf = weight.float()
+            g = torch.sigmoid(F.linear(x[..., :ksplit], wf[:, :ksplit], bias)).clamp(0.01, 0.99)
+            y = F.linear(x[..., ksplit:], wf[:, ksplit:], bias2) + g * aux0.float() + (1 - g) * aux1.float()
+            return y.to(srcs[0].dtype).contiguous()
         if ln_wsum is not None:
             assert KH == 1 and KW == 1 and torch.allclose(ln_wsum, weight.float().sum(1), atol=1e-4)
             x = F.layer_norm(x, (cin,), eps=ln_eps)

@@ -203,3 +203,30 @@ def test_pre_layernorm_rejects_spatial_kernels(hip):
     wp = torch.randn(128, 9 * 128, device="cuda").half()
     with pytest.raises(RuntimeError, match="pre-LayerNorm"):
         hip.conv2d([x], wp, None, 3, 3, 128, ln_wsum=torch.zeros(128, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("tile", [0, 2, 6, 20])
+@pytest.mark.parametrize("shape", [(1, 50, 61, 128, 256, 128), (2, 16, 19, 256, 512, 256), (1, 9, 13, 64, 64, 96)])
+def test_dual_gemm_gate_mix(hip, dtype, tile, shape):
+    """S2M2_EPI_DUALMIX (the two heads of FeatureFusion, feature_fusion.py:15-31, in one launch) == the two separate launches
+    and the fp32 formula: (W2.h[ks:] + b2) + g*z0 + (1-g)*z1, g = clamp(sigmoid(W1.h[:ks] + b1), .01, .99)."""
+    n, h, w, ks, k2, cout = shape
+    g = torch.Generator(device="cuda").manual_seed(ks + k2 + tile)
+    hdn = torch.randn(n, h, w, ks + k2, device="cuda", generator=g).to(dtype)
+    z0 = torch.randn(n, h, w, cout, device="cuda", generator=g).to(dtype)
+    z1 = torch.randn(n, h, w, cout, device="cuda", generator=g).to(dtype)
+    w1 = (torch.randn(cout, ks, 1, 1, device="cuda", generator=g) / math.sqrt(ks)).to(dtype)
+    w2 = (torch.randn(cout, k2, 1, 1, device="cuda", generator=g) / math.sqrt(k2)).to(dtype)
+    b1, b2 = torch.randn(cout, device="cuda", generator=g), torch.randn(cout, device="cuda", generator=g)
+    p1, p2 = pack.pack_conv(w1, dtype), pack.pack_conv(w2, dtype)
+    wcat = torch.cat([p1, p2], dim=1).contiguous()
+    y = hip.conv2d([hdn], wcat, pack.pack_bias(b1, cout), 1, 1, cout, act=hip.ACT_SIGMOID, epi=hip.EPI_DUALMIX, aux0=z0, aux1=z1,
+                   ksplit=ks, bias2=pack.pack_bias(b2, cout), tile=tile)
+    gate = torch.sigmoid(F.linear(hdn[..., :ks].float(), w1.float().reshape(cout, ks), b1)).clamp(0.01, 0.99)
+    ref = F.linear(hdn[..., ks:].float(), w2.float().reshape(cout, k2), b2) + gate * z0.float() + (1 - gate) * z1.float()
+    m = hip.conv2d([hdn[..., :ks]], p1, pack.pack_bias(b1, cout), 1, 1, cout, act=hip.ACT_SIGMOID, epi=hip.EPI_GATEMIX, aux0=z0, aux1=z1)
+    y2 = hip.conv2d([hdn[..., ks:]], p2, pack.pack_bias(b2, cout), 1, 1, cout, epi=hip.EPI_ADD, aux0=m)
+    tol = 1e-4 if dtype == torch.float32 else 8e-3
+    assert float((y.float() - ref).abs().max()) < tol
+    assert float((y.float() - y2.float()).abs().max()) < tol
