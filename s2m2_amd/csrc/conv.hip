@@ -381,9 +381,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i) ln_s[i] = ln_q[i] = ln_shift[i] = 0.f;
     CoutRegs<CFG> bias, wsum;                                     // requested now, used after the K loop (wsum: rowsum(W) or the second bias)
-    bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
+    if constexpr (!DUAL) bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
     if constexpr (LN) wsum.load(p.ln_wsum, p.zero, p.Cout, n0, wn, lane);
-    if constexpr (DUAL) wsum.load(p.bias2, p.zero, p.Cout, n0, wn, lane);
 
     // K tiles are requested NPF ahead into a ring of register slots (slot = tile % NPF, static after unrolling): for the short-K
     // layers (1x1, K <= NPF tiles) the whole K of the block is in flight at once -- one memory latency per block instead of one per tile
@@ -441,11 +440,15 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
         }
     }
     ld.drain();
+    if constexpr (DUAL) {                                         // two accumulator sets: no registers to spare during the K loop
+        bias.load(p.bias, p.zero, p.Cout, n0, wn, lane);
+        wsum.load(p.bias2, p.zero, p.Cout, n0, wn, lane);
+    }
 
     // ---- epilogue 1: bias, activation, scale in registers -> staging tile Cs[pixel][cout]
     const LinearPix pix{m0, M};
     AuxRegs<CFG, T> aux;
-    aux.prefetch(p, tid, n0, pix);
+    if constexpr (!DUAL) aux.prefetch(p, tid, n0, pix);           // (the dual-GEMM epilogue has no registers to park them in)
     if constexpr (LN) {
         LnRow ln[CFG::MT];
         const float inv = 1.0f / (float)Ktot;
@@ -468,8 +471,13 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
         for (int it = 0; it < AX::NP; ++it) {
             const int q = tid + CFG::NT * it, r = q / AX::PCR, pcc = q - r * AX::PCR;
+            const int co = n0 + pcc * VEC;
+            long long m;
+            const bool ok = q < AX::TOTAL && pix(r, m) && co < p.Cout;
+            const raw16_t u0 = global_load16(ok ? static_cast<const T*>(p.aux0) + m * p.aux0_stride + co : static_cast<const T*>(p.zero));
+            const raw16_t u1 = global_load16(ok ? static_cast<const T*>(p.aux1) + m * p.aux1_stride + co : static_cast<const T*>(p.zero));
             mix[it] = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)(q < AX::TOTAL ? r : 0) * CFG::CRS + pcc * VEC);
-            aux_combine(mix[it], S2M2_EPI_GATEMIX, __builtin_bit_cast(Vec16<T>, aux.a0[it]), __builtin_bit_cast(Vec16<T>, aux.a1[it]));
+            aux_combine(mix[it], S2M2_EPI_GATEMIX, __builtin_bit_cast(Vec16<T>, u0), __builtin_bit_cast(Vec16<T>, u1));
         }
         __syncthreads();
         stage_tile<CFG, T, S2M2_ACT_NONE>(acc2, Cs, wsum, 1.0f, wm, wn, lane);
@@ -1265,6 +1273,7 @@ static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
 template <typename T>
 static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     const long long M = (long long)a.N * a.Ho * a.Wo;
+    const bool auto_tile = tile == 0;
     if (tile == 0) {                                              // measured on MI355X (tools/convbench.py, profiles/r01)
         const int Ktot = a.KH * a.KW * a.Cin;
         if (a.KH * a.KW > 1 && a.KH <= 3 && a.KW <= 3 && a.stride == 1 && !a.shuffle2 && !a.korder) {
@@ -1287,6 +1296,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         }
     }
     if (a.epi == S2M2_EPI_DUALMIX) {                              // two GEMMs, one launch: the v1 tiles the heuristic picks for 1x1 layers
+        if (auto_tile) tile = 2;                                  // measured end to end: 64x64 / 128-byte K rows (the 8-wave 128x128 tile needs 168 VGPRs with two accumulator sets: one block per CU)
         if constexpr (sizeof(T) == 2) {
             switch (tile) {
                 case 2: return launch_conv<T, 64, 64, 2, 8, 1, 4, 2>(a, st);
