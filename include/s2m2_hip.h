@@ -226,6 +226,9 @@ int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int C, long lon
  *   s2m2_refine_update  in place: disp += dco[0]; conf = sigmoid(dco[8] + logit(conf, .01)); occ likewise with dco[9]
  *                       (refinenet.py:149-151); then clamp disp at 0 if use_positivity and occ *= (x - disp >= 0) (s2m2.py:177-180)
  *   s2m2_tanh           y = tanh(x) on n elements (hidden = tanh(ctx), s2m2.py:166)
+ *   s2m2_stem_mlp       the two 1x1 layers at the head of CNNEncoder on full-resolution pixels (submodules.py:68-71: conv0 =
+ *                       Conv2d(3,16,1) - GELU - Conv2d(16,16,1)): x8 (npix,8) -> out (npix,16) = W1.gelu(W0.x + b0) + b1;
+ *                       w0 (16,8), w1 (16,16), biases (16): fp32, weights already rounded to the activation dtype
  *   disp, conf, occ, out: (B,h,w) fp32.
  */
 int s2m2_image_prep(const void* img0, const void* img1, void* x8, int B, int H, int W, int img_dtype, int dtype, void* stream);
@@ -235,6 +238,8 @@ int s2m2_global_update(const void* upd, int upd_stride, const float* disp, const
 int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf, float* occ, long long npix, int w, int use_positivity,
                        int dtype, void* stream);
 int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream);
+int s2m2_stem_mlp(const void* x8, const float* w0, const float* b0, const float* w1, const float* b1, void* out, long long npix, int dtype,
+                  void* stream);
 
 /*
  * [8f-1] image_pad of the reference driver (src/s2m2/core/utils/image_utils.py:27-71), on the device: (B,C,H,W) planar image

@@ -7,6 +7,7 @@
 //   unary          tanh of the context features (hidden state init)                 (s2m2.py:166)
 // All maps are (B,h,w) fp32; "small" side inputs are (B,h,w,8) NHWC in the activation dtype with unused channels zero.
 #include "common.h"
+#include "epilogue.h"
 
 namespace s2m2 {
 
@@ -153,6 +154,69 @@ extern "C" int s2m2_refine_update(const void* dco, int dco_stride, float* disp, 
     else if (dtype == S2M2_F32) hipLaunchKernelGGL((refine_update_kernel<float>), grid1(npix), dim3(256), 0, st, (const float*)dco, dco_stride, disp, conf, occ, npix, w, use_positivity);
     else return set_error("refine_update: unsupported dtype %d", dtype);
     return check_launch("refine_update");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stem: the two 1x1 layers at the head of the CNN encoder, conv0 = Conv2d(3,16,1) - GELU - Conv2d(16,16,1) (reference
+// submodules.py:68-71), on FULL-resolution pixels (2.5 M per pair at 1216x1024).  With K = 8 / 16 and N = 16 a GEMM tile is
+// all padding and per-block overhead (K5: 145 + 134 us); per pixel it is 384 FMAs + 16 GELUs, so one thread takes one pixel:
+// weights are wave-uniform (scalar loads), the 16-channel intermediate never leaves registers (rounded to the I/O dtype where
+// the separate layers stored it), 16 bytes in, 32 bytes out per pixel.
+// ---------------------------------------------------------------------------------------------------------------
+namespace s2m2 {
+template <typename T>
+__global__ __launch_bounds__(256) void stem_mlp_kernel(const T* __restrict__ x8, const float* __restrict__ w0, const float* __restrict__ b0,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1, T* __restrict__ out,
+                                                       long long npix) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    float x[8];
+    if constexpr (sizeof(T) == 2) {
+        const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x8 + i * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = to_f32(v.v[k]);
+    } else {
+        const Vec16<T> v0 = *reinterpret_cast<const Vec16<T>*>(x8 + i * 8), v1 = *reinterpret_cast<const Vec16<T>*>(x8 + i * 8 + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { x[k] = to_f32(v0.v[k]); x[4 + k] = to_f32(v1.v[k]); }
+    }
+    float h[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float a = b0[j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a = __builtin_fmaf(w0[j * 8 + k], x[k], a);
+        h[j] = to_f32(from_f32<T>(activate<S2M2_ACT_GELU>(a)));
+    }
+    float y[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        float a = b1[o];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a = __builtin_fmaf(w1[o * 16 + j], h[j], a);
+        y[o] = a;
+    }
+    constexpr int VEC = 16 / sizeof(T);
+#pragma unroll
+    for (int q = 0; q < 16 / VEC; ++q) {
+        Vec16<T> v;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(y[q * VEC + e]);
+        *reinterpret_cast<Vec16<T>*>(out + i * 16 + q * VEC) = v;
+    }
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_stem_mlp(const void* x8, const float* w0, const float* b0, const float* w1, const float* b1, void* out, long long npix,
+                             int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(x8 && w0 && b0 && w1 && b1 && out && npix > 0, "stem_mlp: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == S2M2_F16) hipLaunchKernelGGL((stem_mlp_kernel<half_t>), grid1(npix), dim3(256), 0, st, (const half_t*)x8, w0, b0, w1, b1, (half_t*)out, npix);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((stem_mlp_kernel<float>), grid1(npix), dim3(256), 0, st, (const float*)x8, w0, b0, w1, b1, (float*)out, npix);
+    else return set_error("stem_mlp: unsupported dtype %d", dtype);
+    return check_launch("stem_mlp");
 }
 
 extern "C" int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream) {

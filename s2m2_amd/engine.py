@@ -62,6 +62,7 @@ class Engine:
         self.fuse_ln = os.environ.get("S2M2_FUSE_LN", "1") != "0"      # A/B switch: 0 = separate K6 LayerNorm launches
         self.use_chain = os.environ.get("S2M2_CHAIN", "1") != "0"      # A/B switch: 0 = one K5 launch per 1x1 layer instead of K9 chains
         self._chain_ok: Dict[int, bool] = {}
+        self.fuse_stem = os.environ.get("S2M2_FUSE_STEM", "1") != "0"    # A/B switch: 0 = the two full-resolution stem layers as K5 launches
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -374,8 +375,15 @@ class Engine:
         B = img0.shape[0]
         x8 = hip.image_prep(img0, img1, self.dtype)                             # (2B,H,W,8): channels 1..3 = normalised RGB, 0 free
         p = "cnn_backbone"                                                      # CNNEncoder (submodules.py:63-93)
-        t = self.cconv(self._conv0(), [x8], act=hip.ACT_GELU)
-        t = self.cconv(self.std(p + ".conv0.2"), [t])
+        c0, c2 = self._conv0(), self.std(p + ".conv0.2")
+        if self.fuse_stem and tuple(c0[0].shape) == (16, 8) and tuple(c2[0].shape) == (16, 16) and c0[2] == 1 and c2[2] == 1:
+            st = self._packed.get("stem|fp32")                                  # conv0 = 1x1 - GELU - 1x1 per pixel on the VALU (K8)
+            if st is None:
+                st = self._packed["stem|fp32"] = (c0[0].float().contiguous(), c0[1], c2[0].float().contiguous(), c2[1])
+            t = hip.stem_mlp(x8, *st)
+        else:
+            t = self.cconv(c0, [x8], act=hip.ACT_GELU)
+            t = self.cconv(c2, [t])
         t = self.cconv(self.std(p + ".conv1_down.0"), [t], act=hip.ACT_GELU, stride=2)
         f2 = self.cconv(self.std(p + ".conv1_down.2"), [t])
         f2 = hip.groupnorm_nhwc(f2, 8, self.p[p + ".norm1.weight"], self.p[p + ".norm1.bias"])

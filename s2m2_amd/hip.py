@@ -63,6 +63,7 @@ SIGNATURES = {
     "s2m2_global_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_refine_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "s2m2_tanh": (_i, [_vp, _vp, _ll, _i, _vp]),
+    "s2m2_stem_mlp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
     "s2m2_image_pad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "s2m2_layernorm": (_i, [_vp, _vp, _ll, _i, _ll, _ll, _i, _vp]),
     "s2m2_groupnorm_workspace_bytes": (ctypes.c_size_t, [_i, _i]),
@@ -424,6 +425,19 @@ def tanh(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(x)
     _check(load().s2m2_tanh(x.data_ptr(), y.data_ptr(), x.numel(), _DT[x.dtype], _stream()), "s2m2_tanh")
     return y
+
+
+def stem_mlp(x8: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor) -> torch.Tensor:
+    """(N,H,W,8) -> (N,H,W,16): Conv1x1(8->16) - GELU - Conv1x1(16->16) per pixel (s2m2_stem_mlp); fp32 weights (16,8), (16,16), biases (16)."""
+    _dev(x8, w0, b0, w1, b1)
+    if x8.shape[-1] != 8 or tuple(w0.shape) != (16, 8) or tuple(w1.shape) != (16, 16) or b0.numel() != 16 or b1.numel() != 16:
+        raise ValueError("stem_mlp: x8 (...,8), w0 (16,8), w1 (16,16), biases (16)")
+    if any(t.dtype != torch.float32 for t in (w0, b0, w1, b1)):
+        raise ValueError("stem_mlp: weights and biases must be fp32")
+    out = torch.empty(tuple(x8.shape[:-1]) + (16,), device=x8.device, dtype=x8.dtype)
+    _check(load().s2m2_stem_mlp(x8.data_ptr(), w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), out.data_ptr(),
+                                x8.numel() // 8, _DT[x8.dtype], _stream()), "s2m2_stem_mlp")
+    return out
 
 
 def image_pad(img: torch.Tensor, factor: int = 32) -> torch.Tensor:

@@ -83,6 +83,9 @@ def make():
             t = y
         return t.to(x.dtype)
 
+    def stem_mlp(x8, w0, b0, w1, b1):
+        return F.linear(F.gelu(F.linear(x8.float(), w0, b0)), w1, b1).to(x8.dtype)
+
     def layernorm(x, out=None):
         return F.layer_norm(x.float(), (x.shape[-1],)).to(x.dtype)
 
@@ -167,6 +170,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, stem_mlp):
         setattr(ns, f.__name__, f)
     return ns

@@ -44,3 +44,28 @@ def test_run_stereo_matching_on_a_non_x32_pair():
     assert tuple(d.shape) == (270, 330) and tuple(o.shape) == (270, 330) and tuple(c.shape) == (270, 330)
     assert torch.isfinite(d).all() and 0.0 <= score <= 1.0 and ms > 0
     assert utils.image_crop(torch.zeros(1, 1, 288, 352), (270, 330)).shape[-2:] == (270, 330)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_stem_mlp_matches_the_two_conv_layers(dtype):
+    """K8 stem (conv0 = Conv1x1(3,16)-GELU-Conv1x1(16,16), submodules.py:68-71, per pixel on the VALU) == the two K5 launches it
+    replaces and the fp32 formula with the intermediate rounded to the I/O dtype."""
+    import torch.nn.functional as F
+    from s2m2_amd import hip, pack
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x8 = torch.zeros(2, 37, 53, 8, device="cuda", dtype=dtype)
+    x8[..., 1:4] = (torch.rand(2, 37, 53, 3, device="cuda", generator=g) * 2 - 1).to(dtype)
+    w0 = torch.zeros(16, 8, 1, 1, device="cuda")
+    w0[:, 1:4] = torch.randn(16, 3, 1, 1, device="cuda", generator=g)
+    w1 = torch.randn(16, 16, 1, 1, device="cuda", generator=g) / 4
+    b0, b1 = torch.randn(16, device="cuda", generator=g), torch.randn(16, device="cuda", generator=g)
+    p0, p1 = pack.pack_conv(w0.to(dtype), dtype), pack.pack_conv(w1.to(dtype), dtype)
+    y = hip.stem_mlp(x8, p0.float().contiguous(), pack.pack_bias(b0, 16), p1.float().contiguous(), pack.pack_bias(b1, 16))
+    t = hip.conv2d([x8], p0, pack.pack_bias(b0, 16), 1, 1, 16, act=hip.ACT_GELU)
+    y2 = hip.conv2d([t], p1, pack.pack_bias(b1, 16), 1, 1, 16)
+    h = F.gelu(F.linear(x8.float(), p0.float(), b0)).to(dtype).float()
+    ref = F.linear(h, p1.float(), b1)
+    tol = 2e-5 if dtype == torch.float32 else 4e-3
+    assert y.shape == (2, 37, 53, 16) and y.dtype == dtype
+    assert float((y.float() - ref).abs().max()) < tol
+    assert float((y.float() - y2.float()).abs().max()) < tol

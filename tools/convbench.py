@@ -44,6 +44,11 @@ SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
     ("1/2 3x3 128->64", 1, 512, 608, 128, 64, 3, 3),
     ("1/1 3x3 48->48", 1, 1024, 1216, 48, 48, 3, 3),
     ("1/4 3x3 128->8", 1, 256, 304, 128, 8, 3, 3),
+    ("1/1 3x3 8->32 narrowK", 1, 1024, 1216, 8, 32, 3, 3),
+    ("1/4 3x3 8->160 narrowK", 1, 256, 304, 8, 160, 3, 3),
+    ("1/1 1x1 8->16 x2 narrowK", 2, 1024, 1216, 8, 16, 1, 1),
+    ("1/1 1x1 16->16 x2 narrowK", 2, 1024, 1216, 16, 16, 1, 1),
+    ("1/1 1x1 48->16 narrowK", 1, 1024, 1216, 48, 16, 1, 1),
 ]
 
 
