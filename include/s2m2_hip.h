@@ -163,6 +163,19 @@ int s2m2_mlp_chain_supported(int C, int dtype);
 int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
 
 /*
+ * K10 -- FeatureFusion with 1x1 kernels in ONE launch (reference feature_fusion.py:4-33 with kernel_size = 1: every fusion of
+ *   Unet / MRT, unet.py:39-41, stacked_MRT.py:36-41), the 3C-wide hidden tensor never leaves the CU:
+ *     h = GELU(w1 . cat(z0, z1) + b1);  g = clamp(sigmoid(Wg . h[:C] + bg), .01, .99);  out = (Wf . h[C:] + bf) + g*z0 + (1-g)*z1
+ *   z0, z1, out: `rows` token rows of C channels (row strides in elements, multiples of 8), dtype `dtype`;
+ *   w1 packed (3C, 2C): rows [0,C) = feature_gate.0, rows [C,3C) = feature_fusion.0;  w2 packed (C, 3C) = [Wg (C,C) | Wf (C,2C)]
+ *   along K;  b1 (3C), bg (C), bf (C) fp32.  C = 128 or 256: ask s2m2_feature_fusion_supported.
+ */
+int s2m2_feature_fusion_supported(int C, int dtype);
+int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+                        long long rows, int C, const void* w1, const float* b1, const void* w2, const float* bg, const float* bf,
+                        int dtype, void* stream);
+
+/*
  * [A2,A3] pre-norm LayerNorm without affine over the channel axis (attentions.py:117,148,182,213,243; eps 1e-5, biased var).
  *   x, y: `rows` token rows of C channels, row strides x_stride / y_stride elements (multiples of 8); fp32 arithmetic.
  */

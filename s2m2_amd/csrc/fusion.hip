@@ -1,0 +1,287 @@
+// K10 -- FeatureFusion with 1x1 kernels as ONE launch (s2m2_feature_fusion).
+//
+// Reference feature_fusion.py:4-33 (kernel_size 1: every FeatureFusion of Unet / MRT except the 3x3 one of the CNN pyramid):
+//     z = cat(z0, z1)                                   2C channels
+//     h = GELU(W1 . z + b1)                             3C channels: rows [0, C) = feature_gate.0, rows [C, 3C) = feature_fusion.0
+//     g = clamp(sigmoid(Wg . h[:C] + bg), .01, .99)     feature_gate.2
+//     out = (Wf . h[C:] + bf) + g * z0 + (1 - g) * z1   feature_fusion.2
+// As K5 launches this is two GEMMs with a 3C-wide intermediate going through HBM (K = 256 / 384: a handful of K tiles per block,
+// overhead-dominated) -- 1.3 ms of the 10.4 ms pair.  Here a block owns BM rows:
+//   * the z0 | z1 row tile stays in LDS for the whole kernel (A operand of the first layer AND the two mix operands of the epilogue);
+//   * h is produced one C-wide slice at a time into a [BM][C+pad] LDS tile and consumed immediately as the next K range of the
+//     second layer (slice 0 -> the gate accumulators, slices 1, 2 -> the fusion accumulators), so only BM x C of it ever exists;
+//   * all weights form ONE stream of [C couts x 64 bytes of K] chunks (per slice: 2C/BK chunks of W1, then C/BK chunks of
+//     [Wg | Wf]), D chunks in flight in registers as in K9;
+//   * MFMA roles, staging and rounding points as in K5 / K9: h, g, the mix and the fusion term are each rounded to the I/O dtype
+//     where the separate launches stored them.
+#include "common.h"
+#include "epilogue.h"
+#include <stdlib.h>
+
+namespace s2m2 {
+
+struct FusionArgs {
+    const void* z0;
+    const void* z1;
+    void* out;
+    long long z0_stride, z1_stride, out_stride, rows;
+    const void* w1;          // (3C, 2C)
+    const void* w2;          // (C, 3C) = [Wg | Wf]
+    const float* b1;         // 3C
+    const float* bg;         // C
+    const float* bf;         // C
+    const void* zero;
+};
+
+template <typename T, int C_, int BM_, int NW_>
+struct FusionCfg {
+    static constexpr int C = C_, BM = BM_, NW = NW_, NT = 64 * NW_, D = 4;
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int BK = 4 * VEC;                    // K elements per chunk (64 bytes per weight row)
+    static constexpr int RS = BK + VEC;                   // weight tile row stride in LDS
+    static constexpr int KSTEPS = BK / 16;
+    static constexpr int XRS = 2 * C + VEC;               // z0 | z1 tile row stride
+    static constexpr int HRS = C + VEC;                   // h slice / staging tile row stride
+    static constexpr int CRS = HRS;                       // (name used by stage_tile)
+    static constexpr int WM = BM, MT = BM / 32, WN = C / NW, NTL = WN / 32;
+    static constexpr int K0 = 2 * C / BK;                 // chunks of one first-layer slice
+    static constexpr int K1 = C / BK;                     // chunks of one second-layer K range
+    static constexpr int PER_SLICE = K0 + K1;
+    static constexpr int TOTAL = 3 * PER_SLICE;
+    static constexpr int WROWS = NT / 4;
+    static constexpr int B_IT = C / WROWS;
+    static constexpr int PPR = C / VEC;                   // 16-byte pieces per C-wide row
+    static constexpr int X_IT = BM * PPR / NT;            // pieces per thread for one C-wide tile
+    static constexpr size_t X_BYTES = (size_t)BM * XRS * sizeof(T);
+    static constexpr size_t H_BYTES = (size_t)BM * HRS * sizeof(T);
+    static constexpr size_t W_BYTES = (size_t)C * RS * sizeof(T);
+    static constexpr size_t LDS_BYTES = X_BYTES + H_BYTES + 2 * W_BYTES;
+    static_assert(C % 128 == 0 && K0 % D == 0 && K1 % D == 0 && (BM * PPR) % NT == 0 && BM % 32 == 0 && WN % 32 == 0 && C % WROWS == 0,
+                  "unsupported fusion tile");
+    static_assert(LDS_BYTES <= 160 * 1024, "fusion tile does not fit the 160 KB LDS");
+};
+
+// weight stream: position j -> slice s = j / PER_SLICE, r = j % PER_SLICE;  r < K0: rows [sC, sC+C) of W1, K chunk r;
+// else rows [0, C) of W2, K chunk s*K1 + (r - K0)
+template <typename CFG, typename T>
+struct FusionStream {
+    raw16_t r[CFG::D][CFG::B_IT];
+    const T *w1, *w2;
+    int lrow, pc;
+    __device__ __forceinline__ void init(const FusionArgs& p, int tid) {
+        w1 = static_cast<const T*>(p.w1); w2 = static_cast<const T*>(p.w2);
+        lrow = tid >> 2; pc = tid & 3;
+    }
+    __device__ __forceinline__ void fetch(int j, int SLOT) {      // j block-uniform, SLOT static after unrolling
+        const int s = j / CFG::PER_SLICE, rr = j - s * CFG::PER_SLICE;
+        const bool first = rr < CFG::K0;
+        const T* base = first ? w1 + (size_t)s * CFG::C * (2 * CFG::C) + (size_t)rr * CFG::BK
+                              : w2 + (size_t)(s * CFG::K1 + rr - CFG::K0) * CFG::BK;
+        const int rstride = first ? 2 * CFG::C : 3 * CFG::C;
+        const T* q = base + (size_t)lrow * rstride + pc * CFG::VEC;
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + (size_t)it * CFG::WROWS * rstride);
+    }
+    __device__ __forceinline__ void stash(T* wb, int SLOT) const {
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it)
+            *reinterpret_cast<raw16_t*>(wb + (size_t)(lrow + CFG::WROWS * it) * CFG::RS + pc * CFG::VEC) = r[SLOT][it];
+    }
+};
+
+template <typename T> struct Quad;                                  // 4 consecutive channels of one row
+template <> struct Quad<half_t> { half4_t v; };
+template <> struct Quad<float> { float4_t v; };
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(CFG::NT) void feature_fusion_kernel(FusionArgs p) {
+    constexpr int C = CFG::C, BM = CFG::BM, VEC = CFG::VEC, BK = CFG::BK, RS = CFG::RS, XRS = CFG::XRS, HRS = CFG::HRS, D = CFG::D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* X = reinterpret_cast<T*>(smem);                                                   // [BM][2C + pad]: z0 | z1
+    T* H = reinterpret_cast<T*>(smem + CFG::X_BYTES);                                    // [BM][C + pad]: one slice of h; staging tile at the end
+    T* W0 = reinterpret_cast<T*>(smem + CFG::X_BYTES + CFG::H_BYTES);
+    T* W1 = reinterpret_cast<T*>(smem + CFG::X_BYTES + CFG::H_BYTES + CFG::W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * BM;
+
+    FusionStream<CFG, T> ws;
+    ws.init(p, tid);
+    ws.fetch(0, 0);
+    raw16_t xr0[CFG::X_IT], xr1[CFG::X_IT];
+#pragma unroll
+    for (int it = 0; it < CFG::X_IT; ++it) {
+        const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+        const long long m = m0 + row;
+        const bool ok = m < p.rows;
+        xr0[it] = global_load16(ok ? static_cast<const T*>(p.z0) + m * p.z0_stride + pcx * VEC : static_cast<const T*>(p.zero));
+        xr1[it] = global_load16(ok ? static_cast<const T*>(p.z1) + m * p.z1_stride + pcx * VEC : static_cast<const T*>(p.zero));
+    }
+#pragma unroll
+    for (int f = 1; f < D; ++f) ws.fetch(f, f);
+    ws.stash(W0, 0);
+#pragma unroll
+    for (int it = 0; it < CFG::X_IT; ++it) {
+        const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+        *reinterpret_cast<raw16_t*>(X + (size_t)row * XRS + pcx * VEC) = xr0[it];
+        *reinterpret_cast<raw16_t*>(X + (size_t)row * XRS + C + pcx * VEC) = xr1[it];
+    }
+    __syncthreads();
+
+    float16_t accg[CFG::MT][CFG::NTL], accf[CFG::MT][CFG::NTL];                          // second layer: gate / fusion
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accg[i][j][r] = accf[i][j][r] = 0.f;
+
+    const int brow = (wn * CFG::WN + l31) * RS + hi * 8;
+    // one K chunk: acc += Wtile(chunk) . A[:, k0 .. k0 + BK)
+    auto chunk_step = [&](float16_t (&acc)[CFG::MT][CFG::NTL], const T* arow, int ars, int f, int j) __attribute__((always_inline)) {
+        T* wb = (f & 1) ? W1 : W0;                                  // PER_SLICE, K0, K1 and D are even: LDS buffer of chunk j = j & 1 = f & 1
+        T* wnext = (f & 1) ? W0 : W1;
+        if (j + D < CFG::TOTAL) ws.fetch(j + D, f);
+        const T* b = wb + brow;
+#pragma unroll
+        for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+            Frag<T> xf[CFG::MT], wf[CFG::NTL];
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], arow + (size_t)i * 32 * ars + kk * 16);
+#pragma unroll
+            for (int jn = 0; jn < CFG::NTL; ++jn) load_frag(wf[jn], b + (size_t)jn * 32 * RS + kk * 16);
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                for (int jn = 0; jn < CFG::NTL; ++jn) mma32(acc[i][jn], wf[jn], xf[i]);
+        }
+        if (j + 1 < CFG::TOTAL) ws.stash(wnext, (f + 1) % D);
+        __syncthreads();
+    };
+
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+        // ---- first layer, slice s: h[:, sC .. sC + C) = GELU(W1[sC .. sC + C, :] . z + b1)
+        CoutRegs<CFG> b1;
+        b1.load(p.b1 + s * C, p.zero, C, 0, wn, lane);
+        float16_t acc[CFG::MT][CFG::NTL];
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int jbase = s * CFG::PER_SLICE;
+        const T* xrow = X + (size_t)l31 * XRS + hi * 8;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CFG::K0; c0 += D) {
+#pragma unroll
+            for (int f = 0; f < D; ++f) chunk_step(acc, xrow + (c0 + f) * BK, XRS, f, jbase + c0 + f);
+        }
+        stage_tile<CFG, T, S2M2_ACT_GELU>(acc, H, b1, 1.0f, 0, wn, lane);
+        __syncthreads();
+        // ---- second layer, K range s: gate (s == 0) or fusion (s == 1, 2) accumulators += [Wg | Wf][:, sC .. sC + C) . h slice
+        const T* hrow = H + (size_t)l31 * HRS + hi * 8;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CFG::K1; c0 += D) {
+            if (s == 0) {
+#pragma unroll
+                for (int f = 0; f < D; ++f) chunk_step(accg, hrow + (c0 + f) * BK, HRS, f, jbase + CFG::K0 + c0 + f);
+            } else {
+#pragma unroll
+                for (int f = 0; f < D; ++f) chunk_step(accf, hrow + (c0 + f) * BK, HRS, f, jbase + CFG::K0 + c0 + f);
+            }
+        }
+        // (the trailing barrier of the last chunk: every wave is done with the h slice before the next one overwrites it)
+    }
+
+    // ---- epilogue: out = round(round(accf + bf) + round(g * z0 + (1 - g) * z1)), g = clamp(round(sigmoid(accg + bg)), .01, .99)
+    CoutRegs<CFG> bg, bf;
+    bg.load(p.bg, p.zero, C, 0, wn, lane);
+    bf.load(p.bf, p.zero, C, 0, wn, lane);
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i) {
+        const int row = i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cl = wn * CFG::WN + j * 32 + 8 * g4 + 4 * hi;
+                const Quad<T> q0 = *reinterpret_cast<const Quad<T>*>(X + (size_t)row * XRS + cl);
+                const Quad<T> q1 = *reinterpret_cast<const Quad<T>*>(X + (size_t)row * XRS + C + cl);
+                Quad<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gate = to_f32(from_f32<T>(activate<S2M2_ACT_SIGMOID>(accg[i][j][4 * g4 + e] + bg.v[j][g4][e])));
+                    const float gc = fminf(fmaxf(gate, 0.01f), 0.99f);
+                    const float mix = to_f32(from_f32<T>(gc * to_f32(q0.v[e]) + (1.0f - gc) * to_f32(q1.v[e])));
+                    const float fus = to_f32(from_f32<T>(accf[i][j][4 * g4 + e] + bf.v[j][g4][e]));
+                    o.v[e] = from_f32<T>(fus + mix);
+                }
+                *reinterpret_cast<Quad<T>*>(H + (size_t)row * HRS + cl) = o;
+            }
+        }
+    }
+    __syncthreads();
+    T* outp = static_cast<T*>(p.out);
+#pragma unroll
+    for (int it = 0; it < CFG::X_IT; ++it) {
+        const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+        const long long m = m0 + row;
+        if (m < p.rows)
+            *reinterpret_cast<raw16_t*>(outp + m * p.out_stride + pcx * VEC) = *reinterpret_cast<const raw16_t*>(H + (size_t)row * HRS + pcx * VEC);
+    }
+}
+
+static const void* fusion_zero_page() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
+    }
+    return z;
+}
+
+template <typename T, int C, int BM, int NW>
+static int launch_fusion(const FusionArgs& a, hipStream_t st) {
+    using CFG = FusionCfg<T, C, BM, NW>;
+    auto kern = feature_fusion_kernel<CFG, T>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)CFG::LDS_BYTES) != hipSuccess)
+            return set_error("feature_fusion: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.rows + BM - 1) / BM)), dim3(CFG::NT), CFG::LDS_BYTES, st, a);
+    return check_launch("feature_fusion");
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_feature_fusion_supported(int C, int dtype) {
+    return (dtype == S2M2_F16 || dtype == S2M2_F32) && (C == 128 || C == 256);
+}
+
+extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+                                   long long rows, int C, const void* w1, const float* b1, const void* w2, const float* bg,
+                                   const float* bf, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(z0 && z1 && out && w1 && w2 && b1 && bg && bf, "feature_fusion: null pointer");
+    S2M2_REQUIRE(s2m2_feature_fusion_supported(C, dtype), "feature_fusion: C=%d dtype=%d is not supported (C = 128 or 256)", C, dtype);
+    S2M2_REQUIRE(rows > 0 && rows < (1LL << 31), "feature_fusion: rows=%lld", rows);
+    S2M2_REQUIRE(z0_stride >= C && z1_stride >= C && out_stride >= C && z0_stride % 8 == 0 && z1_stride % 8 == 0 && out_stride % 8 == 0,
+                 "feature_fusion: row strides must be multiples of 8 and at least C");
+    FusionArgs a;
+    a.z0 = z0; a.z1 = z1; a.out = out; a.z0_stride = z0_stride; a.z1_stride = z1_stride; a.out_stride = out_stride; a.rows = rows;
+    a.w1 = w1; a.w2 = w2; a.b1 = b1; a.bg = bg; a.bf = bf;
+    a.zero = fusion_zero_page();
+    S2M2_REQUIRE(a.zero, "feature_fusion: cannot allocate the zero page");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // 32-row tiles everywhere: measured end to end (same-box A/B), the 64-row tile of C = 128 needs 234 VGPRs (three accumulator
+    // sets) and runs one block per CU
+    if (dtype == S2M2_F16) {
+        if (C == 128) return launch_fusion<half_t, 128, 32, 4>(a, st);
+        return launch_fusion<half_t, 256, 32, 8>(a, st);
+    }
+    if (C == 128) return launch_fusion<float, 128, 32, 4>(a, st);
+    return launch_fusion<float, 256, 32, 8>(a, st);
+}

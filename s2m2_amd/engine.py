@@ -63,6 +63,8 @@ class Engine:
         self.use_chain = os.environ.get("S2M2_CHAIN", "1") != "0"      # A/B switch: 0 = one K5 launch per 1x1 layer instead of K9 chains
         self._chain_ok: Dict[int, bool] = {}
         self.fuse_stem = os.environ.get("S2M2_FUSE_STEM", "1") != "0"    # A/B switch: 0 = the two full-resolution stem layers as K5 launches
+        self.fuse_fusion = os.environ.get("S2M2_FUSE_FUSION", "1") != "0"  # A/B switch: 0 = FeatureFusion as K5 launches instead of K10
+        self._fusion_ok: Dict[int, bool] = {}
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -184,20 +186,36 @@ class Engine:
         self.join(b, u)
         return self.cconv(self.std(p + ".convs.2"), [t], epi=hip.EPI_ADD, aux0=b)
 
+    def dual_heads(self, p: str):
+        """[gate.2 | fusion.2] stacked along K (the channel order of the hidden tensor) + the two biases"""
+        key = p + "|gate.2+fusion.2"
+        dual = self._packed.get(key)
+        if dual is None:
+            g2, f2 = self.std(p + ".feature_gate.2"), self.std(p + ".feature_fusion.2")
+            dual = self._packed[key] = (torch.cat([g2[0], f2[0]], dim=1).contiguous(), g2[1], f2[1])
+        return dual
+
+    def fusion_ok(self, c: int) -> bool:
+        ok = self._fusion_ok.get(c)
+        if ok is None:
+            ok = self._fusion_ok[c] = hip.feature_fusion_supported(c, self.dtype)
+        return ok
+
     def fusion(self, p: str, z0: Tensor, z1: Tensor) -> Tensor:
         """FeatureFusion (feature_fusion.py:4-33): out = fusion(z) + g*z0 + (1-g)*z1, g = clamp(sigmoid(gate(z)), .01, .99).
         Both first layers read cat(z0, z1): one GEMM; the gate mix and the final add are epilogues."""
         c = z0.shape[-1]
         cg = self.p[p + ".feature_gate.0.weight"].shape[0]
         spec = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
+        rows = z0.numel() // c
+        if (self.fuse_fusion and spec[2] == 1 and spec[3] == 1 and cg == c and self.fusion_ok(c)
+                and (c <= 128 or rows <= 8192)):              # wide rows in bulk (C = 256 at 1/16 x 2 images): the two K5 launches are faster
+            dual = self.dual_heads(p)                              # K10: the whole block in one launch, h never leaves the CU
+            return hip.feature_fusion(z0, z1, spec[0], spec[1], dual[0], dual[1], dual[2])
         gf = self.cconv(spec, [z0, z1], act=hip.ACT_GELU)
         if self.fuse_heads and cg % 64 == 0:
             # both second layers in one launch: weight rows [gate.2 | fusion.2] along K (= the channel order of gf), two accumulators
-            key = p + "|gate.2+fusion.2"
-            dual = self._packed.get(key)
-            if dual is None:
-                g2, f2 = self.std(p + ".feature_gate.2"), self.std(p + ".feature_fusion.2")
-                dual = self._packed[key] = (torch.cat([g2[0], f2[0]], dim=1).contiguous(), g2[1], f2[1])
+            dual = self.dual_heads(p)
             return hip.conv2d([gf], dual[0], dual[1], 1, 1, dual[0].shape[0], act=hip.ACT_SIGMOID, epi=hip.EPI_DUALMIX, aux0=z0, aux1=z1,
                               ksplit=cg, bias2=dual[2])
         m = self.cconv(self.std(p + ".feature_gate.2"), [gf[..., :cg]], act=hip.ACT_SIGMOID, epi=hip.EPI_GATEMIX, aux0=z0, aux1=z1)

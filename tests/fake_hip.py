@@ -83,6 +83,15 @@ def make():
             t = y
         return t.to(x.dtype)
 
+    def feature_fusion_supported(C, dtype):
+        return C in (128, 256)
+
+    def feature_fusion(z0, z1, w1, b1, w2, bg, bf):
+        C = z0.shape[-1]
+        h = F.gelu(F.linear(torch.cat([z0.float(), z1.float()], -1), w1.float(), b1))
+        g = torch.sigmoid(F.linear(h[..., :C], w2.float()[:, :C], bg)).clamp(0.01, 0.99)
+        return (F.linear(h[..., C:], w2.float()[:, C:], bf) + g * z0.float() + (1 - g) * z1.float()).to(z0.dtype)
+
     def stem_mlp(x8, w0, b0, w1, b1):
         return F.linear(F.gelu(F.linear(x8.float(), w0, b0)), w1, b1).to(x8.dtype)
 
@@ -170,6 +179,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, stem_mlp):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
     return ns

@@ -1,0 +1,68 @@
+"""GPU parity of K10 (s2m2_feature_fusion: FeatureFusion with 1x1 kernels in one launch, feature_fusion.py:4-33) against the fp32
+formula (intermediates rounded to the I/O dtype where the kernel rounds them) and against the K5 launches it replaces.
+
+Tolerances: fp32 -- exact-fp32 MFMA chains vs torch's summation order through two layers: 2e-4 absolute on O(1-3) values.
+fp16 -- h, the gate, the mix and the fusion term are rounded to fp16 and h feeds the second GEMM: 1.5e-2 absolute."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from s2m2_amd import pack
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from s2m2_amd import hip as h
+    h.load()
+    return h
+
+
+def _weights(C, dtype, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    w1 = (torch.randn(3 * C, 2 * C, 1, 1, device="cuda", generator=g) / math.sqrt(2 * C)).to(dtype)
+    wg = (torch.randn(C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+    wf = (torch.randn(C, 2 * C, 1, 1, device="cuda", generator=g) / math.sqrt(2 * C)).to(dtype)
+    b1, bg, bf = (torch.randn(n, device="cuda", generator=g) * 0.5 for n in (3 * C, C, C))
+    return w1, wg, wf, b1, bg, bf
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(128, (2, 50, 61)), (128, (1, 256, 40)), (128, (1, 1, 1)), (256, (2, 32, 38)), (256, (1, 9, 7))])
+def test_feature_fusion_vs_torch_and_k5(hip, dtype, shape):
+    C, shp = shape
+    assert hip.feature_fusion_supported(C, dtype)
+    g = torch.Generator(device="cuda").manual_seed(C + shp[1])
+    wide = torch.randn(*shp, 2 * C + 8, device="cuda", generator=g).to(dtype)
+    z0 = wide[..., :C]                                            # strided rows (a channel slice of a wider tensor)
+    z1 = (torch.randn(*shp, C, device="cuda", generator=g) * 1.5).to(dtype)
+    w1, wg, wf, b1, bg, bf = _weights(C, dtype, 11 * C)
+    p1 = pack.pack_conv(w1, dtype)
+    p2 = torch.cat([pack.pack_conv(wg, dtype), pack.pack_conv(wf, dtype)], dim=1).contiguous()
+    y = hip.feature_fusion(z0, z1, p1, pack.pack_bias(b1, 3 * C), p2, pack.pack_bias(bg, C), pack.pack_bias(bf, C))
+    assert y.shape == z1.shape and y.dtype == dtype
+
+    def rd(t):
+        return t.to(dtype).float()
+    h = rd(F.gelu(F.linear(torch.cat([z0.float(), z1.float()], -1), w1.float().reshape(3 * C, 2 * C), b1)))
+    gate = rd(torch.sigmoid(F.linear(h[..., :C], wg.float().reshape(C, C), bg))).clamp(0.01, 0.99)
+    ref = rd(rd(F.linear(h[..., C:], wf.float().reshape(C, 2 * C), bf)) + rd(gate * z0.float() + (1 - gate) * z1.float()))
+    tol = 2e-4 if dtype == torch.float32 else 1.5e-2
+    assert float((y.float() - ref).abs().max()) < tol
+    # the launches it replaces: K5 (concat + GELU), K5 dual-GEMM gate mix
+    z0c = z0.contiguous()
+    gf = hip.conv2d([z0c.reshape(1, 1, -1, C), z1.reshape(1, 1, -1, C)], p1, pack.pack_bias(b1, 3 * C), 1, 1, 3 * C, act=hip.ACT_GELU)
+    y2 = hip.conv2d([gf], p2, pack.pack_bias(bg, C), 1, 1, C, act=hip.ACT_SIGMOID, epi=hip.EPI_DUALMIX, aux0=z0c.reshape(1, 1, -1, C),
+                    aux1=z1.reshape(1, 1, -1, C), ksplit=C, bias2=pack.pack_bias(bf, C))
+    assert float((y.float().reshape(-1) - y2.float().reshape(-1)).abs().max()) < tol
+
+
+def test_feature_fusion_rejects_unsupported_width(hip):
+    assert not hip.feature_fusion_supported(192, torch.float16)
+    z = torch.zeros(4, 192, device="cuda").half()
+    with pytest.raises(RuntimeError, match="not supported"):
+        hip.feature_fusion(z, z, torch.zeros(576, 384, device="cuda").half(), torch.zeros(576, device="cuda"),
+                           torch.zeros(192, 576, device="cuda").half(), torch.zeros(192, device="cuda"), torch.zeros(192, device="cuda"))
