@@ -280,7 +280,7 @@ extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, lo
     // sets) and runs one block per CU
     if (dtype == S2M2_F16) {
         if (C == 128) return launch_fusion<half_t, 128, 32, 4>(a, st);
-        return launch_fusion<half_t, 256, 32, 8>(a, st);
+        return rows > 8192 ? launch_fusion<half_t, 256, 64, 8>(a, st) : launch_fusion<half_t, 256, 32, 8>(a, st);   // bulk rows: 64-row tiles (weights streamed once per 64 rows)
     }
     if (C == 128) return launch_fusion<float, 128, 32, 4>(a, st);
     return launch_fusion<float, 256, 32, 8>(a, st);

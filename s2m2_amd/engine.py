@@ -207,9 +207,7 @@ class Engine:
         c = z0.shape[-1]
         cg = self.p[p + ".feature_gate.0.weight"].shape[0]
         spec = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
-        rows = z0.numel() // c
-        if (self.fuse_fusion and spec[2] == 1 and spec[3] == 1 and cg == c and self.fusion_ok(c)
-                and (c <= 128 or rows <= 8192)):              # wide rows in bulk (C = 256 at 1/16 x 2 images): the two K5 launches are faster
+        if self.fuse_fusion and spec[2] == 1 and spec[3] == 1 and cg == c and self.fusion_ok(c):
             dual = self.dual_heads(p)                              # K10: the whole block in one launch, h never leaves the CU
             return hip.feature_fusion(z0, z1, spec[0], spec[1], dual[0], dual[1], dual[2])
         gf = self.cconv(spec, [z0, z1], act=hip.ACT_GELU)

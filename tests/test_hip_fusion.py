@@ -31,7 +31,7 @@ def _weights(C, dtype, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
-@pytest.mark.parametrize("shape", [(128, (2, 50, 61)), (128, (1, 256, 40)), (128, (1, 1, 1)), (256, (2, 32, 38)), (256, (1, 9, 7))])
+@pytest.mark.parametrize("shape", [(128, (2, 50, 61)), (128, (1, 256, 40)), (128, (1, 1, 1)), (256, (2, 32, 38)), (256, (1, 9, 7)), (256, (2, 64, 76))])
 def test_feature_fusion_vs_torch_and_k5(hip, dtype, shape):
     C, shp = shape
     assert hip.feature_fusion_supported(C, dtype)
