@@ -37,11 +37,12 @@ struct ChainArgs {
     const void* zero;
 };
 
-template <typename T, int C_, int BM_, int NST_, int NW_>
+template <typename T, int C_, int BM_, int NST_, int NW_, int WP_ = 4>
 struct ChainCfg {
     static constexpr int C = C_, BM = BM_, NST = NST_, NW = NW_, NT = 64 * NW_;
+    static constexpr int WP = WP_;                        // 16-byte pieces per weight row and chunk: 4 (64-byte K chunks) or 8 (128-byte)
     static constexpr int VEC = 16 / sizeof(T);
-    static constexpr int BK = 4 * VEC;                    // K elements per chunk: 64 bytes per weight row
+    static constexpr int BK = WP * VEC;                   // K elements per chunk
     static constexpr int RS = BK + VEC;                   // weight tile row stride in LDS (80 bytes: conflict-free b128 reads)
     static constexpr int KSTEPS = BK / 16;
     static constexpr int ARS = C + VEC;                   // activation tile row stride (16 bytes of padding)
@@ -51,8 +52,8 @@ struct ChainCfg {
 #ifndef S2M2_CHAIN_DEPTH8
 #define S2M2_CHAIN_DEPTH8 1
 #endif
-    static constexpr int D = (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;   // weight chunks in flight
-    static constexpr int WROWS = NT / 4;                  // weight rows covered by one pass of the loader threads (4 pieces per row)
+    static constexpr int D = WP == 8 ? 2 : (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;   // weight chunks in flight
+    static constexpr int WROWS = NT / WP;                 // weight rows covered by one pass of the loader threads (WP pieces per row)
     static constexpr int B_IT = C / WROWS;                // 16-byte weight pieces per thread and chunk
     static constexpr int PPR = C / VEC;                   // 16-byte pieces per activation row
     static constexpr int X_IT = BM * PPR / NT;            // activation pieces per thread
@@ -72,7 +73,7 @@ struct ChainStream {
 
     __device__ __forceinline__ void init(const ChainArgs& p, int tid) {
         w0 = static_cast<const T*>(p.w[0]); w1 = static_cast<const T*>(p.w[1]); w2 = static_cast<const T*>(p.w[2]);
-        lrow = tid >> 2; pc = tid & 3;
+        lrow = tid / CFG::WP; pc = tid % CFG::WP;
         off = lrow * CFG::C + pc * CFG::VEC;
     }
     __device__ __forceinline__ void fetch(int j, int SLOT) {                  // j is block-uniform; SLOT is static after unrolling
@@ -279,9 +280,9 @@ static const void* chain_zero_page() {
     return z;
 }
 
-template <typename T, int C, int BM, int NST, int NW>
+template <typename T, int C, int BM, int NST, int NW, int WP = 4>
 static int launch_chain(const ChainArgs& a, hipStream_t st) {
-    using CFG = ChainCfg<T, C, BM, NST, NW>;
+    using CFG = ChainCfg<T, C, BM, NST, NW, WP>;
     auto kern = mlp_chain_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -294,11 +295,11 @@ static int launch_chain(const ChainArgs& a, hipStream_t st) {
     return check_launch("mlp_chain");
 }
 
-template <typename T, int C, int BM, int NW>
+template <typename T, int C, int BM, int NW, int WP = 4>
 static int launch_chain_n(const ChainArgs& a, int nst, hipStream_t st) {
-    if (nst == 1) return launch_chain<T, C, BM, 1, NW>(a, st);
-    if (nst == 2) return launch_chain<T, C, BM, 2, NW>(a, st);
-    return launch_chain<T, C, BM, 3, NW>(a, st);
+    if (nst == 1) return launch_chain<T, C, BM, 1, NW, WP>(a, st);
+    if (nst == 2) return launch_chain<T, C, BM, 2, NW, WP>(a, st);
+    return launch_chain<T, C, BM, 3, NW, WP>(a, st);
 }
 
 }  // namespace s2m2
@@ -344,11 +345,15 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     static const char* force = getenv("S2M2_CHAIN_CFG");          // tuning only: "s" (32-row tiles) / "m" (64-row tiles)
     char cfg = d->rows <= 8192 ? 's' : 'm';                       // at most one 32-row tile per CU: short tiles, more CUs busy (measured: tools/chainbench.py)
     if (force && *force) cfg = *force;
+    static const bool wide = getenv("S2M2_CHAIN_CHUNK128") != nullptr;   // A/B switch: 128-byte K chunks
     if (d->dtype == S2M2_F16) {
         switch (d->C) {
-            case 128: return cfg == 's' ? launch_chain_n<half_t, 128, 32, 4>(a, d->nstage, st) : launch_chain_n<half_t, 128, 64, 4>(a, d->nstage, st);
-            case 256: return cfg == 's' ? launch_chain_n<half_t, 256, 32, 8>(a, d->nstage, st)
-                                                : launch_chain_n<half_t, 256, 64, 8>(a, d->nstage, st);
+            case 128:
+                if (wide) return cfg == 's' ? launch_chain_n<half_t, 128, 32, 4, 8>(a, d->nstage, st) : launch_chain_n<half_t, 128, 64, 4, 8>(a, d->nstage, st);
+                return cfg == 's' ? launch_chain_n<half_t, 128, 32, 4>(a, d->nstage, st) : launch_chain_n<half_t, 128, 64, 4>(a, d->nstage, st);
+            case 256:
+                if (wide) return cfg == 's' ? launch_chain_n<half_t, 256, 32, 8, 8>(a, d->nstage, st) : launch_chain_n<half_t, 256, 64, 8, 8>(a, d->nstage, st);
+                return cfg == 's' ? launch_chain_n<half_t, 256, 32, 8>(a, d->nstage, st) : launch_chain_n<half_t, 256, 64, 8>(a, d->nstage, st);
             case 384: return launch_chain_n<half_t, 384, 32, 4>(a, d->nstage, st);
             default: return launch_chain_n<half_t, 512, 32, 8>(a, d->nstage, st);
         }

@@ -33,11 +33,13 @@ struct FusionArgs {
     const void* zero;
 };
 
-template <typename T, int C_, int BM_, int NW_>
+template <typename T, int C_, int BM_, int NW_, int WP_ = 4>
 struct FusionCfg {
-    static constexpr int C = C_, BM = BM_, NW = NW_, NT = 64 * NW_, D = 4;
+    static constexpr int C = C_, BM = BM_, NW = NW_, NT = 64 * NW_;
+    static constexpr int WP = WP_;                        // 16-byte pieces per weight row and chunk: 4 (64-byte K chunks) or 8 (128-byte)
+    static constexpr int D = WP == 8 ? 2 : 4;             // chunks in flight (the same bytes either way)
     static constexpr int VEC = 16 / sizeof(T);
-    static constexpr int BK = 4 * VEC;                    // K elements per chunk (64 bytes per weight row)
+    static constexpr int BK = WP * VEC;                   // K elements per chunk
     static constexpr int RS = BK + VEC;                   // weight tile row stride in LDS
     static constexpr int KSTEPS = BK / 16;
     static constexpr int XRS = 2 * C + VEC;               // z0 | z1 tile row stride
@@ -48,7 +50,7 @@ struct FusionCfg {
     static constexpr int K1 = C / BK;                     // chunks of one second-layer K range
     static constexpr int PER_SLICE = K0 + K1;
     static constexpr int TOTAL = 3 * PER_SLICE;
-    static constexpr int WROWS = NT / 4;
+    static constexpr int WROWS = NT / WP;
     static constexpr int B_IT = C / WROWS;
     static constexpr int PPR = C / VEC;                   // 16-byte pieces per C-wide row
     static constexpr int X_IT = BM * PPR / NT;            // pieces per thread for one C-wide tile
@@ -70,7 +72,7 @@ struct FusionStream {
     int lrow, pc;
     __device__ __forceinline__ void init(const FusionArgs& p, int tid) {
         w1 = static_cast<const T*>(p.w1); w2 = static_cast<const T*>(p.w2);
-        lrow = tid >> 2; pc = tid & 3;
+        lrow = tid / CFG::WP; pc = tid % CFG::WP;
     }
     __device__ __forceinline__ void fetch(int j, int SLOT) {      // j block-uniform, SLOT static after unrolling
         const int s = j / CFG::PER_SLICE, rr = j - s * CFG::PER_SLICE;
@@ -240,9 +242,9 @@ static const void* fusion_zero_page() {
     return z;
 }
 
-template <typename T, int C, int BM, int NW>
+template <typename T, int C, int BM, int NW, int WP = 4>
 static int launch_fusion(const FusionArgs& a, hipStream_t st) {
-    using CFG = FusionCfg<T, C, BM, NW>;
+    using CFG = FusionCfg<T, C, BM, NW, WP>;
     auto kern = feature_fusion_kernel<CFG, T>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -276,11 +278,13 @@ extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, lo
     a.zero = fusion_zero_page();
     S2M2_REQUIRE(a.zero, "feature_fusion: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // 32-row tiles everywhere: measured end to end (same-box A/B), the 64-row tile of C = 128 needs 234 VGPRs (three accumulator
-    // sets) and runs one block per CU
+    // measured end to end (same-box A/B): 32-row tiles (the 64-row tile of C = 128 needs 234 VGPRs for its three accumulator sets
+    // and runs one block per CU); 128-byte K chunks (half the barriers of 64-byte chunks, +1.3 %) wherever the tile still fits
+    static const bool narrow = getenv("S2M2_FUSION_CHUNK64") != nullptr;   // A/B switch
     if (dtype == S2M2_F16) {
-        if (C == 128) return launch_fusion<half_t, 128, 32, 4>(a, st);
-        return rows > 8192 ? launch_fusion<half_t, 256, 64, 8>(a, st) : launch_fusion<half_t, 256, 32, 8>(a, st);   // bulk rows: 64-row tiles (weights streamed once per 64 rows)
+        if (C == 128) return narrow ? launch_fusion<half_t, 128, 32, 4>(a, st) : launch_fusion<half_t, 128, 32, 4, 8>(a, st);
+        if (rows > 8192) return launch_fusion<half_t, 256, 64, 8>(a, st);   // bulk rows: 64-row tiles (weights streamed once per 64 rows)
+        return narrow ? launch_fusion<half_t, 256, 32, 8>(a, st) : launch_fusion<half_t, 256, 32, 8, 8>(a, st);
     }
     if (C == 128) return launch_fusion<float, 128, 32, 4>(a, st);
     return launch_fusion<float, 256, 32, 8>(a, st);
