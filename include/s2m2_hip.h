@@ -169,11 +169,14 @@ int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
  *   z0, z1, out: `rows` token rows of C channels (row strides in elements, multiples of 8), dtype `dtype`;
  *   w1 packed (3C, 2C): rows [0,C) = feature_gate.0, rows [C,3C) = feature_fusion.0;  w2 packed (C, 3C) = [Wg (C,C) | Wf (C,2C)]
  *   along K;  b1 (3C), bg (C), bf (C) fp32.  C = 128 or 256: ask s2m2_feature_fusion_supported.
+ *   z1_coarse_h / z1_coarse_w > 0: z1 is the COARSE tensor (N, z1_coarse_h, z1_coarse_w, C) and the kernel reads it through
+ *   nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) (unet.py:32-37: the up_conv feeding every decoder fusion);
+ *   rows = N * 2*z1_coarse_h * 2*z1_coarse_w in raster order.  0 / 0: z1 has one row per output row.
  */
 int s2m2_feature_fusion_supported(int C, int dtype);
 int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
                         long long rows, int C, const void* w1, const float* b1, const void* w2, const float* bg, const float* bf,
-                        int dtype, void* stream);
+                        int z1_coarse_h, int z1_coarse_w, int dtype, void* stream);
 
 /*
  * [A2,A3] pre-norm LayerNorm without affine over the channel axis (attentions.py:117,148,182,213,243; eps 1e-5, biased var).

@@ -31,6 +31,7 @@ struct FusionArgs {
     const float* bg;         // C
     const float* bf;         // C
     const void* zero;
+    int up_h, up_w;          // > 0: z1 is the COARSE (N, up_h, up_w, C) tensor, read through the bilinear x2 resampling (nn.Upsample, align_corners=False)
 };
 
 template <typename T, int C_, int BM_, int NW_, int WP_ = 4>
@@ -116,7 +117,32 @@ __global__ __launch_bounds__(CFG::NT) void feature_fusion_kernel(FusionArgs p) {
         const long long m = m0 + row;
         const bool ok = m < p.rows;
         xr0[it] = global_load16(ok ? static_cast<const T*>(p.z0) + m * p.z0_stride + pcx * VEC : static_cast<const T*>(p.zero));
-        xr1[it] = global_load16(ok ? static_cast<const T*>(p.z1) + m * p.z1_stride + pcx * VEC : static_cast<const T*>(p.zero));
+        if (p.up_h == 0) {
+            xr1[it] = global_load16(ok ? static_cast<const T*>(p.z1) + m * p.z1_stride + pcx * VEC : static_cast<const T*>(p.zero));
+        } else {
+            // the x2 bilinear resampling of K7 (upsample.hip, same arithmetic and rounding) folded into the tile load: row m = (n, Y, X) of
+            // the fine grid reads its four coarse neighbours
+            const int Wo = 2 * p.up_w, Ho = 2 * p.up_h;
+            const long long mm = ok ? m : 0;
+            const int Xf = (int)(mm % Wo);
+            const long long t = mm / Wo;
+            const int Yf = (int)(t % Ho);
+            const long long n = t / Ho;
+            const float sy = fmaxf(((float)Yf + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf(((float)Xf + 0.5f) * 0.5f - 0.5f, 0.f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < p.up_h - 1), x1 = x0 + (x0 < p.up_w - 1);
+            const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+            const T* zb = static_cast<const T*>(p.z1) + n * p.up_h * p.up_w * p.z1_stride + pcx * VEC;
+            const Vec16<T> a = __builtin_bit_cast(Vec16<T>, global_load16(zb + ((long long)y0 * p.up_w + x0) * p.z1_stride));
+            const Vec16<T> b = __builtin_bit_cast(Vec16<T>, global_load16(zb + ((long long)y0 * p.up_w + x1) * p.z1_stride));
+            const Vec16<T> c = __builtin_bit_cast(Vec16<T>, global_load16(zb + ((long long)y1 * p.up_w + x0) * p.z1_stride));
+            const Vec16<T> d = __builtin_bit_cast(Vec16<T>, global_load16(zb + ((long long)y1 * p.up_w + x1) * p.z1_stride));
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                o.v[e] = from_f32<T>(hy * (hx * to_f32(a.v[e]) + lx * to_f32(b.v[e])) + ly * (hx * to_f32(c.v[e]) + lx * to_f32(d.v[e])));
+            xr1[it] = __builtin_bit_cast(raw16_t, o);
+        }
     }
 #pragma unroll
     for (int f = 1; f < D; ++f) ws.fetch(f, f);
@@ -265,7 +291,7 @@ extern "C" int s2m2_feature_fusion_supported(int C, int dtype) {
 
 extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
                                    long long rows, int C, const void* w1, const float* b1, const void* w2, const float* bg,
-                                   const float* bf, int dtype, void* stream) {
+                                   const float* bf, int z1_coarse_h, int z1_coarse_w, int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(z0 && z1 && out && w1 && w2 && b1 && bg && bf, "feature_fusion: null pointer");
     S2M2_REQUIRE(s2m2_feature_fusion_supported(C, dtype), "feature_fusion: C=%d dtype=%d is not supported (C = 128 or 256)", C, dtype);
@@ -275,6 +301,9 @@ extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, lo
     FusionArgs a;
     a.z0 = z0; a.z1 = z1; a.out = out; a.z0_stride = z0_stride; a.z1_stride = z1_stride; a.out_stride = out_stride; a.rows = rows;
     a.w1 = w1; a.w2 = w2; a.b1 = b1; a.bg = bg; a.bf = bf;
+    a.up_h = z1_coarse_h; a.up_w = z1_coarse_w;
+    S2M2_REQUIRE((z1_coarse_h == 0 && z1_coarse_w == 0) || (z1_coarse_h > 0 && z1_coarse_w > 0 && rows % (4LL * z1_coarse_h * z1_coarse_w) == 0),
+                 "feature_fusion: rows=%lld is not a whole number of (2*%d) x (2*%d) images", rows, z1_coarse_h, z1_coarse_w);
     a.zero = fusion_zero_page();
     S2M2_REQUIRE(a.zero, "feature_fusion: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);

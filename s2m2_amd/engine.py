@@ -63,6 +63,7 @@ class Engine:
         self.use_chain = os.environ.get("S2M2_CHAIN", "1") != "0"      # A/B switch: 0 = one K5 launch per 1x1 layer instead of K9 chains
         self._chain_ok: Dict[int, bool] = {}
         self.fuse_stem = os.environ.get("S2M2_FUSE_STEM", "1") != "0"    # A/B switch: 0 = the two full-resolution stem layers as K5 launches
+        self.fuse_up = os.environ.get("S2M2_FUSE_UP", "1") != "0"        # A/B switch: 0 = stand-alone bilinear resample before the decoder fusions
         self.fuse_fusion = os.environ.get("S2M2_FUSE_FUSION", "1") != "0"  # A/B switch: 0 = FeatureFusion as K5 launches instead of K10
         self._fusion_ok: Dict[int, bool] = {}
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
@@ -201,6 +202,18 @@ class Engine:
             ok = self._fusion_ok[c] = hip.feature_fusion_supported(c, self.dtype)
         return ok
 
+    def fusion_up(self, p: str, z0: Tensor, pu: str, xc: Tensor) -> Tensor:
+        """fusion(z0, up_conv(xc)) of the decoders (unet.py:98-110, stacked_MRT.py:113-121): the 1x1 up_conv runs on the coarse grid
+        (see up()) and K10 reads its output through the bilinear resampling -- no stand-alone K7 launch, no upsampled tensor."""
+        spec = self.std(pu + ".1")
+        c = z0.shape[-1]
+        first = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
+        if (self.fuse_fusion and self.fuse_up and spec[2] == 1 and spec[3] == 1 and spec[4] == c and first[2] == 1 and first[3] == 1
+                and self.p[p + ".feature_gate.0.weight"].shape[0] == c and self.fusion_ok(c)):
+            dual = self.dual_heads(p)
+            return hip.feature_fusion(z0, self.cconv(spec, [xc]), first[0], first[1], dual[0], dual[1], dual[2], z1_coarse=True)
+        return self.fusion(p, z0, self.up(pu, xc))
+
     def fusion(self, p: str, z0: Tensor, z1: Tensor) -> Tensor:
         """FeatureFusion (feature_fusion.py:4-33): out = fusion(z) + g*z0 + (1-g)*z1, g = clamp(sigmoid(gate(z)), .01, .99).
         Both first layers read cat(z0, z1): one GEMM; the gate mix and the final add are epilogues."""
@@ -299,9 +312,9 @@ class Engine:
             z3 = self.attn_block(f"{p}.enc3s.{i}", z3, 8, True, use_pe)
         for i in range(self._count(p + ".dec3s")):
             z3 = self.attn_block(f"{p}.dec3s.{i}", z3, 8, True, False)
-        n2 = self.conv_block(p + ".dec2", self.fusion(p + ".concat_conv2", z2, self.up(p + ".up_conv2", z3)))
-        n1 = self.conv_block(p + ".dec1", self.fusion(p + ".concat_conv1", z1, self.up(p + ".up_conv1", n2)))
-        n0 = self.conv_block(p + ".dec0", self.fusion(p + ".concat_conv0", z0, self.up(p + ".up_conv0", n1)))
+        n2 = self.conv_block(p + ".dec2", self.fusion_up(p + ".concat_conv2", z2, p + ".up_conv2", z3))
+        n1 = self.conv_block(p + ".dec1", self.fusion_up(p + ".concat_conv1", z1, p + ".up_conv1", n2))
+        n0 = self.conv_block(p + ".dec0", self.fusion_up(p + ".concat_conv0", z0, p + ".up_conv0", n1))
         return n0, n1, n2, z3
 
     def mrt(self, p: str, z0: Tensor, z1: Tensor, z2: Tensor, z3: Tensor):
@@ -313,9 +326,9 @@ class Engine:
             z3 = self.attn_block(f"{p}.enc_attn3s.{i}", z3, 8, True)
         for i in range(2):
             z3 = self.attn_block(f"{p}.dec_attn3s.{i}", z3, 8, True)
-        z2 = self.attn_block(p + ".dec_attn2", self.fusion(p + ".up_concat2", z2, self.up(p + ".up_conv2", z3)), 4, False)
-        z1 = self.attn_block(p + ".dec_attn1", self.fusion(p + ".up_concat1", z1, self.up(p + ".up_conv1", z2)), 2, False)
-        z0 = self.attn_block(p + ".dec_attn0", self.fusion(p + ".up_concat0", z0, self.up(p + ".up_conv0", z1)), 1, False)
+        z2 = self.attn_block(p + ".dec_attn2", self.fusion_up(p + ".up_concat2", z2, p + ".up_conv2", z3), 4, False)
+        z1 = self.attn_block(p + ".dec_attn1", self.fusion_up(p + ".up_concat1", z1, p + ".up_conv1", z2), 2, False)
+        z0 = self.attn_block(p + ".dec_attn0", self.fusion_up(p + ".up_concat0", z0, p + ".up_conv0", z1), 1, False)
         return z0, z1, z2, z3
 
     # ---- refiners ------------------------------------------------------------------------------------

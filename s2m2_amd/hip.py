@@ -55,7 +55,7 @@ SIGNATURES = {
     "s2m2_mlp_chain_supported": (_i, [_i, _i]),
     "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
     "s2m2_feature_fusion_supported": (_i, [_i, _i]),
-    "s2m2_feature_fusion": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "s2m2_feature_fusion": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _ll, _i, _vp]),
     "s2m2_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _ll,
                             _i, _i, _i, _vp]),
@@ -284,11 +284,19 @@ def feature_fusion_supported(C: int, dtype: torch.dtype) -> bool:
 
 
 def feature_fusion(z0: torch.Tensor, z1: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, bg: torch.Tensor,
-                   bf: torch.Tensor) -> torch.Tensor:
+                   bf: torch.Tensor, z1_coarse: bool = False) -> torch.Tensor:
     """FeatureFusion with 1x1 kernels in one launch (s2m2_feature_fusion): z0, z1 (..., C); w1 packed (3C, 2C) = [gate.0; fusion.0],
-    w2 packed (C, 3C) = [gate.2 | fusion.2]; biases fp32."""
+    w2 packed (C, 3C) = [gate.2 | fusion.2]; biases fp32.  z1_coarse: z0 is (N, 2h, 2w, C) and z1 the coarse (N, h, w, C) tensor,
+    read through the bilinear x2 resampling."""
     C = z0.shape[-1]
-    if z1.shape != z0.shape or z1.dtype != z0.dtype:
+    if z1.dtype != z0.dtype or z1.shape[-1] != C:
+        raise ValueError("feature_fusion: z0 and z1 must match")
+    hc = wc = 0
+    if z1_coarse:
+        if z0.dim() != 4 or z1.dim() != 4 or tuple(z0.shape[:3]) != (z1.shape[0], 2 * z1.shape[1], 2 * z1.shape[2]):
+            raise ValueError("feature_fusion: z1_coarse needs z0 (N,2h,2w,C) and z1 (N,h,w,C)")
+        hc, wc = z1.shape[1], z1.shape[2]
+    elif z1.shape != z0.shape:
         raise ValueError("feature_fusion: z0 and z1 must match")
     if tuple(w1.shape) != (3 * C, 2 * C) or tuple(w2.shape) != (C, 3 * C) or w1.dtype != z0.dtype or w2.dtype != z0.dtype:
         raise ValueError(f"feature_fusion: w1 must be ({3 * C}, {2 * C}) and w2 ({C}, {3 * C}) in {z0.dtype}")
@@ -300,7 +308,7 @@ def feature_fusion(z0: torch.Tensor, z1: torch.Tensor, w1: torch.Tensor, b1: tor
     _, s1 = _token_rows(z1, "feature_fusion")
     out = torch.empty(z0.shape, device=z0.device, dtype=z0.dtype)
     _check(load().s2m2_feature_fusion(z0.data_ptr(), z1.data_ptr(), out.data_ptr(), s0, s1, C, rows, C, w1.data_ptr(), b1.data_ptr(),
-                                      w2.data_ptr(), bg.data_ptr(), bf.data_ptr(), _DT[z0.dtype], _stream()), "s2m2_feature_fusion")
+                                      w2.data_ptr(), bg.data_ptr(), bf.data_ptr(), hc, wc, _DT[z0.dtype], _stream()), "s2m2_feature_fusion")
     return out
 
 

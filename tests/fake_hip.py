@@ -86,8 +86,10 @@ def make():
     def feature_fusion_supported(C, dtype):
         return C in (128, 256)
 
-    def feature_fusion(z0, z1, w1, b1, w2, bg, bf):
+    def feature_fusion(z0, z1, w1, b1, w2, bg, bf, z1_coarse=False):
         C = z0.shape[-1]
+        if z1_coarse:
+            z1 = F.interpolate(z1.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).to(z0.dtype)
         h = F.gelu(F.linear(torch.cat([z0.float(), z1.float()], -1), w1.float(), b1))
         g = torch.sigmoid(F.linear(h[..., :C], w2.float()[:, :C], bg)).clamp(0.01, 0.99)
         return (F.linear(h[..., C:], w2.float()[:, C:], bf) + g * z0.float() + (1 - g) * z1.float()).to(z0.dtype)

@@ -66,3 +66,24 @@ def test_feature_fusion_rejects_unsupported_width(hip):
     with pytest.raises(RuntimeError, match="not supported"):
         hip.feature_fusion(z, z, torch.zeros(576, 384, device="cuda").half(), torch.zeros(576, device="cuda"),
                            torch.zeros(192, 576, device="cuda").half(), torch.zeros(192, device="cuda"), torch.zeros(192, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(128, (2, 13, 21)), (256, (1, 16, 19)), (128, (1, 1, 1))])
+def test_feature_fusion_reads_z1_through_the_bilinear_upsampling(hip, dtype, shape):
+    """z1_coarse: K10 fed with the coarse tensor == K7 resample2x (nn.Upsample bilinear x2, align_corners=False) followed by K10,
+    bit for bit (same arithmetic, same rounding point), and the torch interpolation within rounding."""
+    C, (n, hc, wc) = shape
+    g = torch.Generator(device="cuda").manual_seed(C + hc)
+    z0 = torch.randn(n, 2 * hc, 2 * wc, C, device="cuda", generator=g).to(dtype)
+    zc = torch.randn(n, hc, wc, C, device="cuda", generator=g).to(dtype)
+    w1, wg, wf, b1, bg, bf = _weights(C, dtype, 5 * C)
+    p1 = pack.pack_conv(w1, dtype)
+    p2 = torch.cat([pack.pack_conv(wg, dtype), pack.pack_conv(wf, dtype)], dim=1).contiguous()
+    args = (p1, pack.pack_bias(b1, 3 * C), p2, pack.pack_bias(bg, C), pack.pack_bias(bf, C))
+    y = hip.feature_fusion(z0, zc, *args, z1_coarse=True)
+    up = hip.resample2x(zc, 1)
+    y2 = hip.feature_fusion(z0, up, *args)
+    assert torch.equal(y, y2)
+    ref_up = F.interpolate(zc.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+    assert float((up.float() - ref_up).abs().max()) < (1e-5 if dtype == torch.float32 else 4e-3)
