@@ -20,8 +20,8 @@
 #include <stdlib.h>
 
 // compile-time ablation switches (tools/conv_ablate.py; never set in the shipped library):
-// 1 no global loads inside the K loop, 2 no MFMA, 4 no LDS stash inside the loop, 8 no fragment reads,
-// 16 no bias/activation math, 32 no global stores, 64 no K loop at all
+// 2 no MFMA, 8 no fragment reads, 16 no bias/activation math, 32 no global stores, 64 no K loop at all
+// (1 = no global loads / 4 = no LDS stash inside the K loop were retired with the uniform fetch/stash loop)
 #ifndef S2M2_CONV_DBG
 #define S2M2_CONV_DBG 0
 #endif

@@ -473,7 +473,7 @@ class Engine:
 
 
 class GraphRunner:
-    """hipGraph replay of the forward for one (batch, height, width): the ~900 kernel launches of a forward cost more host time
+    """hipGraph replay of the forward for one (batch, height, width): the ~350 kernel launches of a forward cost more host time
     than GPU time once the kernels are fast, so they are captured once (``torch.cuda.graph`` = hipStreamBeginCapture on the stream
     every C-ABI call enqueues on) and replayed.  With ``split_k1`` the graph is cut around K1 so that bench.py can bracket that one
     kernel with HIP events inside the timed region: features graph -> K1 (eager) -> finish graph."""

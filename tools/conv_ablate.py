@@ -1,5 +1,5 @@
 """Conv ablation: times one conv shape for experiment builds libs2m2_hip_cdbg<N>.so (compile-time S2M2_CONV_DBG=N).
-Build:  for d in 1 2 4 5 7 8; do S2M2_LIB_SUFFIX=_cdbg$d S2M2_BUILD_DEFINES=-DS2M2_CONV_DBG=$d python -m s2m2_amd.build; done"""
+Build:  for d in 2 8 16 32 64; do S2M2_LIB_SUFFIX=_cdbg$d S2M2_BUILD_DEFINES=-DS2M2_CONV_DBG=$d python -m s2m2_amd.build; done"""
 import os, sys, subprocess
 for suffix in sys.argv[1:] or [""]:
     env = dict(os.environ, S2M2_LIB_SUFFIX=suffix)
