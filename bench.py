@@ -89,13 +89,26 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_gather = os.environ.get("S2M2_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ   # single-GPU check of the RCCL gather path
+    if world > 1 or force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on STDOUT when the communicator is created: stdout must carry exactly one JSON line, so the
+        # communicator is created (eager init + one barrier) with fd 1 pointing at stderr
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     from s2m2_amd.model import build_model
-    from s2m2_amd.shard import gather_outputs
+    from s2m2_amd.shard import gather_outputs_async
     from s2m2_amd.weights import noise_pair
 
     model = build_model(a.model, use_positivity=True, refine_iter=a.refine_iter).to(dev).eval()
@@ -105,18 +118,30 @@ def main():
     use_fp16 = a.dtype == "fp16"
     eng = model.engine(torch.float16 if use_fp16 else torch.float32)
 
+    pending = [None]                                  # the output gather of the previous step (N > 1), still in flight
+    # S2M2_BENCH_FORCE_GATHER=1 (under torchrun with one rank): exercise the RCCL gather path on a single GPU
+    gather = world > 1 or force_gather
+
     def step():
         with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
             out = model(left, right)
-        if world > 1:
-            out = gather_outputs(out, dist, dst=0)
+        if gather:                                    # gather of step i overlaps the forward of step i+1 (RCCL runs on its own stream)
+            if pending[0] is not None:
+                pending[0].wait(stack=False)
+            pending[0] = gather_outputs_async(out, dist, dst=0)
         return out
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait(stack=False)
+            pending[0] = None
 
     # HIP events around every K1 launch (the forward is replayed as two hipGraphs cut around K1, see engine.GraphRunner); enabled
     # before the warm-up so that graph capture happens there: call 1 runs eagerly, call 2 captures, later calls replay
     eng.k1_events = []
     for _ in range(max(a.warmup, 2)):
         step()
+    drain()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -125,6 +150,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()                                           # the last gather belongs to the timed region
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

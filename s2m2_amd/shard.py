@@ -15,20 +15,43 @@ def shard_indices(n_pairs: int, rank: int, world: int) -> List[int]:
     return list(range(rank, n_pairs, world))
 
 
-def gather_outputs(out: Sequence[torch.Tensor], dist, dst: int = 0, group=None) -> Optional[Tuple[torch.Tensor, ...]]:
-    """Gather same-shaped (disp, occ, conf) tuples from all ranks to ``dst``.
+class PendingGather:
+    """An output gather in flight (``gather_outputs_async``): ``wait()`` completes it and returns, on ``dst``, the tuple of tensors with
+    the rank dimension folded into batch, rank-major: (world*B,1,H,W); None elsewhere.  With RCCL the collective runs on its own
+    stream, so the next forward can be enqueued before the maps of this one have arrived (``wait`` makes the CURRENT stream wait,
+    not the host)."""
 
-    Returns on dst a tuple of tensors with the rank dimension folded into batch, rank-major: (world*B,1,H,W);
-    None elsewhere.  One collective per call (the three maps travel as one stacked buffer)."""
+    def __init__(self, work, buf: torch.Tensor, bufs, n_out: int, is_dst: bool):
+        self.work, self.buf, self.bufs, self.n_out, self.is_dst = work, buf, bufs, n_out, is_dst
+
+    def wait(self, stack: bool = True) -> Optional[Tuple[torch.Tensor, ...]]:
+        """stack=False: only complete the collective (the per-rank buffers stay in ``self.bufs`` on dst); nothing is returned."""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if not self.is_dst or not stack:
+            return None
+        allb = torch.stack(self.bufs, 1)                                      # (3,world,B,1,H,W)
+        return tuple(allb[i].reshape(-1, *self.buf.shape[2:]) for i in range(self.n_out))
+
+
+def gather_outputs_async(out: Sequence[torch.Tensor], dist, dst: int = 0, group=None) -> PendingGather:
+    """Start the gather of same-shaped (disp, occ, conf) tuples from all ranks to ``dst``: one collective per call (the three maps
+    travel as one stacked buffer, copied out of the forward's output tensors first, so a hipGraph replay may overwrite those)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     buf = torch.stack([o.float() for o in out], 0).contiguous()              # (3,B,1,H,W)
     bufs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-    dist.gather(buf, bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    allb = torch.stack(bufs, 1)                                               # (3,world,B,1,H,W)
-    return tuple(allb[i].reshape(-1, *buf.shape[2:]) for i in range(len(out)))
+    work = dist.gather(buf, bufs, dst=dst, group=group, async_op=True)
+    return PendingGather(work, buf, bufs, len(out), rank == dst)
+
+
+def gather_outputs(out: Sequence[torch.Tensor], dist, dst: int = 0, group=None) -> Optional[Tuple[torch.Tensor, ...]]:
+    """Gather same-shaped (disp, occ, conf) tuples from all ranks to ``dst`` and wait for them.
+
+    Returns on dst a tuple of tensors with the rank dimension folded into batch, rank-major: (world*B,1,H,W);
+    None elsewhere."""
+    return gather_outputs_async(out, dist, dst, group).wait()
 
 
 def run_sharded(forward: Callable[[torch.Tensor, torch.Tensor], Sequence[torch.Tensor]], left: torch.Tensor,

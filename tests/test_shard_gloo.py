@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from s2m2_amd.shard import gather_outputs, run_sharded, shard_indices
+from s2m2_amd.shard import gather_outputs, gather_outputs_async, run_sharded, shard_indices
 
 
 def _fake_forward(l, r):
@@ -32,6 +32,18 @@ def _worker(rank, world, port, q):
     else:
         assert out is None
         gather_outputs(_fake_forward(left[:1] + rank, right[:1]), dist, 0)
+    # overlapped form used by bench.py: two gathers started back to back, each completed later, results in rank order
+    src = [_fake_forward(left[:1] + rank + 10 * k, right[:1]) for k in range(2)]
+    handles = [gather_outputs_async(o, dist, 0) for o in src]
+    got = [h.wait() for h in handles]
+    if rank == 0:
+        ok = True
+        for k in range(2):
+            exp = torch.cat([_fake_forward(left[:1] + r + 10 * k, right[:1])[0] for r in range(world)], 0)
+            ok = ok and torch.allclose(got[k][0], exp)
+        q.put(ok)
+    else:
+        assert got == [None, None]
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,8 +65,8 @@ def test_world2_gloo_gather_in_pair_order():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=90), q.get(timeout=90)]
+    res = [q.get(timeout=90), q.get(timeout=90), q.get(timeout=90)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res == [True, True]
+    assert res == [True, True, True]
