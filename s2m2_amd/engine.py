@@ -491,19 +491,22 @@ class GraphRunner:
                 eng.run(self.l, self.r)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
+        # thread-local capture mode: with torch.distributed initialised, the RCCL watchdog thread polls events while this thread
+        # captures; in the default (global) mode such a call from another thread invalidates the capture
+        mode = "thread_local"
         if not split_k1:
             self.g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g):
+            with torch.cuda.graph(self.g, capture_error_mode=mode):
                 self.out = eng.run(self.l, self.r)
         else:
             self.ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.ga):
+            with torch.cuda.graph(self.ga, capture_error_mode=mode):
                 self.state = eng.features(self.l, self.r)
             tr = self.state[0]
             self.cv = torch.empty((B, tr.shape[1], tr.shape[2], tr.shape[2]), device=dev, dtype=tr.dtype)
             eng.cost_volume(tr, out=self.cv)
             self.gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.gb, pool=self.ga.pool()):
+            with torch.cuda.graph(self.gb, pool=self.ga.pool(), capture_error_mode=mode):
                 self.out = eng.finish(*self.state, self.cv)
 
     def __call__(self, img0: Tensor, img1: Tensor):
