@@ -1393,8 +1393,6 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.act = d->act; a.epi = d->epi; a.aux0 = d->aux0; a.aux1 = d->aux1;
     a.aux0_stride = d->aux0_stride; a.aux1_stride = d->aux1_stride;
     a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2; a.korder = d->korder;
-    a.zero = zero_page();
-    S2M2_REQUIRE(a.zero, "conv2d: cannot allocate the zero page");
     a.ln_wsum = d->ln_wsum; a.ln_eps = d->ln_eps;
     a.ksplit = d->ksplit; a.bias2 = d->bias2;
     if (d->epi == S2M2_EPI_DUALMIX)
@@ -1408,6 +1406,8 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.stride = d->stride; a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
     S2M2_REQUIRE(d->korder == 0 || d->korder == 1, "conv2d: korder=%d (0 or 1)", d->korder);
     S2M2_REQUIRE(!d->korder || a.Cin % (d->dtype == S2M2_F16 ? 32 : 16) == 0, "conv2d: korder 1 needs Cin=%d to be a multiple of 64 bytes of channels", a.Cin);
+    a.zero = zero_page();                                         // (first device call: every argument check is above)
+    S2M2_REQUIRE(a.zero, "conv2d: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d->dtype == S2M2_F16) return dispatch_conv<half_t>(a, d->tile, st);
     if (d->dtype == S2M2_F32) return dispatch_conv<float>(a, d->tile, st);

@@ -44,3 +44,40 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/libs2m2_hip.so")
     with pytest.raises(RuntimeError, match="no PyTorch fallback"):
         hip.load()
+
+
+def test_argument_validation_of_the_gemm_entry_points(lib):
+    """Validation returns an error code + message before any device call (no GPU needed): descriptor ranges, supported widths,
+    the pre-LayerNorm / dual-GEMM preconditions."""
+    import ctypes
+    assert lib.s2m2_conv2d(None, None) != 0 and b"null descriptor" in lib.s2m2_last_error()
+    d = hip.ConvDesc()
+    d.nsrc = 5
+    assert lib.s2m2_conv2d(ctypes.byref(d), None) != 0 and b"nsrc" in lib.s2m2_last_error()
+    # a plausible 3x3 descriptor with a pre-LayerNorm request: rejected (1x1 layers only)
+    d = hip.ConvDesc()
+    d.nsrc, d.N, d.H, d.W, d.KH, d.KW, d.Cout, d.out_stride, d.stride = 1, 1, 8, 8, 3, 3, 128, 128, 1
+    d.src[0], d.src_c[0], d.src_stride[0] = 4096, 128, 128
+    d.weight, d.out, d.ln_wsum, d.ln_eps, d.dtype = 4096, 4096, 4096, 1e-5, hip.F16
+    assert lib.s2m2_conv2d(ctypes.byref(d), None) != 0 and b"pre-LayerNorm" in lib.s2m2_last_error()
+    d.ln_wsum, d.KH, d.KW, d.epi, d.act, d.aux0, d.aux1, d.ksplit, d.out_scale = None, 1, 1, hip.EPI_DUALMIX, hip.ACT_SIGMOID, 4096, 4096, 40, 1.0
+    assert lib.s2m2_conv2d(ctypes.byref(d), None) != 0 and b"DUALMIX" in lib.s2m2_last_error()
+
+    assert lib.s2m2_mlp_chain_supported(128, hip.F16) == 1 and lib.s2m2_mlp_chain_supported(192, hip.F16) == 0
+    assert lib.s2m2_mlp_chain_supported(512, hip.F32) == 0
+    assert lib.s2m2_mlp_chain(None, None) != 0 and b"null descriptor" in lib.s2m2_last_error()
+    c = hip.ChainDesc()
+    c.x, c.out, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.out_stride = 4096, 4096, 128, 4, hip.F16, 8, 128, 128
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"nstage" in lib.s2m2_last_error()
+    c.nstage, c.C = 2, 192
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"not supported" in lib.s2m2_last_error()
+    c.C, c.carry, c.res_stage = 128, 1, -1
+    c.weight[0] = c.weight[1] = 4096
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"carry" in lib.s2m2_last_error()
+
+    assert lib.s2m2_feature_fusion_supported(128, hip.F16) == 1 and lib.s2m2_feature_fusion_supported(384, hip.F16) == 0
+    assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 64, 192, 4096, 4096, 4096, 4096, 4096, 0, 0, hip.F16, None) != 0
+    assert b"not supported" in lib.s2m2_last_error()
+    assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 60, 128, 4096, 4096, 4096, 4096, 4096, 4, 4, hip.F16, None) != 0
+    assert b"whole number" in lib.s2m2_last_error()
+    assert lib.s2m2_stem_mlp(None, None, None, None, None, None, 8, hip.F16, None) != 0
