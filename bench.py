@@ -1,31 +1,45 @@
 #!/usr/bin/env python3
 """Headline benchmark: stereo pairs/s of the S2M2 hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank per GPU;
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or started plainly, in which case bench.py launches its N
+ranks itself through torch.distributed.run on 127.0.0.1 and rank 0 prints the one JSON line.  ``--gpus N`` with fewer than N
+visible devices fails loudly.
 
 Workload (BASELINE.json metric / configs[2] per GPU): S model (C=128, NTR=1), 1216x1024, fp16 compute (autocast, the
 reference's deployment mode), refine_iter=3, use_positivity=True, ONE stereo pair per GPU per step (weak scaling: pairs shard
 across ranks with no data-path collective; for N>1 each step ends with the RCCL gather of the three output maps to rank 0).
 Inputs are synthetic uint8-valued images already resident in HBM; weights are the seeded random init (no checkpoints ship).
 
-Prints ONE JSON line on rank 0 with `roofline` (K1 = LayerNorm+correlation kernel, HBM bound, measured with HIP events
-around its launches inside the timed region) and `cpu_baseline` (the CPU oracle = port of the reference forward, timed on
-this box's host cores on one pair of the same workload).
+The JSON line carries, next to the contract's fields:
+* ``roofline``            K1 = LayerNorm + correlation kernel, HBM bound: HIP events around its launches inside the timed region;
+* ``roofline_attention``  K4 attention kernels, MFMA bound: one instrumented eager forward AFTER the timed region with HIP events
+                          around every K4 launch, analytic FLOPs 4*N^2*d*heads*batch -> fraction of the dense
+                          fp16 MFMA peak (north_star: "MFMA utilisation on the attention GEMMs");
+* ``forward``             multiply-accumulate work of one forward as executed (counted per launch) / time per pair;
+* ``cpu_baseline``        the CPU oracle (port of the reference forward) on this box's host cores: thread-count sweep, 1 warm-up
+                          + 3 timed runs at the best count.
+
+``--dry`` (CPU, gloo, no model): exercises launcher, rendezvous, gather and max-over-ranks timing without a GPU (tests).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
 def parse():
@@ -41,25 +55,72 @@ def parse():
     ap.add_argument("--refine-iter", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--dry", action="store_true", help="CPU/gloo plumbing check of the multi-rank path: no GPU, no model")
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` -> N ranks under torch.distributed.run
+# ---------------------------------------------------------------------------------------------------------------------------
+def launch_ranks(a) -> int:
+    if not a.dry:
+        import torch
+        n = torch.cuda.device_count()
+        if n < a.gpus:
+            sys.stderr.write(f"bench.py: --gpus {a.gpus} requested but only {n} GPU(s) visible; refusing to run a smaller job\n")
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (port of the reference forward), thread sweep
+# ---------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(model_type, H, W, refine_iter):
-    """Oracle (CPU restatement of the reference forward, fp32) on this box's host cores: one 1216x1024 pair (~10-30 s)."""
+    """Oracle (CPU restatement of the reference forward, fp32) on this box's host cores, one pair of the benchmark workload per run:
+    1 warm-up, one timed run per thread count in the sweep, 2 more at the best count (value = median of its 3).  Default intra-op
+    thread counts (128 on the GPU box) oversubscribe the oneDNN/ATen kernels: measured 35.7 s per pair at 128 threads in round 1."""
+    import torch
     from oracle import s2m2_oracle as O
     from s2m2_amd.spec import MODEL_CONFIGS
     from s2m2_amd.weights import noise_pair, seeded_state_dict
     C, ntr = MODEL_CONFIGS[model_type]
     sd = seeded_state_dict(C, 1, ntr, 0)
-    l, r = noise_pair(64, 96, 1, 1)
-    O.forward(sd, l, r, True, 1)                                   # warm up oneDNN primitives
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
+    sweep = sorted({t for t in (16, 32, 64) if t <= ncpu} or {min(8, ncpu)})
     l, r = noise_pair(H, W, 1, 0)
-    t0 = time.perf_counter()
-    O.forward(sd, l, r, True, refine_iter)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "pairs/s", "seconds_per_pair": dt, "cores": torch.get_num_threads(),
-            "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"1 pair {W}x{H} {model_type}-model fp32 refine_iter={refine_iter}, oracle/s2m2_oracle.py (torch CPU ops), 1 timed run after a 96x64 warm-up"}
+
+    def one():
+        t0 = time.perf_counter()
+        O.forward(sd, l, r, True, refine_iter)
+        return time.perf_counter() - t0
+
+    torch.set_num_threads(sweep[len(sweep) // 2])
+    one()                                                          # warm-up at full size (oneDNN primitive creation, page faults)
+    times = {}
+    for t in sweep:
+        torch.set_num_threads(t)
+        times[t] = [one()]
+    best = min(times, key=lambda t: times[t][0])
+    torch.set_num_threads(best)
+    times[best] += [one(), one()]
+    dt = sorted(times[best])[1]
+    torch.set_num_threads(default_threads)
+    return {"value": 1.0 / dt, "unit": "pairs/s", "seconds_per_pair": dt, "cores": best, "host_cpus": ncpu, "kind": "port",
+            "thread_sweep_seconds": {str(t): [round(x, 3) for x in v] for t, v in times.items()},
+            "port_vs_reference": "oracle 2.1 s vs unmodified reference 3.2 s per 640x480 r=1 pair on the 8 cores of the build container "
+                                 "(same ATen CPU kernels; the oracle skips nn.Module dispatch and the (N,N,32) PE gather)",
+            "sample": f"1 pair {W}x{H} {model_type}-model fp32 refine_iter={refine_iter} per run, oracle/s2m2_oracle.py (torch CPU ops): "
+                      f"1 warm-up, 1 run per thread count, median of 3 at the best count"}
 
 
 def pmc_traffic(model_type, H, W, use_fp16, B):
@@ -77,36 +138,102 @@ def pmc_traffic(model_type, H, W, use_fp16, B):
     return d.get("traffic_bytes"), os.path.relpath(files[-1], ROOT)
 
 
+def _quiet_init(dist, backend, rank, world, dev):
+    """RCCL prints a version banner on STDOUT when the communicator is created: stdout must carry exactly one JSON line, so the
+    communicator is created (eager init + one barrier) with fd 1 pointing at stderr."""
+    import torch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.barrier()
+        if backend == "nccl":
+            torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+
+
+def dry_run(a, rank, world):
+    """The N>1 control flow on CPU: rendezvous (gloo), per-step async gather to rank 0 overlapped with the next step, barrier-bracketed
+    timing, max over ranks, one JSON line from rank 0.  The "forward" is a stand-in that only depends on the rank's own pair."""
+    import torch
+    import torch.distributed as dist
+    from s2m2_amd.shard import gather_outputs_async
+    if world > 1:
+        _quiet_init(dist, "gloo", rank, world, None)
+    g = torch.Generator().manual_seed(rank)
+    left = torch.rand(a.pairs_per_gpu, 3, 32, 64, generator=g)
+    right = torch.rand(a.pairs_per_gpu, 3, 32, 64, generator=g)
+    pending = [None]
+    got = []
+
+    def step():
+        d = (left - right).mean(dim=1, keepdim=True)
+        out = (d, d * 0.5, d.abs())
+        if world > 1:
+            if pending[0] is not None:
+                got.append(pending[0].wait())
+            pending[0] = gather_outputs_async(out, dist, dst=0)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if pending[0] is not None:
+        got.append(pending[0].wait())
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ok = world == 1 or all(x is not None and tuple(x[0].shape) == (world * a.pairs_per_gpu, 1, 32, 64) for x in got)
+        pairs = a.steps * a.pairs_per_gpu * world
+        print(json.dumps({"metric": "stereo pairs/sec (DRY RUN: launcher / gather plumbing on CPU, no model)", "value": pairs / elapsed,
+                          "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "dry": True, "gathers_ok": bool(ok), "config": {"workload": "dry run", "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
-    if a.no_graph:
-        os.environ["S2M2_GRAPH"] = "0"
+    if "RANK" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus}, or plainly)")
+    if a.dry:
+        return dry_run(a, rank, world)
+    if a.no_graph:
+        os.environ["S2M2_GRAPH"] = "0"
+    import torch
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     force_gather = os.environ.get("S2M2_BENCH_FORCE_GATHER") == "1" and "RANK" in os.environ   # single-GPU check of the RCCL gather path
     if world > 1 or force_gather:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on STDOUT when the communicator is created: stdout must carry exactly one JSON line, so the
-        # communicator is created (eager init + one barrier) with fd 1 pointing at stderr
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            dist.barrier()
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        _quiet_init(dist, "nccl", rank, world, dev)
 
+    from s2m2_amd import hip
     from s2m2_amd.model import build_model
     from s2m2_amd.shard import gather_outputs_async
     from s2m2_amd.weights import noise_pair
@@ -119,7 +246,6 @@ def main():
     eng = model.engine(torch.float16 if use_fp16 else torch.float32)
 
     pending = [None]                                  # the output gather of the previous step (N > 1), still in flight
-    # S2M2_BENCH_FORCE_GATHER=1 (under torchrun with one rank): exercise the RCCL gather path on a single GPU
     gather = world > 1 or force_gather
 
     def step():
@@ -169,11 +295,30 @@ def main():
         k1_us = 1e3 * sum(k1_ms) / max(1, len(k1_ms))
         achieved = k1_bytes / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
         pairs = a.steps * B * world
+        ms_per_pair_gpu = 1e3 * elapsed / (a.steps * B)             # one GPU's time per pair
         traffic, traffic_src = pmc_traffic(a.model, a.height, a.width, use_fp16, B)
+        # ---- after the timed region: one instrumented eager forward (work meter + HIP events around every K4 launch)
+        eng.k1_events = None
+        hip.METER, hip.ATTN_EVENTS = {}, []
+        with torch.autocast("cuda", enabled=False):
+            eng.run(left, right, None)
+        torch.cuda.synchronize()
+        meter, attn_ev = hip.METER, hip.ATTN_EVENTS
+        hip.METER = hip.ATTN_EVENTS = None
+        peak_tf = MFMA_F16_PEAK_TFLOPS if use_fp16 else MFMA_F32_PEAK_TFLOPS
+        a_us = sum(1e3 * s.elapsed_time(e_) for s, e_, _, _ in attn_ev)
+        a_fl = sum(f for _, _, f, _ in attn_ev)
+        by_shape = {}
+        for s, e_, f, tag in attn_ev:
+            d = by_shape.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += 1e3 * s.elapsed_time(e_)
+            d[2] += f
+        fwd_flops = sum(v[0] for v in meter.values()) / B
         line = {
             "metric": "stereo pairs/sec, S-model 1216x1024 fp16 refine_iter=3 (ms/pair = 1000*n_gpus/value)",
             "value": pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "ms_per_pair": 1e3 * elapsed / (a.steps * B),
+            "ms_per_step": 1e3 * elapsed / a.steps, "ms_per_pair": ms_per_pair_gpu,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if use_fp16 else "f32", "data": "synthetic",
             "config": {"workload": f"{a.model}-model {a.width}x{a.height} refine_iter={a.refine_iter} use_positivity=True, "
@@ -183,11 +328,24 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": k1_us,
                          "launches_timed": len(k1_ms)},
+            "roofline_attention": {
+                "kernel": "attention_kernel (K4: every QK^T / PV contraction of a forward)", "bound": "mfma",
+                "achieved": a_fl / (a_us * 1e-6) / 1e12 if a_us > 0 else 0.0, "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": (a_fl / (a_us * 1e-6) / 1e12 / peak_tf) if a_us > 0 else 0.0,
+                "flops_per_forward": a_fl, "us_per_forward": a_us, "launches": len(attn_ev),
+                "how": "HIP events around each K4 launch in one eager forward after the timed region (adds ~2 us of dispatch per launch)",
+                "by_shape(batch,heads,N,d)": {k: {"launches": v[0], "us": round(v[1], 1), "tflops": round(v[2] / (v[1] * 1e-6) / 1e12, 1)}
+                                              for k, v in by_shape.items()}},
+            "forward": {"flops_per_pair_executed": fwd_flops, "achieved_tflops": fwd_flops / (ms_per_pair_gpu * 1e-3) / 1e12,
+                        "frac_of_mfma_peak": fwd_flops / (ms_per_pair_gpu * 1e-3) / 1e12 / peak_tf,
+                        "flops_by_family": {k: v[0] / B for k, v in meter.items()}, "launches_by_family": {k: v[1] for k, v in meter.items()},
+                        "note": "2 flops per multiply-accumulate of every GEMM-shaped launch, padded channel counts; per GPU"},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.model, a.height, a.width, a.refine_iter)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -27,18 +27,50 @@ SD = Mapping[str, Tensor]
 
 
 # --------------------------------------------------------------------------------------------------
+# precision mode.  "fp32" (default) is the parity configuration.  "fp16" EMULATES how the reference is deployed
+# (fp32 weights + inputs under ``torch.amp.autocast(float16)``, model_utils.py:75-76) on the CPU: every tensor the CUDA
+# autocast policy would hold in fp16 is rounded to fp16 at the op that produces it (``_q``) while the arithmetic inside an op
+# stays fp32 (= fp16 operands, fp32 accumulation, one rounding of the result, which is what the GPU libraries do).
+# Autocast policy used (PyTorch CUDA op lists): conv / conv_transpose / linear / matmul / einsum / SDPA
+# -> fp16 in and out; layer_norm, group_norm, softmax, exp, log, sum, grid_sampler -> fp32 in and out; everything else
+# runs in its widest input dtype (so fp16 (+,*,gelu,sigmoid,tanh,avg_pool,interpolate,logit) fp16 -> one fp16 rounding each).
+# The fp16 mode is not pinned by reference-generated goldens (the reference cannot run its CUDA autocast path in the
+# CPU-only build container); it is used only to QUANTIFY how far the HIP fp16 mode is from the reference's deployment numerics.
+# --------------------------------------------------------------------------------------------------
+class _Prec:
+    half = False
+
+
+def _q(x: Tensor) -> Tensor:
+    """fp16 storage point of the reference's autocast path (identity in fp32 mode)."""
+    return x.half().float() if _Prec.half else x
+
+
+def _gelu(x: Tensor) -> Tensor:
+    return _q(F.gelu(x))
+
+
+# --------------------------------------------------------------------------------------------------
 # dense building blocks
 # --------------------------------------------------------------------------------------------------
+def _wb(sd: SD, p: str):
+    w, b = sd[p + ".weight"], sd.get(p + ".bias")
+    return (_q(w), _q(b) if b is not None else None)
+
+
 def _conv(sd: SD, p: str, x: Tensor, stride: int = 1, pad=0) -> Tensor:
-    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=pad)
+    w, b = _wb(sd, p)
+    return _q(F.conv2d(_q(x), w, b, stride=stride, padding=pad))
 
 
 def _convT(sd: SD, p: str, x: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
-    return F.conv_transpose2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=pad)
+    w, b = _wb(sd, p)
+    return _q(F.conv_transpose2d(_q(x), w, b, stride=stride, padding=pad))
 
 
 def _lin(sd: SD, p: str, x: Tensor) -> Tensor:
-    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+    w, b = _wb(sd, p)
+    return _q(F.linear(_q(x), w, b))
 
 
 def _ln(x: Tensor) -> Tensor:
@@ -48,39 +80,39 @@ def _ln(x: Tensor) -> Tensor:
 
 def _down(sd: SD, p: str, x: Tensor) -> Tensor:
     """AvgPool2d(2) then 1x1 conv (unet.py:25-30, stacked_MRT.py:22-27)."""
-    return _conv(sd, p + ".1", F.avg_pool2d(x, 2))
+    return _conv(sd, p + ".1", _q(F.avg_pool2d(x, 2)))
 
 
 def _up(sd: SD, p: str, x: Tensor) -> Tensor:
     """bilinear x2 (align_corners=False) then 1x1 conv (unet.py:32-37, stacked_MRT.py:29-34)."""
-    return _conv(sd, p + ".1", F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False))
+    return _conv(sd, p + ".1", _q(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)))
 
 
 def cnn_encoder(sd: SD, p: str, x: Tensor) -> Tuple[Tensor, Tensor]:
     """submodules.py:63-93."""
-    x = _conv(sd, p + ".conv0.2", F.gelu(_conv(sd, p + ".conv0.0", x)))
-    y = _conv(sd, p + ".conv1_down.2", F.gelu(_conv(sd, p + ".conv1_down.0", x, 2, 2)), 1, 1)
-    y = F.group_norm(y, 8, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])
-    y = _conv(sd, p + ".conv2.2", F.gelu(_conv(sd, p + ".conv2.0", y, 1, 1)), 1, 1) + y
+    x = _conv(sd, p + ".conv0.2", _gelu(_conv(sd, p + ".conv0.0", x)))
+    y = _conv(sd, p + ".conv1_down.2", _gelu(_conv(sd, p + ".conv1_down.0", x, 2, 2)), 1, 1)
+    y = F.group_norm(y, 8, sd[p + ".norm1.weight"], sd[p + ".norm1.bias"])          # autocast: fp32 out; the sum below stays fp32
+    y = _conv(sd, p + ".conv2.2", _gelu(_conv(sd, p + ".conv2.0", y, 1, 1)), 1, 1) + y
     x4 = _conv(sd, p + ".conv2_down.0", y, 2, 1)
     return x4, y
 
 
 def conv_block(sd: SD, p: str, z: Tensor) -> Tensor:
     """attentions.py:255-281: 3x3,GELU,3x3  +  1x1,ReLU,1x1."""
-    a = _conv(sd, p + ".convs.2", F.gelu(_conv(sd, p + ".convs.0", z, 1, 1)), 1, 1)
+    a = _conv(sd, p + ".convs.2", _gelu(_conv(sd, p + ".convs.0", z, 1, 1)), 1, 1)
     b = _conv(sd, p + ".convs_1x.2", F.relu(_conv(sd, p + ".convs_1x.0", z)))
-    return a + b
+    return _q(a + b)
 
 
 def feature_fusion(sd: SD, p: str, z0: Tensor, z1: Tensor) -> Tensor:
     """feature_fusion.py:24-31 (gate clamp [0.01, 0.99]); kernel size read from the weight."""
     z = torch.cat([z0, z1], 1)
     k = sd[p + ".feature_gate.0.weight"].shape[-1]
-    g = torch.sigmoid(_conv(sd, p + ".feature_gate.2", F.gelu(_conv(sd, p + ".feature_gate.0", z, 1, k // 2))))
-    g = g.clamp(0.01, 0.99)
-    f = _conv(sd, p + ".feature_fusion.2", F.gelu(_conv(sd, p + ".feature_fusion.0", z, 1, k // 2)))
-    return f + g * z0 + (1 - g) * z1
+    g = _q(torch.sigmoid(_conv(sd, p + ".feature_gate.2", _gelu(_conv(sd, p + ".feature_gate.0", z, 1, k // 2)))))
+    g = _q(g.clamp(0.01, 0.99))                                       # fp16 mode: the bounds land on fp16 values (0.01 -> 0.010002)
+    f = _conv(sd, p + ".feature_fusion.2", _gelu(_conv(sd, p + ".feature_fusion.0", z, 1, k // 2)))
+    return _q(_q(f + _q(g * z0)) + _q(_q(1 - g) * z1))
 
 
 # --------------------------------------------------------------------------------------------------
@@ -91,22 +123,29 @@ def _heads(x: Tensor, nh: int) -> Tensor:
     return x.reshape(b, n, nh, c // nh).permute(0, 2, 1, 3)
 
 
-def _sdpa(q: Tensor, k: Tensor, v: Tensor) -> Tuple[Tensor, Tensor]:
+def _sdpa(q: Tensor, k: Tensor, v: Tensor, explicit: bool = False) -> Tuple[Tensor, Tensor]:
+    """fp16 mode: ``explicit`` = the einsum / softmax / einsum spelling of the PE blocks (attentions.py:42-45: the scaled q and
+    the score matrix are fp16 tensors, softmax returns fp32); otherwise F.scaled_dot_product_attention on fp16 q/k/v (flash:
+    scores and softmax stay fp32 inside the kernel, the probabilities are rounded to fp16 for the PV product)."""
     d = q.shape[-1]
-    s = torch.matmul(q * (d ** -0.5), k.transpose(-1, -2))
+    if _Prec.half and not explicit:
+        s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+    else:
+        s = _q(torch.matmul(_q(q * (d ** -0.5)), k.transpose(-1, -2)))
     a = torch.softmax(s, dim=-1)
-    return torch.matmul(a, v), a
+    return _q(torch.matmul(_q(a), v)), a
 
 
 def self_attn(sd: SD, p: str, x: Tensor, nh: int, pe: Optional[Tensor]) -> Tensor:
     """attentions.py:33-54.  ``pe`` (N,N,32) only for blocks that own a ``pe_proj``."""
     b, n, c = x.shape
     q, k, v = (_heads(_lin(sd, p + "." + t, x), nh) for t in ("q", "k", "v"))
-    o, a = _sdpa(q, k, v)
-    if (p + ".pe_proj.weight") in sd:
+    use_pe = (p + ".pe_proj.weight") in sd
+    o, a = _sdpa(q, k, v, explicit=use_pe)
+    if use_pe:
         assert pe is not None
-        pe_sum = torch.einsum("bhij,ijc->bhic", a, pe)           # attentions.py:47
-        o = o + _lin(sd, p + ".pe_proj", pe_sum)
+        pe_sum = _q(torch.einsum("bhij,ijc->bhic", _q(a), _q(pe)))           # attentions.py:47
+        o = _q(o + _lin(sd, p + ".pe_proj", pe_sum))
     o = o.permute(0, 2, 1, 3).reshape(b, n, -1)
     return _lin(sd, p + ".proj", o)
 
@@ -125,7 +164,7 @@ def cross_attn(sd: SD, p: str, x: Tensor, y: Tensor, nh: int) -> Tuple[Tensor, T
 
 def ffn(sd: SD, p: str, z: Tensor) -> Tensor:
     """attentions.py:245-250."""
-    return _lin(sd, p + ".ffn.2", F.gelu(_lin(sd, p + ".ffn.0", _ln(z)))) + z
+    return _q(_lin(sd, p + ".ffn.2", _gelu(_lin(sd, p + ".ffn.0", _ln(z)))) + z)
 
 
 def _cross_block(sd: SD, p: str, z: Tensor, nh: int, two_d: bool) -> Tensor:
@@ -135,7 +174,7 @@ def _cross_block(sd: SD, p: str, z: Tensor, nh: int, two_d: bool) -> Tensor:
     b, h, w, c = x.shape
     shp = (b, h * w, c) if two_d else (b * h, w, c)
     ox, oy = cross_attn(sd, p + ".attn", x.reshape(shp), y.reshape(shp), nh)
-    return torch.cat([ox.reshape(b, h, w, c), oy.reshape(b, h, w, c)], 0) + z
+    return _q(torch.cat([ox.reshape(b, h, w, c), oy.reshape(b, h, w, c)], 0) + z)
 
 
 def _self_block(sd: SD, p: str, z: Tensor, nh: int, two_d: bool, pe: Optional[Tensor]) -> Tensor:
@@ -143,7 +182,7 @@ def _self_block(sd: SD, p: str, z: Tensor, nh: int, two_d: bool, pe: Optional[Te
     b, h, w, c = z.shape
     shp = (b, h * w, c) if two_d else (b * h, w, c)
     zz = z.reshape(shp)
-    return (self_attn(sd, p + ".attn", _ln(zz), nh, pe) + zz).reshape(b, h, w, c)
+    return _q(self_attn(sd, p + ".attn", _ln(zz), nh, pe) + zz).reshape(b, h, w, c)
 
 
 def global_attn_block(sd: SD, p: str, z: Tensor, nh: int, pe: Optional[Tensor]) -> Tensor:
@@ -240,13 +279,16 @@ def ln_corr(feat: Tensor, gamma: Tensor, beta: Tensor) -> Tensor:
     """feat (2B,C,h,w) NCHW, left = first B.  cv[b,y,i,j] = <LN(f0[b,:,y,i]), LN(f1[b,:,y,j])>."""
     f = F.layer_norm(feat.permute(0, 2, 3, 1), (feat.shape[1],), gamma, beta, 1e-5)
     f0, f1 = f.chunk(2, 0)
-    return torch.matmul(f0, f1.transpose(-1, -2))                      # (B,h,w,w), no 1/sqrt(C)
+    return _q(torch.matmul(_q(f0), _q(f1).transpose(-1, -2)))          # (B,h,w,w), no 1/sqrt(C); fp16 mode: einsum in/out fp16
 
 
-def _lse(x: Tensor, dim: int) -> Tensor:
-    """logsumexp_stable (submodules.py:147-152): m + log(max(sum exp(x-m), 1e-30))."""
+def _lse(x: Tensor, dim: int, x_is_half: bool = False) -> Tensor:
+    """logsumexp_stable (submodules.py:147-152): m + log(max(sum exp(x-m), 1e-30)).  fp16 mode: only the first call sees an
+    fp16 tensor (the padded cost volume), so only there is ``x - m`` an fp16 result; exp/sum/log are fp32 ops under autocast
+    and every later argument (cv + fp32 potentials) is fp32 by type promotion."""
     m = x.amax(dim=dim, keepdim=True)
-    s = (x - m).exp().sum(dim=dim, keepdim=True).clamp_min(1e-30)
+    xm = _q(x - m) if x_is_half else x - m
+    s = xm.exp().sum(dim=dim, keepdim=True).clamp_min(1e-30)
     return (m + s.log()).squeeze(dim)
 
 
@@ -261,13 +303,13 @@ def sinkhorn_prob(cv: Tensor, use_positivity: bool, ot_iter: int = 3) -> Tensor:
     marg = torch.cat([torch.ones(w), torch.tensor([float(w)])]) / (2 * w)
     lmu = marg.log()
     lnu = marg.log()
-    v = lnu - _lse(S, 2)                                               # over i
+    v = lnu - _lse(S, 2, x_is_half=_Prec.half)                         # over i
     u = lmu - _lse(S + v[:, :, None, :], 3)                            # over j
     for _ in range(ot_iter - 1):
         v = lnu - _lse(S + u[:, :, :, None], 2)
         u = lmu - _lse(S + v[:, :, None, :], 3)
     logp = S + u[:, :, :, None] + v[:, :, None, :]
-    P = (logp[:, :, :-1, :-1] + torch.log(torch.tensor(2.0 * w))).exp()          # undo the 1/(2w) marginals
+    P = _q((logp[:, :, :-1, :-1] + torch.log(torch.tensor(2.0 * w))).exp())      # undo the 1/(2w) marginals; ``.to(dtype)`` :200
     if use_positivity:
         P = P.masked_fill(upper, 0)
     return P
@@ -284,12 +326,12 @@ def regress(P: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     num = torch.zeros(B, h, w)
     for k in range(-2, 3):
         pk = torch.gather(Pp, 3, (ind + k + 2)[..., None])[..., 0]
-        conf = conf + pk
-        num = num + pk * (ind + k)
-    corr = (num + 1e-4) / (conf + 1e-4)
+        conf = _q(conf + pk)                                           # fp16 mode: fp16 accumulators (submodules.py:232-236)
+        num = _q(num + _q(pk * (ind + k)))
+    corr = _q(_q(num + 1e-4) / _q(conf + 1e-4))
     xs = torch.linspace(0, w - 1, w)
-    disp = xs.reshape(1, 1, w) - corr
-    occ = P.sum(dim=3)
+    disp = _q(xs.reshape(1, 1, w) - corr)
+    occ = P.sum(dim=3)                                                 # ``sum`` is an fp32 op under autocast
     return disp[:, None], conf[:, None], occ[:, None], ind
 
 
@@ -315,8 +357,12 @@ def _sample_rows(img: Tensor, x: Tensor, yrow: Tensor) -> Tensor:
     R, Hs, Ws = img.shape
     Wt = torch.tensor(float(Ws))
     Ht = torch.tensor(float(Hs))
-    gx = 2 * x / (Wt - 1) - 1
-    gy = 2 * yrow / (Ht - 1) - 1
+    if _Prec.half:      # bilinear_sampler's coordinate arithmetic runs on fp16 tensors; grid_sample itself is an fp32 op (autocast)
+        gx = _q(_q(2 * x / (Wt - 1)) - 1)
+        gy = _q(_q(2 * yrow / (Ht - 1)) - 1)
+    else:
+        gx = 2 * x / (Wt - 1) - 1
+        gy = 2 * yrow / (Ht - 1) - 1
     ix = (gx + 1) * ((Ws - 1) / 2)
     iy = (gy + 1) * ((Hs - 1) / 2)
     x0 = ix.floor()
@@ -340,13 +386,13 @@ def cv_lookup(cv: Tensor, disp: Tensor, radius: int = 4) -> Tuple[Tensor, Tensor
     B, h, w, _ = cv.shape
     img0 = cv.reshape(B * h, w, w)
     wh = w // 2
-    img1 = ((cv[..., 0:2 * wh:2] + cv[..., 1:2 * wh:2]) * 0.5).reshape(B * h, w, wh)    # avg-pool along j
+    img1 = _q((cv[..., 0:2 * wh:2] + cv[..., 1:2 * wh:2]) * 0.5).reshape(B * h, w, wh)    # avg-pool along j
     dx = torch.linspace(-radius, radius, 2 * radius + 1).reshape(1, 1, -1)
     i = torch.arange(w, dtype=torch.float32).reshape(1, w, 1)
     d = disp.reshape(B * h, w, 1)
     yrow = i + 0 * dx
-    c1 = _sample_rows(img0, i - d + dx, yrow.expand(B * h, w, -1))
-    c2 = _sample_rows(img1, i / 2 - d / 2 + dx, yrow.expand(B * h, w, -1))
+    c1 = _sample_rows(img0, _q(_q(i - d) + dx), yrow.expand(B * h, w, -1))            # fp16 mode: coords, disp, dx are fp16 tensors
+    c2 = _sample_rows(img1, _q(_q(i / 2 - _q(d / 2)) + dx), yrow.expand(B * h, w, -1))
     T = 2 * radius + 1
     return (c1.reshape(B, h, w, T).permute(0, 3, 1, 2).contiguous(),
             c2.reshape(B, h, w, T).permute(0, 3, 1, 2).contiguous())
@@ -363,40 +409,47 @@ def _logit(x: Tensor, eps: float) -> Tensor:
 def global_refiner(sd: SD, p: str, ctx: Tensor, disp: Tensor, conf: Tensor) -> Tensor:
     """refinenet.py:61-73."""
     mask = (conf > 0.2).float()
-    x = torch.cat([disp / 1e2 * mask, torch.logit(mask * conf, eps=1e-1), ctx], 1)
-    f = _conv(sd, p + ".init_feat.2", F.gelu(_conv(sd, p + ".init_feat.0", x, 1, 1)))
+    x = torch.cat([_q(disp / 1e2) * mask, torch.logit(mask * conf, eps=1e-1), ctx], 1)
+    f = _conv(sd, p + ".init_feat.2", _gelu(_conv(sd, p + ".init_feat.0", x, 1, 1)))
     f = unet(sd, p + ".refine_unet", f)[0]
-    upd = _conv(sd, p + ".out_feat.0", f, 1, 1) * 1e2
-    return mask * disp + (1 - mask) * upd
+    upd = _q(_conv(sd, p + ".out_feat.0", f, 1, 1) * 1e2)
+    return _q(mask * disp + (1 - mask) * upd)
 
 
 def conv_gru(sd: SD, p: str, h: Tensor, x: Tensor) -> Tensor:
     """refinenet.py:22-36: vertical (3x1) then horizontal (1x3) GRU pass."""
     for sfx, pad in (("1", (1, 0)), ("2", (0, 1))):
         hx = torch.cat([h, x], 1)
-        z = torch.sigmoid(_conv(sd, f"{p}.convz{sfx}", hx, 1, pad))
-        r = torch.sigmoid(_conv(sd, f"{p}.convr{sfx}", hx, 1, pad))
-        q = torch.tanh(_conv(sd, f"{p}.convq{sfx}", torch.cat([r * h, x], 1), 1, pad))
-        h = (1 - z) * h + z * q
+        z = _q(torch.sigmoid(_conv(sd, f"{p}.convz{sfx}", hx, 1, pad)))
+        r = _q(torch.sigmoid(_conv(sd, f"{p}.convr{sfx}", hx, 1, pad)))
+        q = _q(torch.tanh(_conv(sd, f"{p}.convq{sfx}", torch.cat([_q(r * h), x], 1), 1, pad)))
+        h = _q(_q(_q(1 - z) * h) + _q(z * q))
     return h
 
 
-def local_refiner(sd: SD, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor):
-    """refinenet.py:126-154."""
-    cl = torch.logit(conf, eps=1e-2)
+def local_refiner(sd: SD, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor,
+                  occ_is_fp32: bool = False):
+    """refinenet.py:126-154.  fp16 mode: ``occ`` arrives as an fp32 tensor on the first iteration (DispInit's ``sum``) and as
+    fp16 afterwards (``.to(disp.dtype)``), which decides where its logit and the updated logit are rounded."""
+    cl = _q(torch.logit(conf, eps=1e-2))
     ol = torch.logit(occ, eps=1e-2)
+    if not occ_is_fp32:
+        ol = _q(ol)
     c1, c2 = cv_lookup(cv, disp)
-    f1 = _conv(sd, p + ".corr_feat1.2", F.gelu(_conv(sd, p + ".corr_feat1.0", c1 / 16)))
-    f2 = _conv(sd, p + ".corr_feat2.2", F.gelu(_conv(sd, p + ".corr_feat2.0", c2 / 16)))
-    fd = _conv(sd, p + ".disp_feat.2", F.gelu(_conv(sd, p + ".disp_feat.0", disp / 1e2, 1, 1)), 1, 1)
-    fc = _conv(sd, p + ".conf_occ_feat.2", F.gelu(_conv(sd, p + ".conf_occ_feat.0", torch.cat([cl, ol], 1), 1, 1)))
+    f1 = _conv(sd, p + ".corr_feat1.2", _gelu(_conv(sd, p + ".corr_feat1.0", c1 / 16)))
+    f2 = _conv(sd, p + ".corr_feat2.2", _gelu(_conv(sd, p + ".corr_feat2.0", c2 / 16)))
+    fd = _conv(sd, p + ".disp_feat.2", _gelu(_conv(sd, p + ".disp_feat.0", _q(disp / 1e2), 1, 1)), 1, 1)
+    fc = _conv(sd, p + ".conf_occ_feat.2", _gelu(_conv(sd, p + ".conf_occ_feat.0", torch.cat([cl, ol], 1), 1, 1)))
     x = torch.cat([fd, f1, f2, ctx, fc], 1)
-    x = _conv(sd, p + ".disp_corr_ctx_cat.2", F.gelu(_conv(sd, p + ".disp_corr_ctx_cat.0", x)), 1, 1)
+    x = _conv(sd, p + ".disp_corr_ctx_cat.2", _gelu(_conv(sd, p + ".disp_corr_ctx_cat.0", x)), 1, 1)
     x = unet(sd, p + ".refine_unet", x)[0]
     hn = conv_gru(sd, p + ".gru", hidden, x)
-    dd = _conv(sd, p + ".disp_update.2", F.gelu(_conv(sd, p + ".disp_update.0", hn, 1, 1)), 1, 1)
-    co = _conv(sd, p + ".conf_occ_update.2", F.gelu(_conv(sd, p + ".conf_occ_update.0", hn, 1, 1)), 1, 1)
-    return hn, disp + dd, torch.sigmoid(co[:, 0:1] + cl), torch.sigmoid(co[:, 1:2] + ol), (c1, c2)
+    dd = _conv(sd, p + ".disp_update.2", _gelu(_conv(sd, p + ".disp_update.0", hn, 1, 1)), 1, 1)
+    co = _conv(sd, p + ".conf_occ_update.2", _gelu(_conv(sd, p + ".conf_occ_update.0", hn, 1, 1)), 1, 1)
+    so = co[:, 1:2] + ol
+    if not occ_is_fp32:
+        so = _q(so)
+    return hn, _q(disp + dd), _q(torch.sigmoid(_q(co[:, 0:1] + cl))), _q(torch.sigmoid(so)), (c1, c2)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -419,7 +472,7 @@ def upsample1x(x: Tensor, logits: Tensor, output_upsample: bool = False) -> Tens
     n = _neigh9(x)
     if output_upsample:
         n = n.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
-        logits = F.interpolate(logits, scale_factor=2, mode="bilinear", align_corners=False)
+        logits = _q(F.interpolate(logits, scale_factor=2, mode="bilinear", align_corners=False))
     return (n * logits.softmax(1)).sum(1, keepdim=True)
 
 
@@ -445,10 +498,23 @@ def upsample_mask_1x(sd: SD, p: str, disp: Tensor, rgb: Tensor, f2x: Tensor) -> 
 # --------------------------------------------------------------------------------------------------
 @torch.no_grad()
 def forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool = False, refine_iter: int = 3,
-            output_upsample: bool = False, capture: Optional[Dict[str, Tensor]] = None):
+            output_upsample: bool = False, capture: Optional[Dict[str, Tensor]] = None, precision: str = "fp32"):
     """Returns (disp_up, occ_up, conf_up), each (B,1,H,W) fp32.  ``capture`` (optional dict) receives the
     stage boundaries the parity tests compare: feature_tr_4x, cv, argmax, disp0/conf0/occ0, disp_g,
-    per-iteration disp/conf/occ/corr, masks."""
+    per-iteration disp/conf/occ/corr, masks.  ``precision``: "fp32" (parity configuration) or "fp16" (emulation of the
+    reference's autocast deployment mode, see the precision note at the top of this file)."""
+    if precision not in ("fp32", "fp16"):
+        raise ValueError(precision)
+    old = _Prec.half
+    _Prec.half = precision == "fp16"
+    try:
+        return _forward(sd, img0, img1, use_positivity, refine_iter, output_upsample, capture)
+    finally:
+        _Prec.half = old
+
+
+def _forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool, refine_iter: int, output_upsample: bool,
+             capture: Optional[Dict[str, Tensor]]):
     cap = capture if capture is not None else {}
     sd = {k: v.float() for k, v in sd.items()}
     a = (img0.float() / 255.0 - 0.5) * 2
@@ -472,13 +538,14 @@ def forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool = False, re
         disp = disp.clamp(min=0)
     cap["disp_g"] = disp
     fus = feature_fusion(sd, "feat_fusion_layer", tr0, py[0][:B])
-    ctx = _conv(sd, "ctx_feat.2", F.gelu(_conv(sd, "ctx_feat.0", fus)))
-    hidden = torch.tanh(ctx)
+    ctx = _conv(sd, "ctx_feat.2", _gelu(_conv(sd, "ctx_feat.0", fus)))
+    hidden = _q(torch.tanh(ctx))
     cap["ctx"] = ctx
     w = disp.shape[-1]
     xs = torch.arange(w, dtype=torch.float32).reshape(1, 1, 1, w)
     for it in range(refine_iter):
-        hidden, disp, conf, occ, corr = local_refiner(sd, "refiner", hidden, ctx, disp, conf, occ, cv)
+        hidden, disp, conf, occ, corr = local_refiner(sd, "refiner", hidden, ctx, disp, conf, occ, cv,
+                                                      occ_is_fp32=_Prec.half and it == 0)
         if use_positivity:
             disp = disp.clamp(min=0)
         occ = occ * (xs - disp >= 0)
@@ -489,7 +556,7 @@ def forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool = False, re
     cap["hidden"] = hidden
     m4 = upsample_mask_4x(sd, "upsample_mask_4x_refine", hidden, f2_left)
     cap["mask4x"] = m4
-    d_up = upsample4x(disp * 4, m4)
+    d_up = upsample4x(_q(disp * 4), m4)
     o_up = upsample4x(occ, m4)
     c_up = upsample4x(conf, m4)
     cap["disp_up4"] = d_up

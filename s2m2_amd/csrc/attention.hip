@@ -410,7 +410,8 @@ static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
         lds = lds > merge ? lds : merge;
     }
     if (lds > 160 * 1024) return set_error("attention: %zu bytes of LDS needed", lds);
-    static size_t attr_bytes = 0;
+    static size_t attr_bytes_dev[kMaxDevices] = {};
+    size_t& attr_bytes = attr_bytes_dev[current_device()];
     if (lds > attr_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return set_error("attention: cannot reserve %zu bytes of LDS", lds);

@@ -272,19 +272,12 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     if constexpr (CFG::NST > 2) ChainStage<CFG, T, 2>::run(p, ws, A0, A1, W0, W1, tid, m0);
 }
 
-static const void* chain_zero_page() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
-    }
-    return z;
-}
-
 template <typename T, int C, int BM, int NST, int NW, int WP = 4>
 static int launch_chain(const ChainArgs& a, hipStream_t st) {
     using CFG = ChainCfg<T, C, BM, NST, NW, WP>;
     auto kern = mlp_chain_kernel<CFG, T>;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device()];
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CFG::LDS_BYTES) != hipSuccess)
@@ -339,7 +332,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     }
     S2M2_REQUIRE(!any_ln || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
     a.res_stage = d->res_stage; a.carry = d->carry; a.ln_eps = d->ln_eps;
-    a.zero = chain_zero_page();
+    a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "mlp_chain: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const char* force = getenv("S2M2_CHAIN_CFG");          // tuning only: "s" (32-row tiles) / "m" (64-row tiles)

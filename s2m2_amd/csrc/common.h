@@ -15,6 +15,12 @@ namespace s2m2 {
 // ------------------------------------------------------------------------------------------------
 int set_error(const char* fmt, ...);            // stores a thread-local message, returns 1
 int check_launch(const char* what);             // hipGetLastError() -> set_error
+// Per-device host state.  A process may drive several GPUs (load_model(..., device='cuda:1') next to cuda:0): everything the
+// library caches on the host is indexed by the calling thread's current HIP device (the Python binding makes the tensors'
+// device current around every call).
+constexpr int kMaxDevices = 32;
+int current_device();                           // hipGetDevice(), clamped to [0, kMaxDevices)
+const void* zero_page();                        // 256 zero bytes in the current device's memory (allocated on first use, never freed)
 
 #define S2M2_REQUIRE(cond, ...)                        \
     do {                                               \

@@ -1185,20 +1185,12 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvArgs p, int ntiles) {
     }
 }
 
-// 256 zero bytes, allocated on the first call (before any graph capture: the engine warms up eagerly)
-static const void* zero_page() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
-    }
-    return z;
-}
-
 template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1, int NWAVES = 4, int MODE = 0>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfg<T, BM, BN, WGM, PPR, NPF, NWAVES>;
     auto kern = conv_igemm_kernel<CFG, T, MODE>;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device()];
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CFG::LDS_BYTES) != hipSuccess)
@@ -1215,7 +1207,8 @@ template <typename T, int BM, int BN, int KP, int NS>
 static int launch_conv2(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfg2<T, BM, BN, KP, NS>;
     auto kern = conv_igemm2_kernel<CFG, T>;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device()];
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CFG::LDS_BYTES) != hipSuccess)
@@ -1232,7 +1225,8 @@ template <typename T, int BN, int NWAVES = 4, int WGM = 2, int DW = 1>
 static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfgH<T, BN, NWAVES, WGM, DW>;
     auto kern = conv_halo_kernel<CFG, T>;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device()];
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CFG::LDS_BYTES) != hipSuccess)
@@ -1253,7 +1247,8 @@ static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     if (a.KH != 1 || a.KW != 1 || a.stride != 1) return set_error("conv2d: the pointwise kernel needs a 1x1 stride-1 layer");
     const size_t lds = CFG::lds_bytes(a.Cin);
     if (lds > 160 * 1024) return set_error("conv2d: pointwise kernel: Cin=%d needs %zu bytes of LDS", a.Cin, lds);
-    static size_t attr_bytes = 0;
+    static size_t attr_bytes_dev[kMaxDevices] = {};
+    size_t& attr_bytes = attr_bytes_dev[current_device()];
     if (lds > attr_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return set_error("conv2d: cannot reserve %zu bytes of LDS", lds);

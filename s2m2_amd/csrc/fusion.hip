@@ -260,19 +260,12 @@ __global__ __launch_bounds__(CFG::NT) void feature_fusion_kernel(FusionArgs p) {
     }
 }
 
-static const void* fusion_zero_page() {
-    static void* z = nullptr;
-    if (!z) {
-        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
-    }
-    return z;
-}
-
 template <typename T, int C, int BM, int NW, int WP = 4>
 static int launch_fusion(const FusionArgs& a, hipStream_t st) {
     using CFG = FusionCfg<T, C, BM, NW, WP>;
     auto kern = feature_fusion_kernel<CFG, T>;
-    static bool attr_done = false;
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device()];
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CFG::LDS_BYTES) != hipSuccess)
@@ -304,7 +297,7 @@ extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, lo
     a.up_h = z1_coarse_h; a.up_w = z1_coarse_w;
     S2M2_REQUIRE((z1_coarse_h == 0 && z1_coarse_w == 0) || (z1_coarse_h > 0 && z1_coarse_w > 0 && rows % (4LL * z1_coarse_h * z1_coarse_w) == 0),
                  "feature_fusion: rows=%lld is not a whole number of (2*%d) x (2*%d) images", rows, z1_coarse_h, z1_coarse_w);
-    a.zero = fusion_zero_page();
+    a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "feature_fusion: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // measured end to end (same-box A/B): 32-row tiles (the 64-row tile of C = 128 needs 234 VGPRs for its three accumulator sets

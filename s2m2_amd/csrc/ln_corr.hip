@@ -339,7 +339,8 @@ struct PipeOf<LnCorrCfg<T, TO, C, NWCAP, 4, true, false>> { using type = LnCorrC
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st) {
     auto kern = ln_corr_kernel<CFG, T, TO>;
-    static bool attr_done = false;                       // per instantiation
+    static bool attr_done_dev[kMaxDevices] = {};                       // per instantiation
+    bool& attr_done = attr_done_dev[current_device()];
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)CFG::lds_bytes(CFG::NWMAX)) != hipSuccess)

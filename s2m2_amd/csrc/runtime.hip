@@ -19,6 +19,23 @@ int check_launch(const char* what) {
     return 0;
 }
 
+int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d < kMaxDevices ? d : kMaxDevices - 1;
+}
+
+// 256 zero bytes per device (source of the padding / tail pieces of the GEMM loaders), allocated on the first call on that device
+// -- before any graph capture: the engine warms up eagerly
+const void* zero_page() {
+    static void* z[kMaxDevices] = {};
+    void*& p = z[current_device()];
+    if (!p) {
+        if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) p = nullptr;
+    }
+    return p;
+}
+
 }  // namespace s2m2
 
 extern "C" int s2m2_version(void) { return 100; }          // 0.1.0

@@ -216,7 +216,8 @@ static int launch_sinkhorn(const void* cv, float* disp, float* conf, float* occ,
     constexpr int NWV = 16;
     auto kern = sinkhorn_regress_kernel<TI, NWV, PPL>;
     const size_t lds = (size_t)(2 + 2 * NWV) * (w + 1) * sizeof(float);
-    static size_t attr_bytes = 0;
+    static size_t attr_bytes_dev[kMaxDevices] = {};
+    size_t& attr_bytes = attr_bytes_dev[current_device()];
     if (lds > attr_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return set_error("sinkhorn: cannot reserve %zu bytes of LDS", lds);

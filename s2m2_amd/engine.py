@@ -44,6 +44,26 @@ def pe_tables(h: int, w: int, device, pe_dim: int = 32) -> Tuple[Tensor, Tensor]
     return table(w), table(h)
 
 
+MAX_PIXELS = 1 << 24            # K5 addresses N*H*W pixels of one tensor with 24 bits (conv.hip); the largest tensor is (2B,H,W,*)
+LDS_BYTES = 160 * 1024
+
+
+def check_limits(H: int, W: int, C: int) -> None:
+    """Geometry limits of the kernel library, validated before the first launch (they raise inside the C ABI otherwise)."""
+    if C not in (64, 128, 192, 256, 384):
+        raise ValueError(f"feature_channels={C}: K1 is instantiated for 64, 128, 192, 256 and 384 channels")
+    if 2 * H * W >= MAX_PIXELS:
+        raise ValueError(f"{W}x{H}: one stereo pair must stay below 2^23 pixels per image (24-bit pixel index of the convolution kernels)")
+    w = W // 4
+    if (2 + 2 * 16) * (w + 1) * 4 > LDS_BYTES:
+        raise ValueError(f"image width {W}: K2 keeps a cost-volume row's potentials in LDS, at most {4 * (LDS_BYTES // 136 - 1)} px wide")
+
+
+def max_batch(H: int, W: int) -> int:
+    """Pairs per launch sequence (S2M2.forward slices larger batches)."""
+    return max(1, (MAX_PIXELS - 1) // (2 * H * W))
+
+
 class Engine:
     def __init__(self, model, dtype: torch.dtype):
         hip.load()                                   # fail loudly if the kernel library is missing
@@ -58,6 +78,7 @@ class Engine:
         self._packed: Dict[object, Spec] = {}
         self._pe_cache: Dict[Tuple[int, int], Tuple[Tensor, Tensor]] = {}
         self._bufs: Dict[object, Tensor] = {}
+        self._ns = None                              # scratch namespace, see zeros()
         self._wsum: Dict[int, Tensor] = {}
         self.fuse_ln = os.environ.get("S2M2_FUSE_LN", "1") != "0"      # A/B switch: 0 = separate K6 LayerNorm launches
         self.use_chain = os.environ.get("S2M2_CHAIN", "1") != "0"      # A/B switch: 0 = one K5 launch per 1x1 layer instead of K9 chains
@@ -139,7 +160,9 @@ class Engine:
 
     def zeros(self, key, shape, dtype=None) -> Tensor:
         """Persistent zero-initialised scratch (padding channels stay zero; the live channels are rewritten by every use)."""
-        k = (key, tuple(shape), dtype or self.dtype)
+        # eager calls: one set per stream (re-entrant across streams); a GraphRunner swaps in its own dictionary (_ns set)
+        ns = self._ns if (self._ns is not None or self.device.type != "cuda") else torch.cuda.current_stream(self.device).cuda_stream
+        k = (key, tuple(shape), dtype or self.dtype, ns)
         b = self._bufs.get(k)
         if b is None:
             b = torch.zeros(shape, device=self.device, dtype=dtype or self.dtype)
@@ -357,7 +380,9 @@ class Engine:
         corr = self.zeros("lr_corr", (B, h, w, 32))
         hip.cv_lookup_into(cv, disp.contiguous(), corr, 0, 16, 4)                                        # K3
         if cap is not None:
-            cap[f"corr1_it{it}"], cap[f"corr2_it{it}"] = corr[..., 0:9].permute(0, 3, 1, 2), corr[..., 16:25].permute(0, 3, 1, 2)
+            # clones: lr_corr is persistent scratch that the next iteration overwrites
+            cap[f"corr1_it{it}"], cap[f"corr2_it{it}"] = (corr[..., 0:9].permute(0, 3, 1, 2).clone(),
+                                                          corr[..., 16:25].permute(0, 3, 1, 2).clone())
         # corr/16 -> 1x1(9->96) GELU 1x1(96->64), both levels as block-diagonal GEMMs (the 1/16 is folded into the weights)
         cf = self.cconv(self.merged(p + "|corrA", [(p + ".corr_feat1.0", 0, 1 / 16, False), (p + ".corr_feat2.0", 16, 1 / 16, False)], 32),
                         [corr], act=hip.ACT_GELU)
@@ -434,10 +459,17 @@ class Engine:
     def finish(self, tr: Tensor, py0: Tensor, f2_left: Tensor, x8: Tensor, cv: Tensor, cap: Optional[dict] = None):
         """Sinkhorn + regression, global refiner, refinement loop, convex upsampling (s2m2.py:153-197)."""
         B = cv.shape[0]
+        # parity tests only ("teacher forcing", cap["inject"]): continue from the checker's tensors at a stage boundary, so that a
+        # legitimate flip of a near-tie argmax (SURVEY.md 8c) is not what the stages downstream are judged on
+        inj = (cap.get("inject") or {}) if cap is not None else {}
+        if "cv" in inj:
+            cv = inj["cv"].to(cv.device, cv.dtype).contiguous()
         disp, conf, occ, amax = hip.sinkhorn_regress(cv, self.use_positivity, 3, want_argmax=True)
         if cap is not None:
             cap.update(feature_tr_4x=tr.permute(0, 3, 1, 2), feature_py_4x=py0.permute(0, 3, 1, 2), cv=cv, argmax=amax,
                        disp0=disp, conf0=conf, occ0=occ)
+            if "disp0" in inj:
+                disp, conf, occ = (inj[k].to(cv.device, torch.float32).contiguous() for k in ("disp0", "conf0", "occ0"))
         tr0 = tr[:B]
         disp = self.global_refiner("global_refiner", tr0, disp, conf)
         if cap is not None:
@@ -445,6 +477,8 @@ class Engine:
         fus = self.fusion("feat_fusion_layer", tr0, py0[:B])
         ctx = self.cconv(self.std("ctx_feat.2"), [self.cconv(self.std("ctx_feat.0"), [fus], act=hip.ACT_GELU)])
         hidden = hip.tanh(ctx)
+        if cap is not None:
+            cap["ctx"] = ctx.permute(0, 3, 1, 2)
         for it in range(self.refine_iter):
             hidden, disp, conf, occ = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, cap, it)
             if cap is not None:
@@ -452,12 +486,17 @@ class Engine:
         m4 = self.mask4x("upsample_mask_4x_refine", hidden, f2_left)
         d_up, o_up, c_up = hip.convex_upsample([disp, occ, conf], m4, 4, scales=[4.0, 1.0, 1.0], chan_out=x8[..., 0])
         m1 = self.mask1x("upsample_mask_1x", x8, f2_left)
+        if cap is not None:
+            cap.update(hidden=hidden.permute(0, 3, 1, 2), mask4x=m4[..., :9].permute(0, 3, 1, 2), disp_up4=d_up,
+                       mask1x=m1[..., :9].permute(0, 3, 1, 2))
         up = self.output_upsample
         return tuple(hip.convex_upsample([d_up, o_up, c_up], m1, 2 if up else 1, scales=[2.0 if up else 1.0, 1.0, 1.0], logit_up2=up))
 
     @torch.no_grad()
     def run(self, img0: Tensor, img1: Tensor, cap: Optional[dict] = None):
         tr, py0, f2_left, x8 = self.features(img0, img1)
+        if cap is not None and "feature_tr_4x" in (cap.get("inject") or {}):           # parity tests only, see finish()
+            tr = cap["inject"]["feature_tr_4x"].to(tr.device, tr.dtype).permute(0, 2, 3, 1).contiguous()
         if self.k1_events is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -482,6 +521,15 @@ class GraphRunner:
         self.eng = eng
         self.split = split_k1
         dev = eng.device
+        self.bufs: Dict[object, Tensor] = {}                      # this graph's persistent scratch (dies with the runner)
+        outer = (eng._bufs, eng._ns)
+        eng._bufs, eng._ns = self.bufs, "graph"
+        try:
+            self._build(eng, B, H, W, split_k1, dev)
+        finally:
+            eng._bufs, eng._ns = outer
+
+    def _build(self, eng: "Engine", B: int, H: int, W: int, split_k1: bool, dev) -> None:
         self.l = torch.zeros((B, 3, H, W), device=dev, dtype=torch.float32)
         self.r = torch.zeros((B, 3, H, W), device=dev, dtype=torch.float32)
         s = torch.cuda.Stream(device=dev)

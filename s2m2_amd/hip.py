@@ -89,6 +89,19 @@ def load() -> ctypes.CDLL:
     return _lib
 
 
+# Optional work meter (bench.py): family -> [flops, launches] of the multiply-accumulate work the launches execute (padded channel
+# counts, 2 flops per MAC); ATTN_EVENTS: list collecting (start event, end event, flops, shape tag) around every K4 launch.
+METER: Optional[dict] = None
+ATTN_EVENTS: Optional[list] = None
+
+
+def _meter(family: str, flops: float) -> None:
+    if METER is not None:
+        e = METER.setdefault(family, [0.0, 0])
+        e[0] += flops
+        e[1] += 1
+
+
 def _check(rc: int, what: str) -> None:
     if rc != 0:
         raise RuntimeError(f"{what} failed: {load().s2m2_last_error().decode()}")
@@ -117,6 +130,7 @@ def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype
     cv_dtype = cv.dtype
     _check(load().s2m2_ln_corr(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
                                B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream()), "s2m2_ln_corr")
+    _meter("ln_corr", 2.0 * B * h * w * w * C)
     return cv
 
 
@@ -225,6 +239,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
         d.bias2 = bias2.data_ptr() if bias2 is not None else None
     d.dtype = _DT[dt]
     _check(load().s2m2_conv2d(ctypes.byref(d), _stream()), "s2m2_conv2d")
+    _meter("conv2d", 2.0 * n * ho * wo * Cout * KH * KW * cin)
     return out
 
 
@@ -276,6 +291,7 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
     out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
     d.out, d.out_stride = out.data_ptr(), C
     _check(load().s2m2_mlp_chain(ctypes.byref(d), _stream()), "s2m2_mlp_chain")
+    _meter("mlp_chain", 2.0 * rows * C * C * len(stages))
     return out
 
 
@@ -309,6 +325,7 @@ def feature_fusion(z0: torch.Tensor, z1: torch.Tensor, w1: torch.Tensor, b1: tor
     out = torch.empty(z0.shape, device=z0.device, dtype=z0.dtype)
     _check(load().s2m2_feature_fusion(z0.data_ptr(), z1.data_ptr(), out.data_ptr(), s0, s1, C, rows, C, w1.data_ptr(), b1.data_ptr(),
                                       w2.data_ptr(), bg.data_ptr(), bf.data_ptr(), hc, wc, _DT[z0.dtype], _stream()), "s2m2_feature_fusion")
+    _meter("feature_fusion", 2.0 * rows * C * C * 9)                # (2C -> 3C) + (C -> C) + (2C -> C)
     return out
 
 
@@ -383,11 +400,20 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, swa
         px, py, gw, gh = pe
         _dev(px, py)
         pe_out = torch.empty((nb, Nq, heads * 32), device=q.device, dtype=q.dtype)
+    flops = 4.0 * nb * heads * Nq * Nk * D                            # QK^T + PV (4 N^2 d per batch x head)
+    ev = None
+    if ATTN_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _check(load().s2m2_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), q.stride(1), k.stride(1), v.stride(1), C,
                                  nb, heads, Nq, Nk, D, float(scale if scale is not None else D ** -0.5), int(swap_halves),
                                  px.data_ptr() if px is not None else None, py.data_ptr() if py is not None else None,
                                  pe_out.data_ptr() if pe_out is not None else None, heads * 32, gw, gh, _DT[q.dtype], _stream()),
            "s2m2_attention")
+    if ev is not None:
+        ev[1].record()
+        ATTN_EVENTS.append((ev[0], ev[1], flops, f"({nb},{heads},{Nq},{D}){'+pe' if pe is not None else ''}"))
+    _meter("attention", flops)
     return (out, pe_out) if pe is not None else out
 
 

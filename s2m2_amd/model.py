@@ -11,6 +11,8 @@
 from __future__ import annotations
 
 import os
+import threading
+from collections import OrderedDict
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -47,8 +49,21 @@ class S2M2(nn.Module):
             node.register_parameter(leaf, nn.Parameter(torch.empty(shape), requires_grad=False))
         self.reset_parameters()
         self._engines: Dict[Tuple, "object"] = {}
-        self._graphs: Dict[Tuple, "object"] = {}
+        self._graphs: "OrderedDict[Tuple, object]" = OrderedDict()      # LRU of captured hipGraphs, see forward()
         self._seen = set()
+        self._epoch = 0                                                 # bumped by invalidate()
+        self._lock = threading.RLock()                                  # host-side enqueue of one forward at a time per module
+
+    # caches and the lock are process state, not model state: copy.deepcopy / pickling (torch.save(model)) drop them
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in ("_engines", "_graphs", "_seen", "_lock"):
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._engines, self._graphs, self._seen, self._lock = {}, OrderedDict(), set(), threading.RLock()
 
     # -- weights -------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -67,8 +82,22 @@ class S2M2(nn.Module):
                 state_dict[k] = own[k]
         self.load_state_dict(state_dict, strict=False)
 
+    def invalidate(self) -> None:
+        """Drop the packed weights and captured graphs.  ``load_state_dict`` / ``my_load_state_dict`` / ``.to()`` / ``.half()`` and any
+        in-place update that bumps a parameter's version counter are detected automatically; call this after writes that bypass it
+        (``p.data.copy_()``, ``p.data = ...``, raw pointers)."""
+        self._epoch += 1
+
     def _weights_version(self) -> Tuple:
-        return tuple(p._version for p in self.parameters()) + (next(self.parameters()).device, next(self.parameters()).dtype)
+        """Cheap fingerprint of the parameter storage: autograd version counters (where they exist: inference tensors have none),
+        data pointers, device, dtype and the explicit epoch."""
+        def ver(p):
+            try:
+                return p._version
+            except RuntimeError:
+                return -1
+        ps = list(self.parameters())
+        return tuple((ver(p), p.data_ptr()) for p in ps) + (ps[0].device, ps[0].dtype, self._epoch)
 
     # -- inference -----------------------------------------------------------------------------------
     def engine(self, dtype: torch.dtype):
@@ -83,17 +112,27 @@ class S2M2(nn.Module):
             self._engines[key] = eng
         return eng
 
-    @torch.no_grad()
     def forward(self, img0: torch.Tensor, img1: torch.Tensor, capture: Optional[dict] = None):
         """img0/img1: (B,3,H,W) in [0,255], H and W multiples of 32 -> (disp, occ, conf), each (B,1,H,W) fp32
         ((B,1,2H,2W), disparity x2, with output_upsample).  Compute dtype: fp16 under ``torch.autocast(float16)``
-        (how the reference is deployed, model_utils.py:76) or when the parameters are fp16, else fp32."""
+        (how the reference is deployed, model_utils.py:76) or when the parameters are fp16, else fp32.
+
+        Like the reference's module this is a pure function of (weights, img0, img1) that may be called from any thread, on any
+        current stream and for a model on any device: launches go to the current stream of the IMAGES' device, captured graphs and
+        scratch buffers are per stream, and a lock serialises the host-side enqueue per module.  ``torch.compile(model)`` (applied by
+        the reference's demos, visualize_2d_simple.py:36-37) is accepted: the body is opaque to the tracer (there is nothing for
+        a compiler to fuse -- every op is already a hand-written kernel)."""
+        return self._forward_impl(img0, img1, capture)
+
+    @torch.compiler.disable
+    @torch.no_grad()
+    def _forward_impl(self, img0: torch.Tensor, img1: torch.Tensor, capture: Optional[dict] = None):
         if not img0.is_cuda:
             raise RuntimeError("s2m2_amd.S2M2 runs on MI355X only: move the model and the images to a CUDA(HIP) device "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
         p0 = next(self.parameters())
-        if p0.device != img0.device:
-            raise RuntimeError(f"model parameters on {p0.device}, images on {img0.device}")
+        if p0.device != img0.device or img1.device != img0.device:
+            raise RuntimeError(f"model parameters on {p0.device}, images on {img0.device} / {img1.device}")
         if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.float16:
             dtype = torch.float16
         else:
@@ -102,21 +141,44 @@ class S2M2(nn.Module):
             raise ValueError(f"expected two (B,3,H,W) images, got {tuple(img0.shape)} and {tuple(img1.shape)}")
         if img0.shape[-1] % 32 or img0.shape[-2] % 32:
             raise ValueError("image height and width must be multiples of 32 (pad with image_pad first)")
-        with torch.autocast("cuda", enabled=False):
+        from .engine import GraphRunner, check_limits, max_batch
+        check_limits(img0.shape[2], img0.shape[3], self.feature_channels)
+        nb = max_batch(img0.shape[2], img0.shape[3])
+        if img0.shape[0] > nb:                                   # K5 indexes pixels with 24 bits: large batches run in slices
+            if capture is not None:
+                raise ValueError(f"capture needs a batch of at most {nb} pairs at this resolution")
+            parts = [self._forward_impl(img0[i:i + nb], img1[i:i + nb]) for i in range(0, img0.shape[0], nb)]
+            return tuple(torch.cat([p[k] for p in parts], 0) for k in range(3))
+        # the tensors' device becomes current: the C ABI launches on the current stream and keeps per-device state
+        with self._lock, torch.cuda.device(img0.device), torch.autocast("cuda", enabled=False):
             eng = self.engine(dtype)
             if capture is not None or os.environ.get("S2M2_GRAPH", "1") == "0":
                 return eng.run(img0, img1, capture)
             # hipGraph replay from the second call with the same geometry on (the first call runs eagerly and warms everything up)
-            key = (tuple(img0.shape), dtype, eng.k1_events is not None)
+            stream = torch.cuda.current_stream(img0.device).cuda_stream
+            key = (tuple(img0.shape), dtype, eng.k1_events is not None, stream)
             runner = self._graphs.get(key)
             if runner is None:
                 if key not in self._seen:
                     self._seen.add(key)
                     return eng.run(img0, img1, None)
-                from .engine import GraphRunner
-                runner = GraphRunner(eng, img0.shape[0], img0.shape[2], img0.shape[3], split_k1=eng.k1_events is not None)
+                # graph state (static input / output buffers) must be ordinary tensors even when the caller is in inference_mode
+                with torch.inference_mode(False), torch.no_grad():
+                    runner = GraphRunner(eng, img0.shape[0], img0.shape[2], img0.shape[3], split_k1=eng.k1_events is not None)
                 self._graphs[key] = runner
+                while len(self._graphs) > int(os.environ.get("S2M2_GRAPH_CACHE", "8")):       # LRU: each graph pins its activations
+                    self._graphs.popitem(last=False)
+            else:
+                self._graphs.move_to_end(key)
             return runner(img0, img1)
+
+    def is_warm(self, img_shape, dtype: torch.dtype = torch.float16) -> bool:
+        """True when a captured graph exists for (B,3,H,W) ``img_shape`` on the current stream (next call = pure replay)."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            return False
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        return any(k[0] == tuple(img_shape) and k[1] == dtype and k[3] == stream for k in self._graphs)
 
 
 def build_model(model_type: str, use_positivity: bool = True, refine_iter: int = 3, output_upsample: bool = False) -> S2M2:

@@ -5,6 +5,10 @@ image_utils.py) -- SURVEY.md section 8f rows 1-2: same names, arguments and retu
 * ``image_pad``            image_utils.py:27-71 (HIP kernel ``s2m2_image_pad``)
 * ``image_crop``           image_utils.py:73-103 (pure slicing)
 * ``run_stereo_matching``  model_utils.py:51-95 (pad -> autocast fp16 forward -> crop -> average confidence)
+* ``compute_confidence_score``   model_utils.py:98-101
+* ``compute_confidence_scores``  the calibration objective (calibration/base.py:15-36 called 20 x 5 times one pair at a time by
+  calibration/cem.py:66-72) for a whole population of rectified pairs at once: one batched forward, or sharded over the ranks of a
+  ``torch.distributed`` group
 """
 from __future__ import annotations
 
@@ -41,7 +45,8 @@ def load_model(pretrain_path: str, model_type: str, use_positivity: bool = True,
 
 def image_pad(img: torch.Tensor, factor: int = 32) -> torch.Tensor:
     """(B,C,H,W) -> (B,C,ceil(H/f)*f,ceil(W/f)*f) fp32 with the reference's blurred border; device tensors only."""
-    return hip.image_pad(img, factor)
+    with torch.cuda.device(img.device):                  # the C ABI launches on the current stream of the current device
+        return hip.image_pad(img, factor)
 
 
 def image_crop(img: torch.Tensor, img_shape: Tuple[int, int]) -> torch.Tensor:
@@ -64,6 +69,11 @@ def run_stereo_matching(model: S2M2, left_torch: torch.Tensor, right_torch: torc
     right_pad = image_pad(right_torch.to(device), 32)
     with torch.inference_mode():
         with torch.amp.autocast(enabled=True, device_type=torch.device(device).type, dtype=torch.float16):
+            if N_repeat > 1:
+                # run-time estimation: the first call with a new geometry runs eagerly and the second captures the hipGraph; keep both
+                # out of the timed loop (a single-shot call, N_repeat = 1, is timed as it is)
+                while not model.is_warm(left_pad.shape, torch.float16) and os.environ.get("S2M2_GRAPH", "1") != "0":
+                    model(left_pad, right_pad)
             starter, ender = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             starter.record()
             for _ in range(N_repeat):
@@ -81,3 +91,48 @@ def run_stereo_matching(model: S2M2, left_torch: torch.Tensor, right_torch: torc
 
 def compute_confidence_score(model: S2M2, left_torch: torch.Tensor, right_torch: torch.Tensor, device) -> float:
     return run_stereo_matching(model, left_torch, right_torch, device, N_repeat=1)[3]
+
+
+@torch.no_grad()
+def compute_confidence_scores(model: S2M2, lefts: torch.Tensor, rights: torch.Tensor, device, batch: Optional[int] = None,
+                              dist=None, group=None, margin: int = 100) -> torch.Tensor:
+    """Average confidence of N rectified pairs ``lefts`` / ``rights`` (N,3,H,W), same number per pair as ``compute_confidence_score``
+    returns for it (pad to x32 -> autocast fp16 forward -> crop -> mean of the confidence map inside a ``margin`` border), evaluated
+    ``batch`` pairs per forward (default: all at once; pairs are independent along the batch axis).
+
+    With ``dist`` (an initialised ``torch.distributed`` module, one rank per GPU) the pairs are sharded round-robin over the ranks
+    of ``group`` -- every rank passes the full population -- and every rank receives all N scores: the only collective is one
+    all-gather of N/world floats per rank.  Returns a float32 CPU tensor (N,)."""
+    N = lefts.shape[0]
+    if rights.shape != lefts.shape or lefts.dim() != 4:
+        raise ValueError(f"expected two (N,3,H,W) batches, got {tuple(lefts.shape)} and {tuple(rights.shape)}")
+    H, W = lefts.shape[-2:]
+    if H <= 2 * margin or W <= 2 * margin:
+        raise ValueError(f"images of {W}x{H} have no interior inside a {margin}-px margin")
+    idx = list(range(N))
+    world = rank = 1
+    if dist is not None:
+        from .shard import shard_indices
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if N % world:
+            raise ValueError(f"{N} pairs do not shard evenly over {world} ranks")
+        idx = shard_indices(N, rank, world)
+    step = batch or max(1, len(idx))
+    scores = []
+    for s0 in range(0, len(idx), step):
+        sel = idx[s0:s0 + step]
+        lp = image_pad(lefts[sel].to(device), 32)
+        rp = image_pad(rights[sel].to(device), 32)
+        with torch.amp.autocast(enabled=True, device_type=torch.device(device).type, dtype=torch.float16):
+            conf = model(lp, rp)[2]
+        conf = image_crop(conf, (H, W)).float()
+        scores.append(conf[:, 0, margin:-margin, margin:-margin].mean(dim=(1, 2)))
+    mine = torch.cat(scores) if scores else torch.empty(0, device=device)
+    if dist is None:
+        return mine.cpu()
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    out = torch.empty(N, dtype=torch.float32)
+    for r in range(world):
+        out[shard_indices(N, r, world)] = parts[r].float().cpu()
+    return out

@@ -8,6 +8,7 @@ integer argmax bit exact wherever the reference's top-2 relative gap exceeds 1e-
 import pytest
 import torch
 
+import parity_util as PU
 from conftest import T, load_golden
 from s2m2_amd.model import S2M2
 from s2m2_amd.weights import seeded_state_dict, synthetic_pair
@@ -43,6 +44,29 @@ def test_fp32_forward_vs_reference_golden(name):
     assert float(err.max()) < 5e-2
     assert float((o - T(g["occ"])).abs().max()) < 2e-4
     assert float((c - T(g["conf"])).abs().max()) < 2e-4
+    # every stage boundary the golden file holds (reference hooks of tests/golden/make_golden.py), same 99.5 % criterion; 99.9 % when
+    # no near-tie argmax differs (a flipped pixel moves disp0 by whole pixels and the refiners spread it)
+    lim = 1e-3 if bool(same.all()) else 5e-3
+    w4 = g["cv"].shape[-1]
+    xs = torch.arange(w4, dtype=torch.float32).reshape(1, 1, 1, w4)
+    clamp = (lambda t: t.clamp(min=0)) if pos else (lambda t: t)
+    stages = {"disp0": T(g["disp0"]), "conf0": T(g["conf0"]), "occ0": T(g["occ0"]), "disp_g": clamp(T(g["disp_g_preclamp"]))}
+    for k in ("feature_tr_4x", "feature_py_4x", "ctx", "hidden"):
+        if k in g:
+            stages[k] = T(g[k])
+    for k in ("mask4x", "mask1x"):
+        if k in g:
+            cap[k] = cap[k][:, :, ::4, ::4]                                  # the golden keeps a strided sample of the logits
+            stages[k] = T(g[k])
+    for it in range(ri):
+        dk = clamp(T(g[f"disp_it{it}_preclamp"]))
+        stages[f"disp_it{it}"] = dk
+        stages[f"conf_it{it}"] = T(g[f"conf_it{it}"])
+        stages[f"occ_it{it}"] = T(g[f"occ_it{it}_premask"]) * (xs - dk >= 0)
+        stages[f"corr1_it{it}"], stages[f"corr2_it{it}"] = T(g[f"corr1_it{it}"]), T(g[f"corr2_it{it}"])
+    for k, ref_t in stages.items():
+        st = PU.stats(cap[k], ref_t)
+        assert st["finite"] and st["frac_out"] <= (2 * lim if k.startswith("corr") else lim), (k, st)
 
 
 def test_batch_independence_and_determinism():

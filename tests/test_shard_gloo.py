@@ -48,6 +48,53 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _conf_worker(rank, world, port, q):
+    """utils.compute_confidence_scores sharded over 2 gloo ranks == the unsharded evaluation (calibration objective).
+    The device pieces (HIP image_pad, the model) are replaced by CPU stand-ins: this test is about the sharding arithmetic."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import s2m2_amd.utils as U
+    U.image_pad = lambda img, factor=32: torch.nn.functional.pad(img.float(), (0, (-img.shape[-1]) % factor, 0, (-img.shape[-2]) % factor))
+    U.image_crop = lambda img, shape: img[..., :shape[0], :shape[1]]
+
+    def model(l, r):
+        c = torch.sigmoid((l - r).mean(dim=1, keepdim=True) / 50)
+        return c, c, c
+    g = torch.Generator().manual_seed(1)
+    lefts = torch.rand(6, 3, 230, 250, generator=g) * 255
+    rights = torch.rand(6, 3, 230, 250, generator=g) * 255
+    sharded = U.compute_confidence_scores(model, lefts, rights, "cpu", dist=dist)
+    single = U.compute_confidence_scores(model, lefts, rights, "cpu", batch=4)
+    ref = torch.stack([model(lefts[i:i + 1], rights[i:i + 1])[2][0, 0, 100:-100, 100:-100].mean() for i in range(6)])
+    q.put(bool(torch.allclose(sharded, ref, atol=1e-6)) and bool(torch.allclose(single, ref, atol=1e-6)) and sharded.shape == (6,))
+    try:
+        U.compute_confidence_scores(model, lefts[:5], rights[:5], "cpu", dist=dist)
+        q.put(False)
+    except ValueError:
+        q.put(True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world2_gloo_sharded_confidence_objective():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_conf_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=90) for _ in range(4)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [True] * 4
+
+
 def test_shard_indices_cover_all_pairs():
     for n, w in [(8, 8), (8, 2), (6, 3), (5, 2)]:
         seen = sorted(p for r in range(w) for p in shard_indices(n, r, w))
