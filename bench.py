@@ -96,7 +96,7 @@ def cpu_baseline(model_type, H, W, refine_iter):
     sd = seeded_state_dict(C, 1, ntr, 0)
     ncpu = os.cpu_count() or 1
     default_threads = torch.get_num_threads()
-    sweep = sorted({t for t in (16, 32, 64) if t <= ncpu} or {min(8, ncpu)})
+    sweep = sorted({t for t in (8, 16, 32) if t <= ncpu} or {ncpu})
     l, r = noise_pair(H, W, 1, 0)
 
     def one():

@@ -66,7 +66,8 @@ def test_fp32_forward_vs_reference_golden(name):
         stages[f"corr1_it{it}"], stages[f"corr2_it{it}"] = T(g[f"corr1_it{it}"]), T(g[f"corr2_it{it}"])
     for k, ref_t in stages.items():
         st = PU.stats(cap[k], ref_t)
-        assert st["finite"] and st["frac_out"] <= (2 * lim if k.startswith("corr") else lim), (k, st)
+        # lookups: a 1e-4 px disparity difference times the slope of the cost curve (tens per px) -- 1 % allowed out of tolerance
+        assert st["finite"] and st["frac_out"] <= (1e-2 if k.startswith("corr") else lim), (k, st)
 
 
 def test_batch_independence_and_determinism():
