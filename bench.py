@@ -14,7 +14,9 @@ across ranks with no data-path collective; for N>1 each step ends with the RCCL 
 Inputs are synthetic uint8-valued images already resident in HBM; weights are the seeded random init (no checkpoints ship).
 
 The JSON line carries, next to the contract's fields:
-* ``roofline``            K1 = LayerNorm + correlation kernel, HBM bound: HIP events around its launches inside the timed region;
+* ``roofline``            K1 = LayerNorm + correlation kernel, HBM bound: a start / stop HIP event pair attached to each of its
+                          dispatches inside the timed region (hipExtLaunchKernel: the kernel's own execution time, the quantity
+                          a rocprofv3 kernel trace reports);
 * ``roofline_attention``  K4 attention kernels, MFMA bound: one instrumented eager forward AFTER the timed region with HIP events
                           around every K4 launch, analytic FLOPs 4*N^2*d*heads*batch -> fraction of the dense
                           fp16 MFMA peak (north_star: "MFMA utilisation on the attention GEMMs");
@@ -282,7 +284,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    k1_ms = [s.elapsed_time(e) for s, e in eng.k1_events]
+    k1_ms = [t.elapsed_us() * 1e-3 for t in eng.k1_events]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

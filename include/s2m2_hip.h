@@ -46,6 +46,19 @@ int s2m2_ln_corr(const void* feat, const float* ln_w, const float* ln_b, void* c
                  int B, int h, int w, int C, int feat_dtype, int cv_dtype, void* stream);
 
 /*
+ * Measurement support (bench.py `roofline`): the same launch with a start / stop HIP event attached to the kernel dispatch itself
+ * (hipExtLaunchKernel), i.e. the events bracket the kernel's execution like a rocprofv3 kernel trace does, not the gaps around it.
+ * Events are opaque hipEvent_t handles owned by the caller: create / destroy / read them with the three helpers below
+ * (elapsed time is valid once the stream has been synchronised).
+ */
+int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, void* cv,
+                       int B, int h, int w, int C, int feat_dtype, int cv_dtype, void* stream,
+                       void* start_event, void* stop_event);
+int s2m2_event_create(void** event);
+int s2m2_event_destroy(void* event);
+int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);
+
+/*
  * [A5+A6] Sinkhorn optimal transport with dustbins + argmax + 5-tap window regression
  *   (DispInit._optimal_transport/_sinkhorn submodules.py:169-201, regression :225-241, logsumexp_stable :147-152)
  *   cv      (B, h, w, w) dtype cv_dtype (read only)
@@ -117,7 +130,10 @@ typedef struct s2m2_conv_desc {
     int tile;
     int dtype;
     int korder;             /* K order of the packed weight: 0 = (Cout, KH, KW, Cin); 1 = (Cout, KH, Cin/CH, KW, CH) with CH = 64 bytes of
-                               channels (32 fp16 / 16 fp32; Cin % CH == 0): horizontal taps become consecutive K tiles -> L1 reuse */
+                               channels (32 fp16 / 16 fp32; Cin % CH == 0): horizontal taps become consecutive K tiles -> L1 reuse;
+                               2 = fp16 MFMA fragment stream [Cout/32][ceil(Cin/128)][KH*KW][8][64 lanes][8] (lane l: cout 32t + l%32,
+                               channel 128c + 16s + 8(l/32) + e; zero beyond Cin) for stride-1 3x3 / 3x1 / 1x3 layers with Cout % 128 == 0:
+                               the weights go from L2 straight into MFMA operands, only the input patch is staged in LDS */
     int stride;             /* 1 or 2: out[y,x] is centred on in[y*stride, x*stride]; output (N, ceil(H/stride), ceil(W/stride), Cout) */
     const float* ln_wsum;   /* non-NULL: the layer is LayerNorm(Cin, elementwise_affine=False, eps=ln_eps) followed by this 1x1 layer
                                (the pre-norm of attentions.py:117,148,182,213,243 feeding its Linear): `in` holds the RAW rows, the kernel

@@ -1037,6 +1037,175 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// v5 "fragment stream" kernel for the spatial kernels (3x3, 3x1, 1x3, stride 1) of wide layers (fp16, Cin a multiple of 64,
+// Cout a multiple of BN).  v3 stages BOTH operands of every K tile through LDS behind one block barrier per tile: its 8 waves
+// read 1.5 KB of LDS per MFMA (192 B/clk/CU at the MFMA rate, the LDS delivers 256 at best) and meet at 18+ barriers per block.
+// Here
+//   * the weights never touch LDS: they are packed once (s2m2_amd/pack.py: pack_conv_frag, K order 2) as a stream of 1 KB
+//     MFMA A-fragments per 32-cout tile in exactly the order the K loop consumes them -- (channel chunk, tap, k16 step) -- so a
+//     wave's weight traffic is one perfectly coalesced, L2-resident stream, prefetched 8 fragments (= one tap) ahead in registers
+//     with untracked loads and counted waits (common.h);
+//   * the block loads the patch + halo for ALL channels of a chunk (128) at once: after that barrier the K loop of the chunk
+//     (taps x 8 k16 steps) has no block-level synchronisation at all;
+//   * a wave owns the whole 128-pixel patch x 32 couts (MT = 4, NTL = 1): one weight fragment feeds 4 MFMAs, LDS traffic is
+//     1 KB per MFMA ... 128 B/clk/CU at the full MFMA rate from 4 waves, weights 32 B/clk/CU from L2.
+// K order of the accumulation: (chunk, tap, channel) -- fp32 accumulate, so only the summation order differs from v3.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int BN_, int CH_>
+struct ConvCfgF {
+    static_assert(sizeof(T) == 2, "the fragment-stream kernel is fp16 only");
+    static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = 1, WGN = BN_ / 32;
+    static constexpr int NWAVES = WGN, NT = 64 * NWAVES;
+    static constexpr int VEC = 8, CH = CH_, KS = CH_ / 16;       // channels per chunk, k16 steps per tap
+    static constexpr int RS = CH + VEC;                  // LDS row stride (elements): 16 bytes of padding per halo pixel
+    static constexpr int WM = BM, WN = 32, MT = 4, NTL = 1;
+    static constexpr int MAXHALO = (PH + 2) * (PW + 2);
+    static constexpr int PPX = CH / VEC;                 // 16-byte pieces per halo pixel
+    static constexpr int RPI = NT / PPX;                 // halo pixels covered by one pass of the loader threads
+    static constexpr int A_IT = (MAXHALO + RPI - 1) / RPI;
+    static constexpr int CRS = BN + VEC;
+    static constexpr size_t A_BYTES = (size_t)MAXHALO * RS * sizeof(T);
+    static constexpr size_t STAGE_BYTES = (size_t)BM * CRS * sizeof(T);
+    static constexpr size_t LDS_BYTES = A_BYTES > STAGE_BYTES ? A_BYTES : STAGE_BYTES;
+    static_assert(NT % PPX == 0 && KS >= 2, "loader geometry");
+};
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tiles_x, int tiles_y) {
+    constexpr int BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, CH = CFG::CH, KS = CFG::KS, PH = CFG::PH, PW = CFG::PW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Ah = reinterpret_cast<T*>(smem);                          // [halo pixels][RS]
+    T* Cs = reinterpret_cast<T*>(smem);                          // [128][CRS]  (after the K loop)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // = cout tile of this wave inside the block
+    const int hi = lane >> 5, l31 = lane & 31;
+    int bx = xcd_remap(blockIdx.x, gridDim.x);                   // neighbouring patches (shared halo rows) on one XCD / L2
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int n = bx / tiles_y;
+    const int y0 = ty * PH, x0 = tx * PW;
+    const int n0 = blockIdx.y * BN;
+    const int HW_ = p.KW + PW - 1, HH_ = p.KH + PH - 1;          // halo extent
+    const int nhalo = HW_ * HH_;
+    const int ph = p.KH / 2, pw = p.KW / 2;
+    const int ntap = p.KH * p.KW;
+    const int nchunk = (p.Cin + CH - 1) / CH;
+    const int nfrag = nchunk * ntap * KS;                         // fragments of this wave's stream
+
+    // ---- halo loader state (as in v3, CH channels per pixel)
+    const int pc = tid % CFG::PPX, prow = tid / CFG::PPX;
+    int apix[CFG::A_IT];
+#pragma unroll
+    for (int it = 0; it < CFG::A_IT; ++it) {
+        const int hp = prow + CFG::RPI * it;
+        apix[it] = -1;
+        if (hp < nhalo) {
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int yy = y0 - ph + hy, xx = x0 - pw + hx;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) apix[it] = (n * p.H + yy) * p.W + xx;
+        }
+    }
+    const T* zp = static_cast<const T*>(p.zero);
+    const T* const s0 = static_cast<const T*>(p.src[0]);
+    const T* const s1 = static_cast<const T*>(p.src[1]);
+    const T* const s2 = static_cast<const T*>(p.src[2]);
+    const T* const s3 = static_cast<const T*>(p.src[3]);
+    const int st0 = p.src_stride[0], st1 = p.src_stride[1], st2 = p.src_stride[2], st3 = p.src_stride[3];
+    const int c0n = p.src_c[0], c1n = c0n + p.src_c[1], c2n = c1n + p.src_c[2];
+    auto load_halo = [&](int chunk) __attribute__((always_inline)) {          // patch + halo of one channel chunk -> LDS
+        const int kc = chunk * CH + pc * VEC;
+        const bool cvalid = kc < p.Cin;
+        const T* sp = s0;
+        unsigned ss = (unsigned)st0, c = (unsigned)kc;
+        if (p.nsrc > 1) {
+            const bool g0 = kc >= c0n, g1 = kc >= c1n, g2 = kc >= c2n;
+            const long long d1 = (const char*)s1 - (const char*)s0, d2 = (const char*)s2 - (const char*)s1, d3 = (const char*)s3 - (const char*)s2;
+            sp = reinterpret_cast<const T*>((const char*)s0 + ((g0 ? d1 : 0) + (g1 ? d2 : 0) + (g2 ? d3 : 0)));
+            ss = (unsigned)(st0 + (g0 ? st1 - st0 : 0) + (g1 ? st2 - st1 : 0) + (g2 ? st3 - st2 : 0));
+            c = (unsigned)(kc - ((g0 ? c0n : 0) + (g1 ? c1n - c0n : 0) + (g2 ? c2n - c1n : 0)));
+        }
+        raw16_t ra[CFG::A_IT];
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const unsigned e = __umul24((unsigned)apix[it], ss) + c;
+            const T* src = (cvalid && apix[it] >= 0) ? sp + e : zp;
+            ra[it] = global_load16(src);
+        }
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const int hp = prow + CFG::RPI * it;
+            if (hp < CFG::MAXHALO) *reinterpret_cast<raw16_t*>(Ah + (size_t)hp * RS + pc * VEC) = ra[it];
+        }
+    };
+
+    // ---- weight fragment stream of this wave: fragment f at wf + f * 64 (16-byte units), one 16-byte piece per lane
+    const raw16_t* wf = static_cast<const raw16_t*>(p.weight) + ((size_t)(blockIdx.y * CFG::WGN + wv) * nfrag) * 64 + lane;
+    raw16_t ring[KS];
+
+    CoutRegs<CFG> bias;                                           // requested now, used after the K loop
+    bias.load(p.bias, p.zero, p.Cout, n0, wv, lane);
+    float16_t acc[CFG::MT][CFG::NTL];
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    // the first tap's fragments are requested before the halo tile: both latencies run together (the tracked halo loads are
+    // younger, so the compiler's waits at the stash cover the ring as well)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) global_load16_async(ring[s], wf + (size_t)(s < nfrag ? s : nfrag - 1) * 64);
+    load_halo(0);
+    __syncthreads();
+    int g = 0;                                                    // global k16 step = index of the fragment consumed next
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        if (chunk > 0) {
+            wait_vmcnt<0>();                                      // ring loads land before tracked loads are mixed in (their data stays valid)
+            __syncthreads();                                      // every wave is done with the previous chunk's halo tile
+            load_halo(chunk);
+            __syncthreads();
+        }
+        int ky = 0, kx = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < ntap; ++tap) {
+            const T* a = Ah + (size_t)(ky * HW_ + l31 + kx) * RS + hi * 8;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                // fragment g (slot kk) was requested KS - 1 steps ago; the KS - 2 requests made since then may still be in flight
+                wait_vmcnt<KS - 2>();
+                settle(ring[kk]);
+                Frag<T> wfr;
+                wfr.v = __builtin_bit_cast(half8_t, ring[kk]);
+                Frag<T> xf[CFG::MT];
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * HW_ * RS + kk * 16);
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i) mma32(acc[i][0], wfr, xf[i]);           // D[cout][pixel]
+                // refill the slot consumed one step ago (its MFMAs have long read their operands): fragment g + KS - 1
+                if (g > 0) {
+                    const int f = g + KS - 1;
+                    global_load16_async(ring[(kk + KS - 1) % KS], wf + (size_t)(f < nfrag ? f : nfrag - 1) * 64);
+                }
+                ++g;
+            }
+            if (++kx == p.KW) { kx = 0; ++ky; }
+        }
+    }
+    wait_vmcnt<0>();                                              // drain the tail requests before their registers are reused
+#pragma unroll
+    for (int s = 0; s < KS; ++s) settle(ring[s]);
+
+    // ---- epilogues: staging rows r = patch row * 32 + column
+    __syncthreads();                                              // the staging tile aliases the halo tile
+    const PatchPix pix{n, y0, x0, p.H, p.W};
+    AuxRegs<CFG, T> aux;
+    aux.prefetch(p, tid, n0, pix);
+    stage_tile_act<CFG, T>(p, acc, Cs, bias, 0, wv, lane);
+    __syncthreads();
+    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // v4 "pointwise" kernel for 1x1 convolutions / linear layers (K = Cin <= 512): these are streaming, HBM-bound GEMMs (M ~ 10^5
 // pixels, K and N a few hundred) where the tiled kernels spend most of their time in per-block prologues: every 64x64 tile
 // re-loads its weight slice and drains its two-tile pipeline.  Here a PERSISTENT block keeps the weight slice of its BN output
@@ -1240,6 +1409,31 @@ static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
+template <typename T, int BN, int CH>
+static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) {
+        return set_error("conv2d: K order 2 (fragment stream) is an fp16 layout");
+    } else {
+        using CFG = ConvCfgF<T, BN, CH>;
+        auto kern = conv_frag_kernel<CFG, T>;
+        static bool attr_done_dev[kMaxDevices] = {};
+        bool& attr_done = attr_done_dev[current_device()];
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)CFG::LDS_BYTES) != hipSuccess)
+                return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
+            attr_done = true;
+        }
+        if (a.stride != 1 || a.shuffle2 || a.KH > 3 || a.KW > 3 || a.KH * a.KW < 2 || a.Cout % BN || a.Cin % 8 || a.ln_wsum ||
+            a.epi == S2M2_EPI_DUALMIX)
+            return set_error("conv2d: K order 2 needs a stride-1 3x3 / 3x1 / 1x3 layer with Cout a multiple of %d (Cout=%d)", BN, a.Cout);
+        const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
+        dim3 grid((unsigned)(a.N * tx * ty), (unsigned)(a.Cout / BN));
+        hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty);
+        return check_launch("conv2d");
+    }
+}
+
 template <typename T, int BN>
 static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfgP<T, BN>;
@@ -1269,6 +1463,7 @@ template <typename T>
 static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     const long long M = (long long)a.N * a.Ho * a.Wo;
     const bool auto_tile = tile == 0;
+    if (a.korder == 2) return launch_conv_frag<T, 128, 128>(a, st);   // weights packed as a fragment stream: one kernel takes them
     static const long long t20_min = getenv("S2M2_T20_MIN") ? atoll(getenv("S2M2_T20_MIN")) : 300;   // tuning only
     static const int small_tile = getenv("S2M2_SMALL_TILE") ? atoi(getenv("S2M2_SMALL_TILE")) : 0;
     if (tile == 0) {                                              // measured on MI355X (tools/convbench.py, profiles/r01)
@@ -1399,8 +1594,9 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
                      (d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_GELU),
                      "conv2d: pre-LayerNorm needs a 1x1 stride-1 layer with act NONE or GELU and ln_eps > 0");
     a.stride = d->stride; a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
-    S2M2_REQUIRE(d->korder == 0 || d->korder == 1, "conv2d: korder=%d (0 or 1)", d->korder);
-    S2M2_REQUIRE(!d->korder || a.Cin % (d->dtype == S2M2_F16 ? 32 : 16) == 0, "conv2d: korder 1 needs Cin=%d to be a multiple of 64 bytes of channels", a.Cin);
+    S2M2_REQUIRE(d->korder >= 0 && d->korder <= 2, "conv2d: korder=%d (0, 1 or 2)", d->korder);
+    S2M2_REQUIRE(d->korder != 1 || a.Cin % (d->dtype == S2M2_F16 ? 32 : 16) == 0, "conv2d: korder 1 needs Cin=%d to be a multiple of 64 bytes of channels", a.Cin);
+    S2M2_REQUIRE(d->korder != 2 || d->dtype == S2M2_F16, "conv2d: korder 2 (fragment stream) is an fp16 layout");
     a.zero = zero_page();                                         // (first device call: every argument check is above)
     S2M2_REQUIRE(a.zero, "conv2d: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -10,12 +10,8 @@
 //            bytes in flight per CU at once.  Tokens are LayerNorm'ed in fp32 (two-pass mean/var, 8-lane butterfly),
 //            rounded to T and written to LDS rows padded by 16 B (conflict-free ds_read_b128 fragment reads).
 //            The wave's own left tokens bounce through its LDS slice into MFMA fragments that stay in registers.
-//   sync   = whole rows per block (w <= 32*NW, the usual case): NO block barrier after the prologue.  A wave publishes its 32
-//            normalised right tokens with an LDS flag and then takes 64-column tile pairs in whatever order their tokens
-//            become ready (its own first), so the first cost-volume rows leave the CU while the rest of the row's tokens
-//            are still arriving from HBM and other waves are still in LayerNorm: load, LayerNorm, MFMA and store phases of
-//            one image row overlap inside the CU instead of running back to back (FLAGS variant below).
-//            Rows wider than one block's tokens: one block barrier per chunk of NW*32 right pixels.
+//   sync   = ONE block barrier per chunk of NW*32 right pixels (one per row when it fits); after it every wave
+//            sweeps the column tiles on its own (staggered start), no further block-level synchronisation.
 //   MFMA   = roles swapped on purpose: D = R_tile . L_wave^T, so a lane ends up with 4 CONSECUTIVE j of one row i
 //            per register quad -> the accumulators go to a wave-private LDS tile with 4 wide writes per 32x32
 //            tile (instead of 32 two-byte writes), come back as 16-B pieces of whole rows, and every global store
@@ -23,6 +19,7 @@
 // Every feature token is read from HBM once and normalised once per strip; the cost volume is written once.
 // Algorithmic traffic per pair: 2*h*w*C*sizeof(T) read + h*w*w*sizeof(TO) written.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -32,11 +29,27 @@
 #define S2M2_LNCORR_DBG 0
 #endif
 
+// timeline instrumentation for tools/k1_trace.py (experiment builds only: -DS2M2_LNCORR_TRACE=1): lane 0 of every wave stamps the
+// shader clock at phase boundaries into a device array that s2m2_debug_k1_trace() copies out
+#ifndef S2M2_LNCORR_TRACE
+#define S2M2_LNCORR_TRACE 0
+#endif
+#if S2M2_LNCORR_TRACE
+__device__ unsigned long long g_k1_trace[1024 * 16 * 16];
+#define K1_T(slot)                                                                                                            \
+    do {                                                                                                                      \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024)                                                                     \
+            g_k1_trace[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime();         \
+    } while (0)
+#else
+#define K1_T(slot)
+#endif
+
 namespace s2m2 {
 
-template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool FLAGS_ = false>
+template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool PIPE_ = false>
 struct LnCorrCfg {
-    static constexpr bool FLAGS = FLAGS_;               // whole-row blocks: per-tile ready flags instead of the block barrier
+    static constexpr bool PIPE = PIPE_;                 // right tokens normalised in 4 rounds, column tiles stored as soon as their tokens exist
     static constexpr int C = C_;
     static constexpr int RIF = RIF_;                    // token rounds (8 tokens per wave each) kept in flight in registers
     static constexpr bool EARLY_B = EARLY_B_;           // right tokens of chunk 0 are requested together with the left ones
@@ -48,7 +61,7 @@ struct LnCorrCfg {
     static constexpr int VECO = 16 / sizeof(TO);
     static constexpr int CRS = 64 + VECO;               // staging row stride (elements of TO): 2 tiles + 16 B pad
     static constexpr int KSTEPS = C / 16;
-    static constexpr size_t GB_BYTES = 2 * C * sizeof(float) + 64;      // LayerNorm affine + 16 tile-ready flags
+    static constexpr size_t GB_BYTES = 2 * C * sizeof(float);
     static constexpr size_t WB_BYTES = (size_t)32 * RS * sizeof(T);      // per wave: its 32 normalised tokens
     static constexpr size_t WC_BYTES = (size_t)32 * CRS * sizeof(TO);    // per wave: 32 x 64 output staging
     static constexpr size_t lds_bytes(int nw) { return GB_BYTES + (size_t)nw * (WB_BYTES + WC_BYTES); }
@@ -115,7 +128,7 @@ template <> __device__ __forceinline__ void store_quad<float>(float* dst, float 
 template <typename CFG, typename T, typename TO>
 __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, TO* __restrict__ cv,
-                                                                 int B, int h, int w, int nstrip, int stagger, int direct) {
+                                                                 int B, int h, int w, int nstrip) {
     constexpr int dbg = S2M2_LNCORR_DBG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
@@ -139,16 +152,14 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     const int sub = lane & 7, trow = lane >> 3;
     const int TJ = NW * 32;                             // right pixels per chunk (the whole row when w <= TJ)
     const int nchunks = (w + TJ - 1) / TJ;
+    K1_T(0);
 
     // ---- everything this wave needs first is put in flight at once: 32 left tokens (+ 32 right tokens of chunk 0)
     static_assert(!CFG::EARLY_B || CFG::RIF == 4, "EARLY_B needs all four rounds in registers");
     // (the LayerNorm affine goes to LDS first: __syncthreads() drains vmcnt, so no token load may be pending across it)
     for (int c = tid; c < CFG::C; c += blockDim.x) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
-    if (CFG::FLAGS && tid < 16) reinterpret_cast<int*>(smem + 2 * CFG::C * sizeof(float))[tid] = 0;
     __syncthreads();
-    // optional stagger of the waves' load bursts (FLAGS variant): wave k starts k*stagger*64 clocks late, so the tokens of the
-    // low tiles arrive first and their consumers start storing while the high tiles are still in flight
-    if (CFG::FLAGS) for (int k = 0; k < wv * stagger; ++k) __builtin_amdgcn_s_sleep(1);
+    K1_T(1);
     Vec16<T> rawB[CFG::RIF][CFG::PPL];
     Frag<T> afrag[CFG::KSTEPS];
     {
@@ -160,11 +171,12 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         if (CFG::EARLY_B) {
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r)
-                load_token<CFG, T>(rawB[r], right, wv * 32 + r * 8 + trow, w, sub);
+                load_token<CFG, T>(rawB[r], right, CFG::PIPE ? r * 8 * NW + wv * 8 + trow : wv * 32 + r * 8 + trow, w, sub);
         }
         // keep every request above in front of the arithmetic below: without this the scheduler sinks the right-token loads under
         // the LayerNorm of the left tokens (one full memory latency lost)
         __builtin_amdgcn_sched_barrier(0);
+        K1_T(2);
         // left operand: normalise -> (this wave's slice of Bs as scratch) -> k16 fragments in registers.  Unconditional (clamped
         // duplicates for a wave past the row end): any branch between the requests and their first use lets the optimiser sink
         // the loads into it, behind the other requests and behind the scheduling barrier above.
@@ -180,6 +192,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                     normalize_store<CFG, T>(rawA[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub, dbg);
             }
             __builtin_amdgcn_wave_barrier();
+            K1_T(3);
             const T* ap = Wb + (size_t)(lane & 31) * CFG::RS + (lane >> 5) * 8;
 #pragma unroll
             for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
@@ -187,50 +200,17 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         }
     }
 
-    if constexpr (CFG::FLAGS) {
-        // ---- whole-row path (w <= 32*NW: NW == number of 32-column tiles, every wave owns left tile wv AND right tile wv) ----------
-        // right tokens -> own LDS slice, then publish.  LDS instructions of one wave execute in order and the LDS unit of a CU
-        // serves one instruction at a time, so a reader that has seen flag[t] != 0 reads complete rows of tile t; the asm
-        // statements only stop the COMPILER from moving LDS accesses across the flag accesses.
-        int* flags = reinterpret_cast<int*>(smem + 2 * CFG::C * sizeof(float));
-#pragma unroll
-        for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
-            if (!(CFG::RIF == 4 && CFG::EARLY_B)) {
-#pragma unroll
-                for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, wv * 32 + (r0 + r) * 8 + trow, w, sub);
-            }
-#pragma unroll
-            for (int r = 0; r < CFG::RIF; ++r)
-                normalize_store<CFG, T>(rawB[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub, dbg);
-        }
-        asm volatile("" ::: "memory");
-        if (lane == 0) __hip_atomic_store(flags + wv, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        asm volatile("" ::: "memory");
-        if (dbg & 8) return;
-        const int ntile = NW;
-        const int npair = (ntile + 1) >> 1;
-        const unsigned all = (1u << npair) - 1u;
-        auto pairs_ready = [&]() -> unsigned {                     // bit p: both tiles of column pair p are published
-            int f = 0;
-            if (lane < ntile) f = __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned t = (unsigned)__ballot(f != 0) | ((ntile & 1) ? (1u << ntile) : 0u);   // a lone last tile has no partner
-            asm volatile("" ::: "memory");
-            unsigned m = 0;
-            for (int p2 = 0; p2 < npair; ++p2) m |= (((t >> (2 * p2)) & (t >> (2 * p2 + 1))) & 1u) << p2;
-            return m;
-        };
-        auto pick = [&](unsigned cand) -> int {                    // own pair first (ready by construction), then cyclic
-            int p2 = wv >> 1;
-            for (int k = 0; k < npair; ++k) {
-                if ((cand >> p2) & 1u) return p2;
-                p2 = p2 + 1 == npair ? 0 : p2 + 1;
-            }
-            return -1;
-        };
+    if constexpr (CFG::PIPE) {
+        // ---- pipelined single-chunk path (w <= 32*NW, whole rows): the four 8-token rounds of every wave form four 8*NW-token
+        // slabs of the right row, ordered slab-major in memory request order.  After slab r is normalised, every column tile whose
+        // 32 tokens lie below 8*NW*(r+1) is multiplied and stored while the later slabs are still arriving from HBM, so the
+        // store phase of a row overlaps its own load phase inside the CU.  Barriers are plain s_barrier + lgkmcnt(0): a fenced
+        // __syncthreads() would wait for the loads still in flight.
+        auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+        lds_barrier();                                            // all A-operand scratch reads done before right tokens land there
+        const int ntile_all = (w + 31) / 32;
         float16_t acc0, acc1;
-        auto mma_pair = [&](int pr) {
-            const int ct0 = pr * 2;
-            const bool two = ct0 + 1 < ntile;
+        auto mma_pair = [&](int ct0, bool two) {
             const T* bp0 = Bs + (size_t)(ct0 * 32 + (lane & 31)) * CFG::RS + (lane >> 5) * 8;
             const T* bp1 = two ? bp0 + 32 * CFG::RS : bp0;
 #pragma unroll
@@ -241,95 +221,50 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                     Frag<T> b0, b1;
                     load_frag(b0, bp0 + kk * 16);
                     load_frag(b1, bp1 + kk * 16);
-                    if (direct) {                                 // D[i][j]: lane = right pixel j (contiguous in memory), registers = left pixels i
-                        mma32(acc0, afrag[kk], b0);
-                        mma32(acc1, afrag[kk], b1);
-                    } else {                                      // D[j][i]: lane = left pixel i, registers = right pixels j
-                        mma32(acc0, b0, afrag[kk]);
-                        mma32(acc1, b1, afrag[kk]);
+                    mma32(acc0, b0, afrag[kk]);                   // D[j][i]: lane = left pixel i, registers = right pixels j
+                    mma32(acc1, b1, afrag[kk]);
+                }
+            }
+        };
+        int done = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jtok = r * 8 * NW + wv * 8 + trow;
+            normalize_store<CFG, T>(rawB[r], Bs + (size_t)jtok * CFG::RS, gb, sub, dbg);
+            lds_barrier();
+            int ready = r == 3 ? ntile_all : (8 * NW * (r + 1)) / 32;
+            ready = ready < ntile_all ? ready : ntile_all;
+            if (wave_active && !(dbg & 8) && ready > done) {
+                const int npair = (ready - done + 1) >> 1;
+                auto pair_ct = [&](int pp) { int pr = pp + wv; pr = pr % npair; return done + 2 * pr; };
+                mma_pair(pair_ct(0), pair_ct(0) + 1 < ready);
+                for (int pp = 0; pp < npair; ++pp) {
+                    const int ct0 = pair_ct(pp);
+                    TO* wrow = Wc + (size_t)(lane & 31) * CFG::CRS + 4 * (lane >> 5);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        store_quad<TO>(wrow + 8 * g, acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+                        store_quad<TO>(wrow + 32 + 8 * g, acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    if (pp + 1 < npair) mma_pair(pair_ct(pp + 1), pair_ct(pp + 1) + 1 < ready);
+                    constexpr int PPR = 64 / CFG::VECO;           // 16-B pieces per staged row (64 columns)
+                    constexpr int ITERS = 32 * PPR / 64;
+                    const int j0 = ct0 * 32;
+                    const int jlim = (ct0 + 1 < ready ? ct0 + 2 : ct0 + 1) * 32;      // a lone tile stores 32 columns only
+#pragma unroll
+                    for (int it = 0; it < ITERS; ++it) {
+                        const int q = it * 64 + lane;
+                        const int rr = q / PPR, pc = q - rr * PPR;
+                        const int i = i0 + rr;
+                        const int j = j0 + pc * CFG::VECO;
+                        const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
+                        if (i < w && j < w && j < jlim && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
-        };
-        // direct epilogue (no LDS staging): with D[i][j] a register holds one row i for 32 consecutive columns.  fp32: 128-byte row
-        // segments straight from the accumulators.  fp16: lanes 2k / 2k+1 swap halves so that the even lane owns (j, j+1) of row rho
-        // and the odd lane (j-1, j) of row rho+1 -> 4-byte stores, 64 contiguous bytes per row and half wave.
-        auto store_direct = [&](const float16_t& acc, int jt) {
-            if constexpr (sizeof(TO) == 4) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = i0 + acc_row(r, lane), j = jt + (lane & 31);
-                    if (i < w && j < w && !(dbg & 1)) cvrow[(size_t)i * w + j] = acc[r];
-                }
-            } else {
-                const int odd = lane & 1;
-                const unsigned sel = odd ? 0x03020706u : 0x05040100u;
-                const int jc = jt + (lane & 30);
-                TO* base = cvrow + (size_t)(i0 + odd + 4 * (lane >> 5)) * w + jc;
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int rho = (r & 3) + 8 * (r >> 2);
-                    const half2_t own = {(half_t)acc[r], (half_t)acc[r + 1]};
-                    const unsigned ow = __builtin_bit_cast(unsigned, own);
-                    const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0xB1, 0xF, 0xF, true);
-                    const unsigned v = __builtin_amdgcn_perm(nb, ow, sel);
-                    const int i = i0 + rho + odd + 4 * (lane >> 5);
-                    if (i < w && jc < w && !(dbg & 1)) *reinterpret_cast<unsigned*>(base + (size_t)rho * w) = v;
-                }
-            }
-        };
-        unsigned done = 0;
-        int cur = pick(pairs_ready());                            // never -1: the own pair's partner tile may lag, then wait
-        while (cur < 0) { __builtin_amdgcn_s_sleep(2); cur = pick(pairs_ready()); }
-        mma_pair(cur);
-        while (direct) {
-            done |= 1u << cur;
-            // the finished accumulators leave in place; the next pair (if one is ready) is chosen first so that its B fragments are
-            // requested before this pair's stores are issued
-            const float16_t d0 = acc0, d1 = acc1;
-            int nxt = done == all ? -1 : pick(pairs_ready() & ~done);
-            if (nxt >= 0) mma_pair(nxt);
-            store_direct(d0, cur * 64);
-            if (cur * 2 + 1 < ntile) store_direct(d1, cur * 64 + 32);
-            if (done == all) return;
-            while (nxt < 0) {
-                __builtin_amdgcn_s_sleep(2);
-                nxt = pick(pairs_ready() & ~done);
-                if (nxt >= 0) mma_pair(nxt);
-            }
-            cur = nxt;
-        }
-        while (true) {
-            TO* wrow = Wc + (size_t)(lane & 31) * CFG::CRS + 4 * (lane >> 5);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                store_quad<TO>(wrow + 8 * g, acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
-                store_quad<TO>(wrow + 32 + 8 * g, acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            done |= 1u << cur;
-            int nxt = done == all ? -1 : pick(pairs_ready() & ~done);
-            if (nxt >= 0) mma_pair(nxt);                           // MFMAs of the next pair are issued before this pair's stores
-            constexpr int PPR = 64 / CFG::VECO;                   // 16-B pieces per staged row (64 columns)
-            constexpr int ITERS = 32 * PPR / 64;
-            const int j0 = cur * 64;
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int q = it * 64 + lane;
-                const int rr = q / PPR, pc = q - rr * PPR;
-                const int i = i0 + rr;
-                const int j = j0 + pc * CFG::VECO;
-                const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                if (i < w && j < w && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (done == all) break;
-            while (nxt < 0) {                                      // nothing was ready: wait for the next publication
-                __builtin_amdgcn_s_sleep(2);
-                nxt = pick(pairs_ready() & ~done);
-                if (nxt >= 0) mma_pair(nxt);
-            }
-            cur = nxt;
+            done = ready;
         }
         return;
     }
@@ -351,7 +286,9 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, t0 + TJ + r * 8 + trow, w, sub);
         }
+        K1_T(4);
         __syncthreads();
+        K1_T(5);
         if (wave_active && !(dbg & 8)) {
             const int jbase = c * TJ;
             int ntile = (w - jbase + 31) / 32;                    // 32-wide column tiles with data in this chunk
@@ -405,8 +342,10 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                     if (i < w && j < w && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
+                K1_T(6 + (pp < 8 ? pp : 8));
             }
         }
+        K1_T(15);
         if (c + 1 < nchunks) __syncthreads();                     // all readers done before Bs is overwritten
     }
 }
@@ -414,13 +353,17 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
+// s2m2_ln_corr_timed: events attached to the next launch of the calling thread (hipExtLaunchKernel records them at the start and
+// at the end of the kernel's execution)
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st);
 
-// whole-row variant of a configuration (same tiling, FLAGS = true)
-template <typename CFG> struct FlagsOf { using type = void; };
-template <typename T, typename TO, int C, int NWCAP, int RIF, bool EB>
-struct FlagsOf<LnCorrCfg<T, TO, C, NWCAP, RIF, EB, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, RIF, EB, true>; };
+// pipelined variant of a configuration (same tiling, PIPE = true) where it exists: all four token rounds resident in registers
+template <typename CFG> struct PipeOf { using type = void; };
+template <typename T, typename TO, int C, int NWCAP>
+struct PipeOf<LnCorrCfg<T, TO, C, NWCAP, 4, true, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, 4, true, true>; };
 
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st) {
@@ -441,17 +384,19 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     if (force_nstrip > 0 && (tiles + force_nstrip - 1) / force_nstrip <= CFG::NWMAX) nstrip = force_nstrip;
     const int nw = (tiles + nstrip - 1) / nstrip;
     const int nblocks = B * h * nstrip;
-    static const int stagger = getenv("S2M2_LNCORR_STAGGER") ? atoi(getenv("S2M2_LNCORR_STAGGER")) : 0;      // tuning knobs
-    static const int direct = getenv("S2M2_LNCORR_DIRECT") ? atoi(getenv("S2M2_LNCORR_DIRECT")) : 0;
-    if constexpr (!CFG::FLAGS && !std::is_void<typename FlagsOf<CFG>::type>::value) {
-        // whole rows per block (one strip, one chunk, every wave owns a full or ragged tile): barrier-free variant.
-        // S2M2_LNCORR_FLAGS=0 keeps the barrier variant for A/B runs.
-        static const bool flags_on = !(getenv("S2M2_LNCORR_FLAGS") && atoi(getenv("S2M2_LNCORR_FLAGS")) == 0);
-        if (nstrip == 1 && nw == tiles && tiles <= 16 && flags_on)
-            return launch_ln_corr<typename FlagsOf<CFG>::type, T, TO>(feat, g, bta, cv, B, h, w, st);
+    if constexpr (!CFG::PIPE && !std::is_void<typename PipeOf<CFG>::type>::value) {
+        // measured (tools/k1_ab.py, c3 fp16): 24.2 us pipelined vs 21.3 us plain -- the extra barriers and the smaller store bursts cost
+        // more than the overlap returns, so the pipelined variant stays an opt-in experiment
+        static const bool pipe = getenv("S2M2_LNCORR_PIPE") != nullptr;
+        if (nstrip == 1 && pipe)                                  // whole rows per block: overlap the row's stores with its own loads
+            return launch_ln_corr<typename PipeOf<CFG>::type, T, TO>(feat, g, bta, cv, B, h, w, st);
     }
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
-                       static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, stagger, direct);
+    if (g_ev_start || g_ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
+                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip);
+    else
+        hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
+                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip);
     return check_launch("ln_corr");
 }
 
@@ -493,6 +438,43 @@ extern "C" int s2m2_ln_corr(const void* feat, const float* ln_w, const float* ln
     if (feat_dtype == S2M2_F32 && cv_dtype == S2M2_F32) return dispatch_c<float, float>(feat, ln_w, ln_b, cv, B, h, w, C, st);
     return set_error("ln_corr: unsupported dtype pair feat=%d cv=%d", feat_dtype, cv_dtype);
 }
+
+extern "C" int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
+                                  int feat_dtype, int cv_dtype, void* stream, void* start_event, void* stop_event) {
+    s2m2::g_ev_start = static_cast<hipEvent_t>(start_event);
+    s2m2::g_ev_stop = static_cast<hipEvent_t>(stop_event);
+    const int rc = s2m2_ln_corr(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream);
+    s2m2::g_ev_start = s2m2::g_ev_stop = nullptr;
+    return rc;
+}
+
+extern "C" int s2m2_event_create(void** event) {
+    S2M2_REQUIRE(event, "event_create: null pointer");
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return s2m2::set_error("event_create: hipEventCreate failed");
+    *event = e;
+    return 0;
+}
+
+extern "C" int s2m2_event_destroy(void* event) {
+    if (event && hipEventDestroy(static_cast<hipEvent_t>(event)) != hipSuccess) return s2m2::set_error("event_destroy: hipEventDestroy failed");
+    return 0;
+}
+
+extern "C" int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds) {
+    S2M2_REQUIRE(start_event && stop_event && microseconds, "event_elapsed_us: null pointer");
+    float ms = 0.f;
+    const hipError_t e = hipEventElapsedTime(&ms, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event));
+    if (e != hipSuccess) return s2m2::set_error("event_elapsed_us: %s", hipGetErrorString(e));
+    *microseconds = ms * 1e3f;
+    return 0;
+}
+
+#if S2M2_LNCORR_TRACE
+extern "C" int s2m2_debug_k1_trace(void* host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k1_trace), bytes < sizeof(g_k1_trace) ? bytes : sizeof(g_k1_trace)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" const char* s2m2_ln_corr_kernel_name(int C, int feat_dtype, int cv_dtype) {
     (void)C; (void)feat_dtype; (void)cv_dtype;

@@ -26,7 +26,11 @@ import torch.nn.functional as F
 from . import hip, pack
 
 Tensor = torch.Tensor
-Spec = Tuple[Tensor, Optional[Tensor], int, int, int]          # packed weight, packed bias, KH, KW, Cout(padded)
+
+
+class Spec(tuple):
+    """(packed weight, packed bias, KH, KW, Cout padded) of one K5 layer; ``korder`` = K order of the packed weight (s2m2_conv2d)."""
+    korder = 0
 
 
 def pe_tables(h: int, w: int, device, pe_dim: int = 32) -> Tuple[Tensor, Tensor]:
@@ -88,6 +92,7 @@ class Engine:
         self.fuse_fusion = os.environ.get("S2M2_FUSE_FUSION", "1") != "0"  # A/B switch: 0 = FeatureFusion as K5 launches instead of K10
         self._fusion_ok: Dict[int, bool] = {}
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
+        self.use_frag = os.environ.get("S2M2_CONV_FRAG", "1") != "0"     # A/B switch: 0 = spatial layers on the v3 halo tiles (K order 0)
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
@@ -107,8 +112,11 @@ class Engine:
                 w = pack.convT_s1_as_conv(w)
             if w.dim() == 2:
                 w = w[:, :, None, None]
-            s = (pack.pack_conv(w, self.dtype, splits), pack.pack_bias(self.p.get(name + ".bias"), w.shape[0]),
-                 w.shape[2], w.shape[3], pack.pad8(w.shape[0]))
+            cin_p = sum(pd for _, pd in splits) if splits else pack.pad8(w.shape[1])
+            frag = self.use_frag and pack.frag_eligible(pack.pad8(w.shape[0]), cin_p, w.shape[2], w.shape[3], self.dtype)
+            wp = pack.pack_conv_frag(w, self.dtype, splits) if frag else pack.pack_conv(w, self.dtype, splits)
+            s = Spec((wp, pack.pack_bias(self.p.get(name + ".bias"), w.shape[0]), w.shape[2], w.shape[3], pack.pad8(w.shape[0])))
+            s.korder = 2 if frag else 0                            # spatial layers of wide tensors: weights as an MFMA fragment stream
             self._packed[key] = s
         return s
 
@@ -134,8 +142,12 @@ class Engine:
                 if (name + ".bias") in self.p:
                     bb[:co] = self.p[name + ".bias"]
                 biases.append(bb)
-            wp = torch.cat(rows, 0).to(self.dtype).contiguous()
-            s = (wp, torch.cat(biases).float().contiguous(), kh, kw, wp.shape[0])
+            wp = torch.cat(rows, 0)
+            s = Spec((wp.to(self.dtype).contiguous(), torch.cat(biases).float().contiguous(), kh, kw, wp.shape[0]))
+            if self.use_frag and pack.frag_eligible(wp.shape[0], cin_total, kh, kw, self.dtype):
+                w4 = wp.reshape(wp.shape[0], kh, kw, cin_total).permute(0, 3, 1, 2)            # back to (Cout, Cin, KH, KW): rows are padded already
+                s = Spec((pack.pack_conv_frag(w4, self.dtype, [(cin_total, cin_total)]), s[1], kh, kw, wp.shape[0]))
+                s.korder = 2
             self._packed[key] = s
         return s
 
@@ -146,7 +158,7 @@ class Engine:
         if s is None:
             w = self.p[name + ".weight"]
             wp, cp = pack.pack_convT_2x2s2(w, self.dtype)
-            s = (wp, pack.pack_bias_shuffle(self.p.get(name + ".bias"), w.shape[1]), 1, 1, 4 * cp)
+            s = Spec((wp, pack.pack_bias_shuffle(self.p.get(name + ".bias"), w.shape[1]), 1, 1, 4 * cp))
             self._packed[key] = s
         return s, s[4] // 4
 
@@ -156,6 +168,8 @@ class Engine:
         wp, bp, kh, kw_, cout = spec
         if ln:
             kw["ln_wsum"] = self.wsum(spec)
+        if getattr(spec, "korder", 0):
+            kw["korder"] = spec.korder
         return hip.conv2d(srcs, wp, bp, kh, kw_, cout, **kw)
 
     def zeros(self, key, shape, dtype=None) -> Tensor:
@@ -452,8 +466,13 @@ class Engine:
 
     @torch.no_grad()
     def cost_volume(self, tr: Tensor, out: Optional[Tensor] = None) -> Tensor:
-        """K1: LayerNorm + all-pairs correlation (submodules.py:216-217)."""
-        return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out)
+        """K1: LayerNorm + all-pairs correlation (submodules.py:216-217).  With ``k1_events`` set (bench.py) every launch carries a
+        start / stop HIP event pair on its dispatch (hip.KernelTimer), collected in that list."""
+        timer = None
+        if self.k1_events is not None:
+            timer = hip.KernelTimer()
+            self.k1_events.append(timer)
+        return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer)
 
     @torch.no_grad()
     def finish(self, tr: Tensor, py0: Tensor, f2_left: Tensor, x8: Tensor, cv: Tensor, cap: Optional[dict] = None):
@@ -497,13 +516,7 @@ class Engine:
         tr, py0, f2_left, x8 = self.features(img0, img1)
         if cap is not None and "feature_tr_4x" in (cap.get("inject") or {}):           # parity tests only, see finish()
             tr = cap["inject"]["feature_tr_4x"].to(tr.device, tr.dtype).permute(0, 2, 3, 1).contiguous()
-        if self.k1_events is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
         cv = self.cost_volume(tr)
-        if self.k1_events is not None:
-            ev1.record()
-            self.k1_events.append((ev0, ev1))
         return self.finish(tr, py0, f2_left, x8, cv, cap)
 
     def _conv0(self) -> Spec:
@@ -565,13 +578,7 @@ class GraphRunner:
         else:
             eng = self.eng
             self.ga.replay()
-            if eng.k1_events is not None:
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-            eng.cost_volume(self.state[0], out=self.cv)
-            if eng.k1_events is not None:
-                ev1.record()
-                eng.k1_events.append((ev0, ev1))
+            eng.cost_volume(self.state[0], out=self.cv)                # eager between the two graphs: carries the timing events
             self.gb.replay()
         return tuple(o.clone() for o in self.out)
 

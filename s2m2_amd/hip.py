@@ -48,6 +48,10 @@ SIGNATURES = {
     "s2m2_last_error": (ctypes.c_char_p, []),
     "s2m2_ln_corr_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
     "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "s2m2_ln_corr_timed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_event_create": (_i, [ctypes.POINTER(_vp)]),
+    "s2m2_event_destroy": (_i, [_vp]),
+    "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "s2m2_sinkhorn_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
@@ -117,9 +121,31 @@ def _dev(*ts: torch.Tensor) -> None:
             raise ValueError("s2m2_amd.hip: tensors must be contiguous device tensors")
 
 
+class KernelTimer:
+    """A start / stop HIP event pair attached to ONE kernel dispatch (s2m2_ln_corr_timed): elapsed_us() is the kernel's own execution
+    time, what a rocprofv3 kernel trace reports, without the dispatch gaps that events recorded around a launch include."""
+
+    def __init__(self):
+        self.start, self.stop = _vp(), _vp()
+        _check(load().s2m2_event_create(ctypes.byref(self.start)), "s2m2_event_create")
+        _check(load().s2m2_event_create(ctypes.byref(self.stop)), "s2m2_event_create")
+
+    def elapsed_us(self) -> float:
+        us = ctypes.c_float()
+        _check(load().s2m2_event_elapsed_us(self.start, self.stop, ctypes.byref(us)), "s2m2_event_elapsed_us")
+        return float(us.value)
+
+    def __del__(self):
+        try:
+            load().s2m2_event_destroy(self.start)
+            load().s2m2_event_destroy(self.stop)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype: Optional[torch.dtype] = None,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w).  [A4]"""
+            out: Optional[torch.Tensor] = None, timer: Optional[KernelTimer] = None) -> torch.Tensor:
+    """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w).  [A4]   timer: see KernelTimer."""
     _dev(feat, ln_w, ln_b)
     twoB, h, w, C = feat.shape
     B = twoB // 2
@@ -128,8 +154,12 @@ def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype
     if tuple(cv.shape) != (B, h, w, w) or not cv.is_contiguous():
         raise ValueError("ln_corr: out must be a contiguous (B,h,w,w) tensor")
     cv_dtype = cv.dtype
-    _check(load().s2m2_ln_corr(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
-                               B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream()), "s2m2_ln_corr")
+    if timer is not None:
+        _check(load().s2m2_ln_corr_timed(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
+                                         B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream(), timer.start, timer.stop), "s2m2_ln_corr_timed")
+    else:
+        _check(load().s2m2_ln_corr(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
+                                   B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream()), "s2m2_ln_corr")
     _meter("ln_corr", 2.0 * B * h * w * w * C)
     return cv
 
@@ -199,8 +229,9 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
         d.src_c[i] = t.shape[3]
         d.src_stride[i] = _nhwc(t)
         cin += t.shape[3]
-    if weight.dtype != dt or not weight.is_contiguous() or tuple(weight.shape) != (Cout, KH * KW * cin):
-        raise ValueError(f"conv2d: packed weight must be {(Cout, KH * KW * cin)} {dt}, got {tuple(weight.shape)} {weight.dtype}")
+    kcols = KH * KW * (-(-cin // 128) * 128) if korder == 2 else KH * KW * cin         # K order 2: K padded to whole 128-channel chunks
+    if weight.dtype != dt or not weight.is_contiguous() or tuple(weight.shape) != (Cout, kcols):
+        raise ValueError(f"conv2d: packed weight must be {(Cout, kcols)} {dt}, got {tuple(weight.shape)} {weight.dtype}")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cout or not bias.is_contiguous()):
         raise ValueError("conv2d: bias must be fp32 (Cout)")
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride

@@ -102,6 +102,60 @@ def test_conv_vs_torch(hip, case, dtype):
         assert float((out1[..., :Cout].float() - ref).abs().max()) < _tol(dtype, cin * KH * KW, max(1.0, float(ref.abs().max())))
 
 
+FRAG_CASES = [
+    # N, H, W, [src channels], Cout, KH, KW, act, epi      (K order 2: weights as an MFMA fragment stream, conv_frag_kernel)
+    (1, 17, 23, [128], 128, 3, 3, 1, 0),                   # ragged patch rows / columns
+    (2, 19, 70, [128, 128], 128, 1, 3, 4, 3),              # GRU pass (1x3) with two sources, two channel chunks, tanh + GRU epilogue
+    (1, 33, 19, [128, 128], 128, 3, 1, 3, 2),              # GRU pass (3x1), sigmoid * aux
+    (1, 12, 20, [256], 256, 3, 3, 2, 1),                   # two cout blocks, residual add
+    (1, 21, 37, [96, 64, 32], 384, 3, 3, 1, 0),            # Cin = 192: a source boundary inside a chunk, half-empty last chunk
+    (1, 64, 76, [128], 128, 3, 3, 0, 0),                   # several patches per row, exact tiling
+    (1, 8, 40, [128, 128, 64, 64], 128, 3, 3, 1, 0),       # four sources, three chunks
+]
+
+
+@pytest.mark.parametrize("case", FRAG_CASES)
+def test_conv_frag_stream(hip, case):
+    N, H, W, cs, Cout, KH, KW, act, epi = case
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(100 + FRAG_CASES.index(case))
+    srcs = [torch.randn(N, H, W, c, device="cuda", generator=g).to(dtype) for c in cs]
+    cin = sum(cs)
+    w = (torch.randn(Cout, cin, KH, KW, device="cuda", generator=g) / math.sqrt(cin * KH * KW)).to(dtype)
+    b = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    assert pack.frag_eligible(Cout, cin, KH, KW, dtype)
+    ref = _ref_conv(srcs, w, b, act)
+    a0 = torch.rand(N, H, W, Cout, device="cuda", generator=g).to(dtype) if epi else None
+    a1 = torch.randn(N, H, W, Cout, device="cuda", generator=g).to(dtype) if epi == 3 else None
+    if epi == 1:
+        ref = ref.half().float() + a0.float()
+    elif epi == 2:
+        ref = ref.half().float() * a0.float()
+    elif epi == 3:
+        ref = (1 - a0.float()) * a1.float() + a0.float() * ref.half().float()
+    wf = pack.pack_conv_frag(w, dtype, [(c, c) for c in cs])
+    bp = pack.pack_bias(b, Cout)
+    out = hip.conv2d(srcs, wf, bp, KH, KW, Cout, act=act, epi=epi, aux0=a0, aux1=a1, korder=2)
+    # same layer through the v3 halo tile (K order 0): both must agree with the reference, and with each other to fp16 rounding
+    w0 = pack.pack_conv(w, dtype, [(c, c) for c in cs])
+    out0 = hip.conv2d(srcs, w0, bp, KH, KW, Cout, act=act, epi=epi, aux0=a0, aux1=a1)
+    torch.cuda.synchronize()
+    tol = _tol(dtype, cin * KH * KW, max(1.0, float(ref.abs().max())))
+    assert float((out.float() - ref).abs().max()) < tol
+    assert float((out.float() - out0.float()).abs().max()) < tol
+    assert float((out != out0).float().mean()) < 0.02          # only fp32 summation order differs: rare 1-ulp flips of the fp16 outputs
+
+
+def test_conv_frag_argument_checks(hip):
+    x = torch.zeros(1, 8, 8, 128, device="cuda", dtype=torch.float16)
+    w = pack.pack_conv_frag(torch.zeros(128, 128, 3, 3), torch.float16)
+    with pytest.raises(RuntimeError, match="K order 2"):
+        hip.conv2d([x], w, None, 3, 3, 128, korder=2, stride=2)
+    x32 = x.float()
+    with pytest.raises((RuntimeError, ValueError)):
+        hip.conv2d([x32], w.float(), None, 3, 3, 128, korder=2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
 @pytest.mark.parametrize("epi", [1, 2, 3, 4])
 def test_conv_epilogues(hip, dtype, epi):

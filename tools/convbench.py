@@ -41,6 +41,10 @@ SHAPES = [  # name, N,H,W, Cin, Cout, KH, KW
     ("1/8 1x1 128->128 x2", 2, 128, 152, 128, 128, 1, 1),
     ("1/8 1x1 256->384 x2", 2, 128, 152, 256, 384, 1, 1),
     ("1/2 3x3 128->128", 1, 512, 608, 128, 128, 3, 3),
+    ("1/2 3x3 128->128 x2", 2, 512, 608, 128, 128, 3, 3),
+    ("1/4 3x3 128->256", 1, 256, 304, 128, 256, 3, 3),
+    ("1/4 3x3 256->384", 1, 256, 304, 256, 384, 3, 3),
+    ("1/4 1x3 256->128", 1, 256, 304, 256, 128, 1, 3),
     ("1/2 3x3 128->64", 1, 512, 608, 128, 64, 3, 3),
     ("1/1 3x3 48->48", 1, 1024, 1216, 48, 48, 3, 3),
     ("1/4 3x3 128->8", 1, 256, 304, 128, 8, 3, 3),
@@ -81,6 +85,10 @@ def main():
             if wk is not None and kw > 1 and tile < 12 and False:
                 t = timeit(lambda: hip.conv2d([x], wk, bp, kh, kw, wk.shape[0], act=hip.ACT_GELU, tile=tile, korder=1), a.iters)
                 line += f" k1 {t:8.1f} ({fl / t / 1e6:6.1f})"
+        if pack.frag_eligible(wp.shape[0], ci, kh, kw, torch.float16):           # v5 fragment-stream kernel (K order 2)
+            wfr = pack.pack_conv_frag(w, torch.float16)
+            t = timeit(lambda: hip.conv2d([x], wfr, bp, kh, kw, wp.shape[0], act=hip.ACT_GELU, korder=2), a.iters)
+            line += f" | frag {t:8.1f} us ({fl / t / 1e6:6.1f})"
         print(line, flush=True)
 
 
