@@ -1064,10 +1064,11 @@ struct ConvCfgF {
     static constexpr int RPI = NT / PPX;                 // halo pixels covered by one pass of the loader threads
     static constexpr int A_IT = (MAXHALO + RPI - 1) / RPI;
     static constexpr int CRS = BN + VEC;
-    static constexpr size_t A_BYTES = (size_t)MAXHALO * RS * sizeof(T);
+    static constexpr int AROWS = A_IT * RPI;             // LDS rows: every loader thread stashes all of its pieces, no exec-masked tail
+    static constexpr size_t A_BYTES = (size_t)AROWS * RS * sizeof(T);
     static constexpr size_t STAGE_BYTES = (size_t)BM * CRS * sizeof(T);
     static constexpr size_t LDS_BYTES = A_BYTES > STAGE_BYTES ? A_BYTES : STAGE_BYTES;
-    static_assert(NT % PPX == 0 && KS >= 2, "loader geometry");
+    static_assert(NT % PPX == 0 && KS >= 2 && KS % 2 == 0, "loader geometry");
 };
 
 template <typename CFG, typename T>
@@ -1132,11 +1133,12 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
             const T* src = (cvalid && apix[it] >= 0) ? sp + e : zp;
             ra[it] = global_load16(src);
         }
+        // every request is consumed, unconditionally (rows past the halo are padding): a tracked load whose use sits under an exec
+        // mask stays "pending" in the compiler's bookkeeping and turns into an s_waitcnt vmcnt(0) at the top of the tap loop, which
+        // would drain the untracked weight ring on every tap
 #pragma unroll
-        for (int it = 0; it < CFG::A_IT; ++it) {
-            const int hp = prow + CFG::RPI * it;
-            if (hp < CFG::MAXHALO) *reinterpret_cast<raw16_t*>(Ah + (size_t)hp * RS + pc * VEC) = ra[it];
-        }
+        for (int it = 0; it < CFG::A_IT; ++it)
+            *reinterpret_cast<raw16_t*>(Ah + (size_t)(prow + CFG::RPI * it) * RS + pc * VEC) = ra[it];
     };
 
     // ---- weight fragment stream of this wave: fragment f at wf + f * 64 (16-byte units), one 16-byte piece per lane
@@ -1169,20 +1171,26 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
 #pragma unroll 1
         for (int tap = 0; tap < ntap; ++tap) {
             const T* a = Ah + (size_t)(ky * HW_ + l31 + kx) * RS + hi * 8;
+            Frag<T> xf[2][CFG::MT];                               // pixel fragments, double buffered across k16 steps
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[0][i], a + (size_t)i * HW_ * RS);
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) {
+                if (kk + 1 < KS) {
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i) load_frag(xf[(kk + 1) & 1][i], a + (size_t)i * HW_ * RS + (kk + 1) * 16);
+                }
                 // fragment g (slot kk) was requested KS - 1 steps ago; the KS - 2 requests made since then may still be in flight
                 wait_vmcnt<KS - 2>();
                 settle(ring[kk]);
                 Frag<T> wfr;
                 wfr.v = __builtin_bit_cast(half8_t, ring[kk]);
-                Frag<T> xf[CFG::MT];
 #pragma unroll
-                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * HW_ * RS + kk * 16);
-#pragma unroll
-                for (int i = 0; i < CFG::MT; ++i) mma32(acc[i][0], wfr, xf[i]);           // D[cout][pixel]
-                // refill the slot consumed one step ago (its MFMAs have long read their operands): fragment g + KS - 1
-                if (g > 0) {
+                for (int i = 0; i < CFG::MT; ++i) mma32(acc[i][0], wfr, xf[kk & 1][i]);   // D[cout][pixel]
+                // refill the slot consumed one step ago (its MFMAs have long read their operands) with fragment g + KS - 1.
+                // UNCONDITIONAL: a branch around an untracked load makes the compiler merge the two register states with copies
+                // that read the slot while its load is in flight.  (Step 0 re-requests fragment KS - 1 into its own slot.)
+                {
                     const int f = g + KS - 1;
                     global_load16_async(ring[(kk + KS - 1) % KS], wf + (size_t)(f < nfrag ? f : nfrag - 1) * 64);
                 }
