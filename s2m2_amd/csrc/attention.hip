@@ -17,8 +17,14 @@
 //           map of a register octet is {16s+4hi+0..3, 16s+8+4hi+0..3}); V is staged TRANSPOSED in LDS (Vt[d][key]) so the
 //           matching A operand is two 4-element reads per lane.  No permutes, no P round trip through LDS.
 //   PE    = (template) contextual relative positional encoding of SelfAttn(use_pe): pe_sum[q,:] = sum_k P[q,k] pe[q,k,:]
-//           with pe[q,k] = 0.5*[px[xq-xk+w-1], py[yq-yk+h-1]] evaluated from the two separable sinc tables (utils.py:32-60)
-//           kept in LDS -- the (N,N,32) tensor of the reference (95 MB at 1216x1024, 1.5 GB for XL) is never built.
+//           with pe[q,k] = 0.5*[px[xq-xk+w-1], py[yq-yk+h-1]] from the two separable sinc tables (utils.py:32-60) kept in LDS
+//           -- the (N,N,32) tensor of the reference (95 MB at 1216x1024, 1.5 GB for XL) is never built.  Because the encoding is
+//           separable, the sum over the N keys factors through the MARGINALS of the attention row over key columns and key rows:
+//             pe_x[q,:] = sum_x' ( sum_{k: x_k = x'} P[q,k] ) px[xq - x' + w - 1, :],   pe_y likewise over y'.
+//           The marginals are two more MFMA products per key tile -- bins^T += OneHot^T . P^T with a one-hot (key -> x bin / y bin)
+//           A operand built from integer compares, the SAME P^T fragments as the PV product as B operand, fp32 accumulators next
+//           to O -- instead of 32 multiply-adds and 8 table reads per key on the VALU; the (w + h) x 16 contraction with the tables
+//           runs once per query after the key loop.  (A first version binned with ds_add_f32: twice SLOWER than the VALU loop.)
 // fp16: v_mfma_f32_32x32x16_f16 with fp32 softmax/accumulators;  fp32 (parity mode): exact v_mfma_f32_32x32x2_f32.
 #include "common.h"
 
@@ -33,8 +39,10 @@ struct AttnArgs {
     const float* px; const float* py; void* pe_out; long long spe; int gw, gh;
 };
 
-template <typename T, int DP_, bool PE_, int MINW_ = 4, bool KSPLIT_ = false>
+template <typename T, int DP_, bool PE_, int MINW_ = 4, bool KSPLIT_ = false, int NXT_ = 2, int NYT_ = 1>
 struct AttnCfg {
+    static constexpr int NXT = NXT_, NYT = NYT_;         // PE: 32-wide bin tiles along x / y of the token grid (grid up to 32*NXT x 32*NYT)
+    static constexpr int SM = (NXT_ + NYT_) * 32 + 1;    // floats per query of the bin scratch (odd: conflict-free rows)
     static constexpr bool KSPLIT = KSPLIT_;              // the 4 waves of a block share ONE 32-query tile and split its keys (few, long rows)
     static constexpr int MINW = MINW_;                   // fewest waves a block is launched with (sizes the staging registers)
     static constexpr int DP = DP_;                       // head dim rounded up to a multiple of 16
@@ -51,6 +59,10 @@ struct AttnCfg {
     static constexpr size_t V_BYTES = (size_t)VROWS * VRS * sizeof(T);
     static constexpr int KP = DP / VEC;                  // 16-byte pieces per K/V row
     static constexpr int MAXW = (DP * sizeof(T) >= 384) ? 4 : 8;   // waves per block: 512 registers per lane for the wide heads
+    // KSPLIT merge scratch (reuses the K/V staging area after the key loop): running max / sum + the four partial O tiles
+    static constexpr size_t MERGE_BYTES = KSPLIT ? (size_t)(256 + 4 * 32 * (ND * 32 + 1)) * sizeof(float) : 0;
+    // PE area (tables + marginal bins) sits behind BOTH, so that it survives the merge
+    static constexpr size_t PE_OFF = ((K_BYTES + V_BYTES > MERGE_BYTES ? K_BYTES + V_BYTES : MERGE_BYTES) + 15) / 16 * 16;
 };
 
 template <typename T> struct Quad;                                     // 4 consecutive elements
@@ -86,7 +98,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);                                   // [KVT][KRS]
     T* Vt = reinterpret_cast<T*>(smem + CFG::K_BYTES);                    // [VROWS][VRS]
-    float* pxs = reinterpret_cast<float*>(smem + CFG::K_BYTES + CFG::V_BYTES);   // PE tables (PE only)
+    float* pxs = reinterpret_cast<float*>(smem + CFG::PE_OFF);            // PE tables, then the marginal bins (PE only)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,6 +116,8 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     const T* vb = static_cast<const T*>(a.v) + (long long)bkv * a.Nk * a.sv + hd * a.D;
 
     float* pys = nullptr;
+    float* pm = nullptr;
+    constexpr int SM = CFG::SM;
     int Lx = 0;
     if constexpr (CFG::PE) {
         Lx = 2 * a.gw - 1;
@@ -111,6 +125,9 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
         pys = pxs + Lx * 16;
         for (int i = tid; i < Lx * 16; i += nthr) pxs[i] = a.px[i];
         for (int i = tid; i < Ly * 16; i += nthr) pys[i] = a.py[i];
+        // bin scratch of this wave's 32 queries (filled from the accumulators after the key loop): row (wv*32 + query), columns
+        // [0, 32*NXT) = key x, [32*NXT, 32*(NXT+NYT)) = key y
+        pm = pys + Ly * 16 + (size_t)wv * 32 * CFG::SM;
     }
 
     // ---- Q fragments of this wave (B operand: lane = query, 8 consecutive d per k16 step), zero beyond D
@@ -197,11 +214,14 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float pe_acc[CFG::PE ? 32 : 1];
+    float16_t bacc[CFG::PE ? CFG::NXT + CFG::NYT : 1];        // PE: marginal bins^T [bin][query], x tiles then y tiles
     if constexpr (CFG::PE) {
 #pragma unroll
-        for (int c = 0; c < 32; ++c) pe_acc[c] = 0.f;
+        for (int t = 0; t < CFG::NXT + CFG::NYT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bacc[t][r] = 0.f;
     }
+    const float inv_gw = CFG::PE ? 1.0f / (float)a.gw : 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float scale2 = a.scale * 1.44269504088896340736f;
     // query grid coordinates (PE)
@@ -271,28 +291,35 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                     }
                 }
                 if constexpr (CFG::PE) {
+                    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {
 #pragma unroll
-                    for (int c = 0; c < 32; ++c) pe_acc[c] *= alpha;
-                    if constexpr (sizeof(T) == 2) {               // the reference multiplies fp16 probabilities (autocast einsum)
+                        for (int t = 0; t < CFG::NXT + CFG::NYT; ++t)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) p[r] = (float)(half_t)p[r];
+                            for (int r = 0; r < 16; ++r) bacc[t][r] *= alpha;
                     }
+                    // bins^T[bin][q] += OneHot^T[bin][key] . P^T[key][q]: the B operand is pf[s] (fp16 mode: the probabilities rounded to
+                    // fp16, as the reference's autocast einsum sees them); the A operand of lane (bin row l31 of tile t, half hi) holds,
+                    // for its 8 k slots = keys 16s + 4hi + {0..3} and 16s + 8 + 4hi + {0..3}, 1 where the key falls into that bin
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kv = kv0 + acc_row(r, lane);
-                        if (kv < a.Nk) {
-                            const int yk = kv / a.gw, xk = kv - yk * a.gw;
-                            const float4_t* tx = reinterpret_cast<const float4_t*>(pxs + (xq - xk + a.gw - 1) * 16);
-                            const float4_t* ty = reinterpret_cast<const float4_t*>(pys + (yq - yk + a.gh - 1) * 16);
+                    for (int sk = 0; sk < 2; ++sk) {
+                        int xk[8], yk[8];
 #pragma unroll
-                            for (int c4 = 0; c4 < 4; ++c4) {
-                                const float4_t u = tx[c4], w = ty[c4];
+                        for (int e = 0; e < 8; ++e) {
+                            const int kv = kv0 + 16 * sk + 4 * hi + (e & 3) + 8 * (e >> 2);
+                            int y = (int)(((float)kv + 0.5f) * inv_gw);          // kv / gw: exact for kv < 2^20
+                            yk[e] = y;
+                            xk[e] = kv - y * a.gw;
+                        }
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    pe_acc[c4 * 4 + e] = __builtin_fmaf(p[r], u[e], pe_acc[c4 * 4 + e]);
-                                    pe_acc[16 + c4 * 4 + e] = __builtin_fmaf(p[r], w[e], pe_acc[16 + c4 * 4 + e]);
-                                }
+                        for (int t = 0; t < CFG::NXT + CFG::NYT; ++t) {
+                            const int bin = (t < CFG::NXT ? t : t - CFG::NXT) * 32 + l31;
+                            Frag<T> oh;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const bool hit = (t < CFG::NXT ? xk[e] : yk[e]) == bin;
+                                if constexpr (sizeof(T) == 2) oh.v[e] = hit ? (half_t)1.0f : (half_t)0.0f; else oh.v[e] = hit ? 1.0f : 0.0f;
                             }
+                            mma32(bacc[t], oh, pf[sk]);
                         }
                     }
                 }
@@ -303,12 +330,11 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     if constexpr (CFG::KSPLIT) {
         // ---- the four waves hold partial (max, sum, O, pe) over disjoint key subsets of the SAME 32 queries: merge through LDS
         static_assert(CFG::KT == 4, "key split uses one 32-key sub-tile per wave and stage");
-        __syncthreads();                                          // K/V staging (and the PE tables) are dead: reuse the space
+        __syncthreads();                                          // K/V staging is dead: reuse the space (the PE area lies behind it)
         float* mm = reinterpret_cast<float*>(smem);               // [4][32] running max
         float* ml = mm + 128;                                     // [4][32] running sum
         float* mo = ml + 128;                                     // [4][32][DPO] partial O (DPO = ND*32 + 1: odd stride, conflict-free)
         constexpr int DPO = ND * 32 + 1;
-        float* mp = mo + 4 * 32 * DPO;                            // [4][32][33] partial pe (PE only)
         const float lw = l_run + __shfl_xor(l_run, 32, 64);
         if (hi == 0) { mm[wv * 32 + l31] = m_run; ml[wv * 32 + l31] = lw; }
 #pragma unroll
@@ -317,9 +343,9 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) mo[(wv * 32 + l31) * DPO + dt * 32 + acc_row(r, lane)] = oacc[dt][r];
         if constexpr (CFG::PE) {
 #pragma unroll
-            for (int c = 0; c < 32; ++c) pe_acc[c] += __shfl_xor(pe_acc[c], 32, 64);
+            for (int t = 0; t < CFG::NXT + CFG::NYT; ++t)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) mp[(wv * 32 + l31) * 33 + 16 * hi + c] = hi ? pe_acc[16 + c] : pe_acc[c];
+                for (int r = 0; r < 16; ++r) pm[(size_t)l31 * SM + t * 32 + acc_row(r, lane)] = bacc[t][r];
         }
         __syncthreads();
         // thread t: query t & 31, channel group t >> 5 (8 groups)
@@ -344,15 +370,26 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 *reinterpret_cast<Quad<T>*>(op + d0) = qd;
             }
             if constexpr (CFG::PE) {
+                // channels 4*grp .. +3: groups 0-3 = x part, 4-7 = y part.  Merged marginal of the query = sum over the four waves'
+                // bins with the softmax merge factors, contracted with the table row selected by the relative offset.
+                const float* base = pys + (2 * a.gh - 1) * 16;                // bins of wave 0
+                const int yq2 = qi / a.gw, xq2 = qi - yq2 * a.gw;
+                const bool ypart = grp >= 4;
+                const int n = ypart ? a.gh : a.gw, off = ypart ? CFG::NXT * 32 : 0;
+                const float* tab = ypart ? pys + (yq2 + a.gh - 1) * 16 + (grp - 4) * 4 : pxs + (xq2 + a.gw - 1) * 16 + grp * 4;
+                float4_t acc4 = {0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < n; ++j) {
+                    float mj = 0.f;
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; ++w4) mj += f[w4] * base[(size_t)(w4 * 32 + q) * SM + off + j];
+                    const float4_t tj = *reinterpret_cast<const float4_t*>(tab - j * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc4[e] = __builtin_fmaf(mj, tj[e], acc4[e]);
+                }
                 T* pp = static_cast<T*>(a.pe_out) + ((long long)b * a.Nq + qi) * a.spe + hd * 32 + grp * 4;
                 Quad<T> qd;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int w4 = 0; w4 < 4; ++w4) v += f[w4] * mp[(w4 * 32 + q) * 33 + grp * 4 + e];
-                    qd.v[e] = from_f32<T>(0.5f * v * inv);
-                }
+                for (int e = 0; e < 4; ++e) qd.v[e] = from_f32<T>(0.5f * acc4[e] * inv);
                 *reinterpret_cast<Quad<T>*>(pp) = qd;
             }
         }
@@ -363,10 +400,12 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qi = q0 + l31;
-    if constexpr (CFG::PE) {
-        // both halves hold partial sums over their 16 keys per tile
+    if constexpr (CFG::PE) {                                      // bins of both halves -> this wave's scratch rows
 #pragma unroll
-        for (int c = 0; c < 32; ++c) pe_acc[c] += __shfl_xor(pe_acc[c], 32, 64);
+        for (int t = 0; t < CFG::NXT + CFG::NYT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pm[(size_t)l31 * SM + t * 32 + acc_row(r, lane)] = bacc[t][r];
+        __builtin_amdgcn_wave_barrier();
     }
     if (qi < a.Nq) {
         T* op = static_cast<T*>(a.out) + ((long long)b * a.Nq + qi) * a.so + hd * a.D;
@@ -383,32 +422,43 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 }
             }
         if constexpr (CFG::PE) {
-            // pe_sum (b, q, head, 32) in T; the 0.5 of get_pe is applied here; half hi writes channels 16*hi .. 16*hi+15
+            // pe_sum (b, q, head, 32) in T; the 0.5 of get_pe is applied here; half hi = 0 contracts the x bins with the px rows
+            // (channels 0..15), half hi = 1 the y bins with the py rows (channels 16..31)
+            const float* row = pm + (size_t)l31 * SM + (hi ? CFG::NXT * 32 : 0);
+            const int n = hi ? a.gh : a.gw;
+            const float* tab = hi ? pys + (yq + a.gh - 1) * 16 : pxs + (xq + a.gw - 1) * 16;
+            float4_t acc4[4];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) acc4[c4] = float4_t{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < n; ++j) {
+                const float mj = row[j];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float4_t tj = *reinterpret_cast<const float4_t*>(tab - j * 16 + c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc4[c4][e] = __builtin_fmaf(mj, tj[e], acc4[c4][e]);
+                }
+            }
             T* pp = static_cast<T*>(a.pe_out) + ((long long)b * a.Nq + qi) * a.spe + hd * 32 + 16 * hi;
 #pragma unroll
             for (int c4 = 0; c4 < 4; ++c4) {
                 Quad<T> qd;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float val = hi ? pe_acc[16 + c4 * 4 + e] : pe_acc[c4 * 4 + e];
-                    qd.v[e] = from_f32<T>(0.5f * val * inv);
-                }
+                for (int e = 0; e < 4; ++e) qd.v[e] = from_f32<T>(0.5f * acc4[c4][e] * inv);
                 *reinterpret_cast<Quad<T>*>(pp + c4 * 4) = qd;
             }
         }
     }
 }
 
-template <typename T, int DP, bool PE, int MINW, bool KSPLIT = false>
-static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
-    using CFG = AttnCfg<T, DP, PE, MINW, KSPLIT>;
+template <typename T, int DP, bool PE, int MINW, bool KSPLIT, int NXT, int NYT>
+static int launch_attn_t(const AttnArgs& a, int nw, hipStream_t st) {
+    using CFG = AttnCfg<T, DP, PE, MINW, KSPLIT, NXT, NYT>;
     auto kern = attention_kernel<CFG, T>;
     size_t lds = CFG::K_BYTES + CFG::V_BYTES;
-    if (PE) lds += (size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 * sizeof(float);
-    if (KSPLIT) {
-        const size_t merge = (size_t)(256 + 4 * 32 * (CFG::ND * 32 + 1) + (PE ? 4 * 32 * 33 : 0)) * sizeof(float);
-        lds = lds > merge ? lds : merge;
-    }
+    if (KSPLIT) lds = lds > CFG::MERGE_BYTES ? lds : CFG::MERGE_BYTES;
+    if (PE)                                                       // tables + (w + h | 1) marginal bins per query of every wave
+        lds = CFG::PE_OFF + ((size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 + (size_t)nw * 32 * CFG::SM) * sizeof(float);
     if (lds > 160 * 1024) return set_error("attention: %zu bytes of LDS needed", lds);
     static size_t attr_bytes_dev[kMaxDevices] = {};
     size_t& attr_bytes = attr_bytes_dev[current_device()];
@@ -421,6 +471,19 @@ static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
     const int nblk = KSPLIT ? ntq : (ntq + nw - 1) / nw;
     hipLaunchKernelGGL(kern, dim3(nblk, a.nb * a.heads), dim3(nw * 64), lds, st, a);
     return check_launch("attention");
+}
+
+// PE variant: bin tiles sized for the token grid -- (2, 1) covers grids up to 64 x 32 (the 1/32 grid of 2048 x 1024 images), (3, 3) up to
+// 96 x 96 (3072 x 3072); without PE the two parameters are inert
+template <typename T, int DP, bool PE, int MINW, bool KSPLIT = false>
+static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
+    if constexpr (PE) {
+        if (a.gw <= 64 && a.gh <= 32) return launch_attn_t<T, DP, PE, MINW, KSPLIT, 2, 1>(a, nw, st);
+        if (a.gw <= 96 && a.gh <= 96) return launch_attn_t<T, DP, PE, MINW, KSPLIT, 3, 3>(a, nw, st);
+        return set_error("attention: positional-encoding grid %d x %d exceeds 96 x 96 cells", a.gw, a.gh);
+    } else {
+        return launch_attn_t<T, DP, PE, MINW, KSPLIT, 1, 1>(a, nw, st);
+    }
 }
 
 template <typename T, int DP, bool PE>

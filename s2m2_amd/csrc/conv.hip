@@ -1051,6 +1051,21 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 //     1 KB per MFMA ... 128 B/clk/CU at the full MFMA rate from 4 waves, weights 32 B/clk/CU from L2.
 // K order of the accumulation: (chunk, tap, channel) -- fp32 accumulate, so only the summation order differs from v3.
 // ---------------------------------------------------------------------------------------------------------------
+// timeline instrumentation of conv_frag_kernel for tools/frag_trace.py (experiment builds only: -DS2M2_FRAG_TRACE=1)
+#ifndef S2M2_FRAG_TRACE
+#define S2M2_FRAG_TRACE 0
+#endif
+#if S2M2_FRAG_TRACE
+__device__ unsigned long long g_frag_trace[4096 * 4 * 8];
+#define FRAG_T(slot)                                                                                                          \
+    do {                                                                                                                      \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && blockIdx.y == 0)                                                  \
+            g_frag_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+#else
+#define FRAG_T(slot)
+#endif
+
 template <typename T, int BN_, int CH_>
 struct ConvCfgF {
     static_assert(sizeof(T) == 2, "the fragment-stream kernel is fp16 only");
@@ -1081,7 +1096,10 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);     // = cout tile of this wave inside the block
     const int hi = lane >> 5, l31 = lane & 31;
-    int bx = xcd_remap(blockIdx.x, gridDim.x);                   // neighbouring patches (shared halo rows) on one XCD / L2
+    // patch <-> block id exactly as in v3 (hardware: block b runs on XCD b % 8): the layers before and after this one then find / leave
+    // every patch in the L2 of the XCD that works on it next.  (An XCD-contiguous remap of the ids made THIS kernel's halo reads
+    // cheaper and the next layer's reads miss: measured +21 us per pass on the second conv of the ConvBlock2D pairs.)
+    int bx = blockIdx.x;
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
     const int n = bx / tiles_y;
@@ -1093,6 +1111,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     const int ntap = p.KH * p.KW;
     const int nchunk = (p.Cin + CH - 1) / CH;
     const int nfrag = nchunk * ntap * KS;                         // fragments of this wave's stream
+    FRAG_T(0);
 
     // ---- halo loader state (as in v3, CH channels per pixel)
     const int pc = tid % CFG::PPX, prow = tid / CFG::PPX;
@@ -1159,6 +1178,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     for (int s = 0; s < KS; ++s) global_load16_async(ring[s], wf + (size_t)(s < nfrag ? s : nfrag - 1) * 64);
     load_halo(0);
     __syncthreads();
+    FRAG_T(1);
     int g = 0;                                                    // global k16 step = index of the fragment consumed next
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         if (chunk > 0) {
@@ -1204,13 +1224,18 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     for (int s = 0; s < KS; ++s) settle(ring[s]);
 
     // ---- epilogues: staging rows r = patch row * 32 + column
+    FRAG_T(2);
     __syncthreads();                                              // the staging tile aliases the halo tile
+    FRAG_T(3);
     const PatchPix pix{n, y0, x0, p.H, p.W};
     AuxRegs<CFG, T> aux;
     aux.prefetch(p, tid, n0, pix);
     stage_tile_act<CFG, T>(p, acc, Cs, bias, 0, wv, lane);
+    FRAG_T(4);
     __syncthreads();
+    FRAG_T(5);
     store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);
+    FRAG_T(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1550,6 +1575,12 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
 }
 
 }  // namespace s2m2
+
+#if S2M2_FRAG_TRACE
+extern "C" int s2m2_debug_frag_trace(void* host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(s2m2::g_frag_trace), bytes < sizeof(s2m2::g_frag_trace) ? bytes : sizeof(s2m2::g_frag_trace)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     using namespace s2m2;

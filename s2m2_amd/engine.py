@@ -102,8 +102,10 @@ class Engine:
         self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and os.environ.get("S2M2_STREAMS", "0") == "1") else None
 
     # ---- weight packing (once per engine) ------------------------------------------------------------
-    def std(self, name: str, splits: Optional[Sequence[Tuple[int, int]]] = None, transposed: bool = False) -> Spec:
-        """One nn.Conv2d / nn.Linear (or stride-1 nn.ConvTranspose2d when ``transposed``) as a K5 weight."""
+    def std(self, name: str, splits: Optional[Sequence[Tuple[int, int]]] = None, transposed: bool = False, frag: bool = True) -> Spec:
+        """One nn.Conv2d / nn.Linear (or stride-1 nn.ConvTranspose2d when ``transposed``) as a K5 weight.  frag=False: the layer is
+        launched with a stride or with an aux-tensor epilogue (measured slower on the fragment-stream kernel: its 4-wave blocks expose the
+        aux latency, profiles/r02/frag_timeline.txt), keep K order 0."""
         key = (name, tuple(splits) if splits else None, transposed)
         s = self._packed.get(key)
         if s is None:
@@ -113,7 +115,7 @@ class Engine:
             if w.dim() == 2:
                 w = w[:, :, None, None]
             cin_p = sum(pd for _, pd in splits) if splits else pack.pad8(w.shape[1])
-            frag = self.use_frag and pack.frag_eligible(pack.pad8(w.shape[0]), cin_p, w.shape[2], w.shape[3], self.dtype)
+            frag = frag and self.use_frag and pack.frag_eligible(pack.pad8(w.shape[0]), cin_p, w.shape[2], w.shape[3], self.dtype)
             wp = pack.pack_conv_frag(w, self.dtype, splits) if frag else pack.pack_conv(w, self.dtype, splits)
             s = Spec((wp, pack.pack_bias(self.p.get(name + ".bias"), w.shape[0]), w.shape[2], w.shape[3], pack.pad8(w.shape[0])))
             s.korder = 2 if frag else 0                            # spatial layers of wide tensors: weights as an MFMA fragment stream
@@ -222,7 +224,7 @@ class Engine:
                 b = self.cconv(c2, [u])
         t = self.cconv(self.std(p + ".convs.0"), [z], act=hip.ACT_GELU)
         self.join(b, u)
-        return self.cconv(self.std(p + ".convs.2"), [t], epi=hip.EPI_ADD, aux0=b)
+        return self.cconv(self.std(p + ".convs.2", frag=False), [t], epi=hip.EPI_ADD, aux0=b)
 
     def dual_heads(self, p: str):
         """[gate.2 | fusion.2] stacked along K (the channel order of the hidden tensor) + the two biases"""
@@ -382,9 +384,9 @@ class Engine:
         for sfx in ("1", "2"):
             with self.fork():
                 z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
-            rh = self.cconv(self.std(f"{p}.convr{sfx}"), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
+            rh = self.cconv(self.std(f"{p}.convr{sfx}", frag=False), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
             self.join(z)
-            h = self.cconv(self.std(f"{p}.convq{sfx}"), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
+            h = self.cconv(self.std(f"{p}.convq{sfx}", frag=False), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
 
     def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it):
@@ -456,8 +458,8 @@ class Engine:
         f2 = self.cconv(self.std(p + ".conv1_down.2"), [t])
         f2 = hip.groupnorm_nhwc(f2, 8, self.p[p + ".norm1.weight"], self.p[p + ".norm1.bias"])
         t = self.cconv(self.std(p + ".conv2.0"), [f2], act=hip.ACT_GELU)
-        f2 = self.cconv(self.std(p + ".conv2.2"), [t], epi=hip.EPI_ADD, aux0=f2)
-        f4 = self.cconv(self.std(p + ".conv2_down.0"), [f2], stride=2)
+        f2 = self.cconv(self.std(p + ".conv2.2", frag=False), [t], epi=hip.EPI_ADD, aux0=f2)
+        f4 = self.cconv(self.std(p + ".conv2_down.0", frag=False), [f2], stride=2)
         py = self.unet("feat_pyramid", f4)
         z = py
         for i in range(self.ntr):

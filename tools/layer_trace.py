@@ -46,16 +46,62 @@ class Tracer:
             s0 = srcs[0]
             return "%dx%d k%dx%d cin=%s->%d s%d act=%d epi=%d%s" % (
                 s0.shape[1], s0.shape[2], kh, kw, "+".join(str(s.shape[3]) for s in srcs), cout, k.get("stride", 1),
-                k.get("act", 0), k.get("epi", 0), " shuf" if k.get("shuffle2") else "")
+                k.get("act", 0), k.get("epi", 0), (" shuf" if k.get("shuffle2") else "") + (" frag" if k.get("korder") == 2 else ""))
         shp = [tuple(x.shape) for x in a if torch.is_tensor(x)]
         return " ".join(str(s) for s in shp[:2])
+
+
+def ab(a):
+    """Same-process A/B of an engine switch: alternating passes of two engines built with ENV=v0 / ENV=v1."""
+    var, vals = a.ab.split("=")
+    v0, v1 = vals.split(",")
+    tr = Tracer(hip)
+    engine_mod.hip = tr
+    m = build_model(a.model, use_positivity=True, refine_iter=a.refine).cuda()
+    engs = []
+    for v in (v0, v1):
+        os.environ[var] = v
+        engs.append(engine_mod.Engine(m, torch.float16))
+    left = torch.rand(1, 3, a.h, a.w, device="cuda") * 255
+    right = torch.rand(1, 3, a.h, a.w, device="cuda") * 255
+    for e in engs:
+        for _ in range(2):
+            e.run(left, right)
+    torch.cuda.synchronize()
+    logs = [[], []]
+    tr.on = True
+    for _ in range(a.iters):
+        for i, e in enumerate(engs):
+            tr.log = logs[i]
+            e.run(left, right)
+    torch.cuda.synchronize()
+    aggs = []
+    for lg in logs:
+        agg = collections.OrderedDict()
+        for name, sig, e0, e1 in lg:
+            d = agg.setdefault((name, sig.replace(" frag", "")), [0, 0.0])
+            d[0] += 1; d[1] += e0.elapsed_time(e1) * 1e3
+        aggs.append(agg)
+    t0 = sum(v[1] for v in aggs[0].values()) / a.iters
+    t1 = sum(v[1] for v in aggs[1].values()) / a.iters
+    print(f"{var}={v0}: {t0 / 1e3:.3f} ms per pass   {var}={v1}: {t1 / 1e3:.3f} ms per pass  (eager, event-bracketed)")
+    rows = []
+    for k, (n, t) in aggs[0].items():
+        if k in aggs[1]:
+            rows.append(((aggs[1][k][1] - t) / a.iters, k, n // a.iters, t / n, aggs[1][k][1] / aggs[1][k][0]))
+    for d, k, n, ta, tb in sorted(rows, key=lambda r: r[0]):
+        if abs(d) >= 2:
+            print("%-16s %-58s x%3d  %s=%s %7.1f us  %s=%s %7.1f us  delta/pass %+8.1f us" % (k[0], k[1], n, var, v0, ta, var, v1, tb, d))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="S"); ap.add_argument("--h", type=int, default=1024); ap.add_argument("--w", type=int, default=1216)
     ap.add_argument("--iters", type=int, default=3); ap.add_argument("--refine", type=int, default=3)
+    ap.add_argument("--ab", default="", help="ENV=0,1: two engines in ONE process (same clocks), per-layer comparison of ENV=0 vs ENV=1")
     a = ap.parse_args()
+    if a.ab:
+        return ab(a)
     tr = Tracer(hip)
     engine_mod.hip = tr
     m = build_model(a.model, use_positivity=True, refine_iter=a.refine).cuda()
