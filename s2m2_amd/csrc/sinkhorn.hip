@@ -11,27 +11,33 @@
 // which underflows to exactly 0 after exp in fp32, so those entries are skipped (bit-identical).
 //
 // The reference materialises ~35 full-volume temporaries (7 exp sweeps).  Here S is read ot_iter + 1 times, row-wise, with 16-byte
-// loads (a lane owns 8 fp16 / 4 fp32 consecutive columns): while a row is in registers the wave computes its u_i (exact
-// max-then-sum log-sum-exp, DPP reductions) AND immediately feeds S_ij + u_i into per-lane online column accumulators for the next
-// v -- the row sweep of iteration k and the column sweep of iteration k+1 are one pass; the last pass goes straight on to the
-// probabilities, argmax (first maximum), row mass and window regression.  u, v and the per-wave column partials live in LDS.
+// loads: while a row is in registers its group of lanes computes u_i (exact max-then-sum log-sum-exp) AND immediately feeds
+// S_ij + u_i into per-lane column accumulators for the next v -- the row sweep of iteration k and the column sweep of iteration
+// k+1 are one pass; the last pass goes straight on to the probabilities, argmax (first maximum), row mass and window regression.
+// u, v and the per-wave column partials live in LDS.
+//
+// Work mapping (round 2): a row belongs to a GROUP of GL = 16 / 32 / 64 lanes, a lane owns 8 consecutive columns in each of up to
+// 3 column chunks of 8*GL columns, so a wave sweeps 64/GL rows at a time and the row reductions are DPP steps inside the group
+// (no v_readlane round trips).  With one row per wave (round 1) a 304-column row used 38 of 64 lanes and, under the positivity
+// triangle, 19 on average.  The column accumulators are "lazy" log-sum-exp states: the stabiliser only moves when an element
+// exceeds it by more than 40 (checked once per 8 elements with a wave vote), otherwise an element costs a subtract, an exp and an
+// add -- the exact sum of exp(x - m) for a fixed m, just not the tightest m.
 #include "common.h"
 
 namespace s2m2 {
 
-struct LSE {                         // running log-sum-exp state: sum of exp(x - m)
+constexpr float kLazy = 40.0f;          // exp(40) * (columns) stays far below the fp32 range
+constexpr float kNegBig = -1.0e30f;     // "no element yet" stabiliser (finite: -inf - -inf would be NaN)
+
+struct LSE {                            // running log-sum-exp state: z = sum of exp(x - m)
     float m, z;
-    __device__ __forceinline__ void init() { m = -INFINITY; z = 0.f; }
-    __device__ __forceinline__ void add(float x) {             // branch-free online update (x may be -inf: no-op)
-        const float mn = fmaxf(m, x);
-        const float e = __expf(-fabsf(x - m));                  // exp(-inf) = 0 on the first element; NaN-free: (-inf) - (-inf) guarded
-        const bool up = x > m;
-        z = (x == -INFINITY) ? z : (up ? z * e + 1.0f : z + e);
-        m = mn;
+    __device__ __forceinline__ void init() { m = kNegBig; z = 0.f; }
+    __device__ __forceinline__ void add_exact(float x) {       // online update with the maximum as stabiliser (x may be -inf: no-op)
+        if (x > m) { z = z * __expf(m - x) + 1.0f; m = x; }
+        else z += __expf(x - m);
     }
     __device__ __forceinline__ void merge(float m2, float z2) {
         const float mn = fmaxf(m, m2);
-        if (mn == -INFINITY) return;
         z = z * __expf(m - mn) + z2 * __expf(m2 - mn);
         m = mn;
     }
@@ -39,38 +45,48 @@ struct LSE {                         // running log-sum-exp state: sum of exp(x 
     __device__ __forceinline__ float value() const { return m + __logf(fmaxf(z, 1e-30f)); }
 };
 
-// full-wave reductions on the VALU data path: 4 DPP steps inside each row of 16 lanes, 4 v_readlane across the rows
 template <int CTRL> __device__ __forceinline__ int dpp_movi(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
-__device__ __forceinline__ float rl(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
-__device__ __forceinline__ float wave_sum_dpp(float x) {
+// reductions over aligned groups of GL lanes, result in every lane of the group: 4 DPP steps cover 16 lanes, ds_bpermute the rest
+template <int GL> __device__ __forceinline__ float group_sum_f(float x) {
     x += dpp_mov<0xB1>(x); x += dpp_mov<0x4E>(x); x += dpp_mov<0x141>(x); x += dpp_mov<0x140>(x);
-    return (rl(x, 0) + rl(x, 16)) + (rl(x, 32) + rl(x, 48));
+    if (GL >= 32) x += __shfl_xor(x, 16, 64);
+    if (GL >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
 }
-__device__ __forceinline__ float wave_max_dpp(float x) {
+template <int GL> __device__ __forceinline__ float group_max_f(float x) {
     x = fmaxf(x, dpp_mov<0xB1>(x)); x = fmaxf(x, dpp_mov<0x4E>(x)); x = fmaxf(x, dpp_mov<0x141>(x)); x = fmaxf(x, dpp_mov<0x140>(x));
-    return fmaxf(fmaxf(rl(x, 0), rl(x, 16)), fmaxf(rl(x, 32), rl(x, 48)));
+    if (GL >= 32) x = fmaxf(x, __shfl_xor(x, 16, 64));
+    if (GL >= 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
+    return x;
 }
-__device__ __forceinline__ int wave_min_dpp(int x) {
+template <int GL> __device__ __forceinline__ int group_min_i(int x) {
     x = min(x, dpp_movi<0xB1>(x)); x = min(x, dpp_movi<0x4E>(x)); x = min(x, dpp_movi<0x141>(x)); x = min(x, dpp_movi<0x140>(x));
-    return min(min(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)),
-               min(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+    if (GL >= 32) x = min(x, __shfl_xor(x, 16, 64));
+    if (GL >= 64) x = min(x, __shfl_xor(x, 32, 64));
+    return x;
 }
 
-template <typename TI, int NWV, int PPL>
+template <typename TI, int NWV, int GL, int NCH>
 __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __restrict__ cv, float* __restrict__ disp,
                                                                     float* __restrict__ conf, float* __restrict__ occ,
                                                                     int32_t* __restrict__ amax, int w, int ot_iter, int use_pos) {
     constexpr int VEC = 16 / sizeof(TI);
-    constexpr int EPL = PPL * VEC;                         // columns per lane: piece p covers j = (lane + 64*p)*VEC .. +VEC-1
+    constexpr int PPC = 8 / VEC;                           // 16-byte pieces per lane and chunk (8 columns)
+    constexpr int CW = 8 * GL;                             // columns per chunk
+    constexpr int RPW = 64 / GL;                           // rows per wave and step
+    constexpr int RPB = RPW * NWV;                         // rows per block and step
+    constexpr int NE = 8 * NCH;                            // columns per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = w + 1;                                   // padded size
-    float* u = reinterpret_cast<float*>(smem);             // [n]
-    float* v = u + n;                                      // [n]
-    float* pm = v + n;                                     // [NWV][n]  per-wave column partial max
-    float* pz = pm + NWV * n;                              // [NWV][n]  per-wave column partial sum
+    const int ns = (n + 3) & ~3;                           // row stride of the LDS vectors (16-byte aligned rows)
+    float* u = reinterpret_cast<float*>(smem);             // [ns]
+    float* v = u + ns;                                     // [ns]
+    float* pm = v + ns;                                    // [NWV][ns]  per-wave column partial stabiliser
+    float* pz = pm + NWV * ns;                             // [NWV][ns]  per-wave column partial sum
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = lane / GL, pl = lane % GL;             // row group inside the wave, position inside the group
     const TI* S = cv + (size_t)blockIdx.x * w * w;
     const float log_row = -__logf(2.0f * w);               // log(1/(2w))   marginal of a regular row/column
     const float log_bin = __logf(0.5f);                    // log(w/(2w))   marginal of the dustbin
@@ -79,108 +95,201 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     float* oc = conf + (size_t)blockIdx.x * w;
     float* oo = occ + (size_t)blockIdx.x * w;
 
-    // a row is requested one iteration ahead as raw 16-byte pieces (no use of the data -> no wait) and decoded when it is consumed
-    auto fetch_row = [&](int i, raw16_t (&raw)[PPL]) __attribute__((always_inline)) {
+    // row i (i == w: the dustbin row, S = 0, never masked): raw 16-byte pieces of the lane's columns j = c*CW + pl*8 + 0..7
+    auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
         const TI* Si = S + (size_t)(i < w ? i : 0) * w;
         const int jend = i < w ? (use_pos ? i + 1 : w) : 0;
 #pragma unroll
-        for (int p = 0; p < PPL; ++p) {
-            const int j0 = (lane + 64 * p) * VEC;
-            if (j0 < jend) raw[p] = global_load16(Si + j0);      // w % VEC == 0: a piece starting inside [0, w) is whole
-        }
-    };
-    auto decode_row = [&](int i, const raw16_t (&raw)[PPL], float (&x)[EPL]) __attribute__((always_inline)) {
-        const int jend = use_pos ? i + 1 : w;
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int p = 0; p < PPL; ++p) {
-            const int j0 = (lane + 64 * p) * VEC;
-            const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[p]);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                if (i < w) x[p * VEC + e] = (j0 + e < jend) ? to_f32(r.v[e]) : -INFINITY;     // masked triangle / past the row
-                else x[p * VEC + e] = (j0 + e < w) ? 0.f : -INFINITY;                          // dustbin row: S = 0, never masked
+            for (int q = 0; q < PPC; ++q) {
+                const int j0 = c * CW + pl * 8 + q * VEC;
+                if (j0 < jend) raw[c][q] = global_load16(Si + j0);          // w % 8 == 0: a piece starting inside [0, w) is whole
             }
-        }
     };
-
-    LSE col[EPL];                                          // column accumulators of this lane (for the next v)
-    LSE bin;                                               // dustbin column (lane-uniform)
-    float vreg[EPL];                                       // v_j of this lane's columns for the current row sweep
-
-    for (int pass = 0; pass <= ot_iter; ++pass) {
-        const bool last = pass == ot_iter;
+    auto decode_row = [&](int i, const raw16_t (&raw)[NCH][PPC], float (&x)[NE]) __attribute__((always_inline)) {
+        const int jend = i < w ? (use_pos ? i + 1 : w) : (i == w ? w : 0);
 #pragma unroll
-        for (int c = 0; c < EPL; ++c) col[c].init();
-        bin.init();
-        if (pass > 0) {
+        for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int p = 0; p < PPL; ++p)
+            for (int q = 0; q < PPC; ++q) {
+                const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[c][q]);
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    const int j = (lane + 64 * p) * VEC + e;
-                    vreg[p * VEC + e] = j < w ? v[j] : 0.f;
+                    const int j = c * CW + pl * 8 + q * VEC + e;
+                    x[c * 8 + q * VEC + e] = j < jend ? (i < w ? to_f32(r.v[e]) : 0.f) : -INFINITY;   // masked triangle / past the row
                 }
-        }
-        const float vbin = pass > 0 ? v[w] : 0.f;
-        // rows i = wv, wv + NWV, ... ; the dustbin row i = w (S = 0, never masked) is row number w of the same sequence
-        raw16_t rcur[PPL], rnext[PPL];
-#pragma unroll
-        for (int p = 0; p < PPL; ++p) { rcur[p] = (raw16_t){0.f, 0.f, 0.f, 0.f}; rnext[p] = rcur[p]; }
-        fetch_row(wv, rcur);
-        for (int i = wv; i <= w; i += NWV) {
-            if (i + NWV <= w) fetch_row(i + NWV, rnext);          // in flight under this row's arithmetic
-            float x[EPL];
-            decode_row(i, rcur, x);
-#pragma unroll
-            for (int p = 0; p < PPL; ++p) rcur[p] = rnext[p];
-            float ui = 0.f;
-            if (pass > 0) {
-                // ---- row sweep: u_i = log mu_i - LSE_j(S_ij + v_j), dustbin column included (S = 0)
-                float mloc = -INFINITY;
-#pragma unroll
-                for (int c = 0; c < EPL; ++c) mloc = fmaxf(mloc, x[c] + vreg[c]);
-                const float m = fmaxf(wave_max_dpp(mloc), vbin);
-                float sloc = 0.f;
-#pragma unroll
-                for (int c = 0; c < EPL; ++c) sloc += __expf(x[c] + vreg[c] - m);
-                const float ssum = wave_sum_dpp(sloc) + __expf(vbin - m);
-                ui = (i == w ? log_bin : log_row) - (m + __logf(fmaxf(ssum, 1e-30f)));
-                if (lane == 0) u[i] = ui;
             }
-            if (!last) {
-                // ---- column sweep contribution of this row: S_ij + u_i
+    };
+
+    const int r0 = wv * RPW + grp;                         // rows of this group: r0, r0 + RPB, ...
+    // chunks that hold unmasked columns for ANY row of this wave in the step starting at row i0 (uniform per wave): under the
+    // positivity triangle row i ends at column i, so the early steps skip the right-hand chunks altogether
+    auto chunks_needed = [&](int i0) {
+        const int imax = i0 + wv * RPW + RPW - 1;
+        return (!use_pos || imax >= w) ? NCH : min(NCH, imax / CW + 1);
+    };
+    int* flag = reinterpret_cast<int*>(pz + NWV * ns);     // fast column sweep lost a column (underflow): redo the pass exactly
+
+    // ---- exact column sweep: v_j = log nu_j - LSE_i(S_ij + u_i) with lazy-maximum accumulators (pass 0, where u = 0, and the
+    // fallback of the fast sweep below)
+    auto exact_cols = [&](bool use_u) __attribute__((always_inline)) {
+        LSE col[NE], bin;
 #pragma unroll
-                for (int c = 0; c < EPL; ++c) col[c].add(x[c] + ui);
-                bin.add(ui);
+        for (int c = 0; c < NE; ++c) col[c].init();
+        bin.init();
+        for (int i0 = 0; i0 <= w; i0 += RPB) {
+            const int i = i0 + r0;
+            const bool active = i <= w;
+            const int nchw = chunks_needed(i0);
+            raw16_t raw[NCH][PPC];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int q = 0; q < PPC; ++q) raw[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f};
+            if (active) fetch_row(i, raw);
+            float x[NE];
+            decode_row(active ? i : w + 1, raw, x);
+            const float ua = active ? (use_u ? u[i] : 0.f) : -INFINITY;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c >= nchw) continue;
+                float t[8], dmax = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { t[e] = x[c * 8 + e] + ua; dmax = fmaxf(dmax, t[e] - col[c * 8 + e].m); }
+                if (__builtin_amdgcn_ballot_w64(dmax > kLazy)) {                  // rare: a stabiliser is too far below its new element
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) col[c * 8 + e].add_exact(t[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) col[c * 8 + e].z += __expf(t[e] - col[c * 8 + e].m);
+                }
+            }
+            bin.add_exact(ua);
+        }
+        // combine: across the row groups of a wave (lanes with equal pl), then across waves through LDS
+#pragma unroll
+        for (int off = GL; off < 64; off <<= 1) {
+#pragma unroll
+            for (int c = 0; c < NE; ++c) col[c].merge(__shfl_xor(col[c].m, off, 64), __shfl_xor(col[c].z, off, 64));
+            bin.merge(__shfl_xor(bin.m, off, 64), __shfl_xor(bin.z, off, 64));
+        }
+        __syncthreads();                                   // readers of pm / pz / v of the previous pass are done
+        if (grp == 0) {
+#pragma unroll
+            for (int c = 0; c < NE; ++c) {
+                const int j = (c / 8) * CW + pl * 8 + (c % 8);
+                if (j < w) { pm[wv * ns + j] = col[c].m; pz[wv * ns + j] = col[c].z; }
+            }
+            if (pl == 0) { pm[wv * ns + w] = bin.m; pz[wv * ns + w] = bin.z; }
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += NWV * 64) {
+            LSE t; t.init();
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) t.merge(pm[k * ns + j], pz[k * ns + j]);
+            v[j] = (j == w ? log_bin : log_row) - t.value();
+        }
+        __syncthreads();
+    };
+
+    exact_cols(false);                                     // pass 0: v = log nu - LSE_i(S)
+
+    // ---- passes 1 .. ot_iter: row sweep (exact max-then-sum) fused with the next column sweep.  With e_ij = exp(S_ij + v_j - m_i)
+    // from the row sweep, the column term is exp(S_ij + u_i - (c0 - v_j)) = e_ij * exp(u_i + m_i - c0): ONE multiply-add per element
+    // against the per-row factor f_i -- the stabiliser c0 - v_j is the column's previous log-sum-exp up to a constant, and
+    // f_i <= 1 for c0 = log(1/2) (u_i + m_i <= log mu_i), so nothing can overflow; a column whose sum underflows (it would need a
+    // dynamic range of e^80 inside the volume) raises a flag and the pass is redone with exact_cols.
+    const float c0 = log_bin;
+    for (int pass = 1; pass <= ot_iter; ++pass) {
+        const bool last = pass == ot_iter;
+        float zc[NE], zbin = 0.f;
+#pragma unroll
+        for (int c = 0; c < NE; ++c) zc[c] = 0.f;
+        const float vbin = v[w];
+        if (tid == 0) *flag = 0;
+        raw16_t rcur[NCH][PPC], rnext[NCH][PPC];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < PPC; ++q) { rcur[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f}; rnext[c][q] = rcur[c][q]; }
+        fetch_row(r0, rcur);
+        for (int i0 = 0; i0 <= w; i0 += RPB) {             // uniform trip count for every wave (groups past row w idle)
+            const int i = i0 + r0;
+            const bool active = i <= w;
+            const int nchw = chunks_needed(i0);
+            if (i + RPB <= w) fetch_row(i + RPB, rnext);          // in flight under this row's arithmetic
+            float x[NE];
+            decode_row(active ? i : w + 1, rcur, x);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int q = 0; q < PPC; ++q) rcur[c][q] = rnext[c][q];
+            // ---- row sweep: u_i = log mu_i - LSE_j(S_ij + v_j), dustbin column included (S = 0)
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c >= nchw) continue;
+                const int j0 = c * CW + pl * 8;
+                const float4_t va = j0 < n ? *reinterpret_cast<const float4_t*>(v + j0) : float4_t{0.f, 0.f, 0.f, 0.f};
+                const float4_t vb = j0 + 4 < n ? *reinterpret_cast<const float4_t*>(v + j0 + 4) : float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[c * 8 + e] += e < 4 ? va[e] : vb[e - 4]; mloc = fmaxf(mloc, x[c * 8 + e]); }   // x <- S + v (masked: -inf)
+            }
+            const float m = fmaxf(group_max_f<GL>(mloc), vbin);
+            float sloc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c >= nchw) continue;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[c * 8 + e] = __expf(x[c * 8 + e] - m); sloc += x[c * 8 + e]; }               // x <- e_ij
+            }
+            const float srow = group_sum_f<GL>(sloc);
+            const float ebin = __expf(vbin - m);
+            const float ui = (i == w ? log_bin : log_row) - (m + __logf(fmaxf(srow + ebin, 1e-30f)));
+            if (!last) {
+                if (pl == 0 && active) u[i] = ui;                                 // (only the exact fallback reads it)
+                const float f = active ? __expf(ui + m - c0) : 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c >= nchw) continue;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) zc[c * 8 + e] = __builtin_fmaf(x[c * 8 + e], f, zc[c * 8 + e]);
+                }
+                zbin = __builtin_fmaf(ebin, f, zbin);
             } else if (i < w) {
-                // ---- probabilities, argmax (first max wins), window regression, row mass
+                // ---- probabilities P_ij = e_ij * exp(m_i + u_i + log 2w), argmax (first max wins), window regression, row mass
                 const float ci = ui + log2w;
-                float best = -1.f, mass = 0.f;
+                const float gsc = __expf(m + ci);
+                const int jend = use_pos ? i + 1 : w;
+                float best = -1.f;
                 int bj = 0x7fffffff;
 #pragma unroll
-                for (int c = 0; c < EPL; ++c) {
-                    const float pr = __expf(x[c] + ci + vreg[c]);                  // exp(-inf) = 0 for masked / out-of-range columns
-                    mass += pr;
-                    const int j = (lane + 64 * (c / VEC)) * VEC + (c % VEC);
-                    if (x[c] != -INFINITY && pr > best) { best = pr; bj = j; }    // strict: keeps the first maximum of this lane
+                for (int c = 0; c < NCH; ++c) {
+                    if (c >= nchw) continue;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int j = c * CW + pl * 8 + e;
+                        const float pr = x[c * 8 + e] * gsc;
+                        if (j < jend && pr > best) { best = pr; bj = j; }        // strict: keeps the first maximum of this lane
+                    }
                 }
-                const float bmax = wave_max_dpp(best);
-                bj = wave_min_dpp(best == bmax ? bj : 0x7fffffff);
-                mass = wave_sum_dpp(mass);
-                // 5 taps around the argmax, evaluated by lanes 0..4 (zero outside [0,w) and in the masked triangle)
+                const float bmax = group_max_f<GL>(best);
+                bj = group_min_i<GL>(best == bmax ? bj : 0x7fffffff);
+                const float mass = srow * gsc;
+                // 5 taps around the argmax, evaluated by lanes 0..4 of the group (zero outside [0,w) and in the masked triangle)
                 const TI* Si = S + (size_t)i * w;
-                const int jend = use_pos ? i + 1 : w;
-                const int jj = bj + lane - 2;
+                const int jj = bj + pl - 2;
                 float pk = 0.f;
-                if (lane < 5 && jj >= 0 && jj < jend) pk = __expf(to_f32(Si[jj]) + ci + v[jj]);
+                if (pl < 5 && jj >= 0 && jj < jend) pk = __expf(to_f32(Si[jj]) + ci + v[jj]);
                 float cf = 0.f, num = 0.f;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {                                     // same summation order as the reference loop
-                    const float pr = rl(pk, k);
+                    const float pr = __shfl(pk, grp * GL + k, 64);
                     cf += pr;
                     num += pr * (float)(bj + k - 2);
                 }
-                if (lane == 0) {
+                if (pl == 0) {
                     const float corr = (num + 1e-4f) / (cf + 1e-4f);
                     od[i] = (float)i - corr;
                     oc[i] = cf;
@@ -190,32 +299,43 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             }
         }
         if (last) break;
-        // ---- combine the per-wave column partials into v
+        // ---- combine the partial column sums: across the row groups of a wave (lanes with equal pl), then across waves through LDS
 #pragma unroll
-        for (int p = 0; p < PPL; ++p)
+        for (int off = GL; off < 64; off <<= 1) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const int j = (lane + 64 * p) * VEC + e;
-                if (j < w) { pm[wv * n + j] = col[p * VEC + e].m; pz[wv * n + j] = col[p * VEC + e].z; }
+            for (int c = 0; c < NE; ++c) zc[c] += __shfl_xor(zc[c], off, 64);
+            zbin += __shfl_xor(zbin, off, 64);
+        }
+        __syncthreads();                                   // every row sweep of this pass has read v
+        if (grp == 0) {
+#pragma unroll
+            for (int c = 0; c < NE; ++c) {
+                const int j = (c / 8) * CW + pl * 8 + (c % 8);
+                if (j < w) pz[wv * ns + j] = zc[c];
             }
-        if (lane == 0) { pm[wv * n + w] = bin.m; pz[wv * n + w] = bin.z; }
-        __syncthreads();
-        for (int j = tid; j < n; j += NWV * 64) {
-            LSE t; t.init();
-#pragma unroll
-            for (int k = 0; k < NWV; ++k) t.merge(pm[k * n + j], pz[k * n + j]);
-            v[j] = (j == w ? log_bin : log_row) - t.value();
+            if (pl == 0) pz[wv * ns + w] = zbin;
         }
         __syncthreads();
+        for (int j = tid; j < n; j += NWV * 64) {
+            float z = 0.f;
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) z += pz[k * ns + j];
+            if (!(z > 1e-30f) || !(z < 3.0e38f)) *flag = 1;                       // underflow (or NaN): this pass needs the exact sweep
+            v[j] = (j == w ? log_bin : log_row) - ((c0 - v[j]) + __logf(z));
+        }
+        __syncthreads();
+        if (*flag) exact_cols(true);                       // uniform for the block; rewrites every v_j from S and u
     }
 }
 
-template <typename TI, int PPL>
+template <typename TI, int GL, int NCH>
 static int launch_sinkhorn(const void* cv, float* disp, float* conf, float* occ, int32_t* amax, int rows, int w, int ot_iter,
                            int use_pos, hipStream_t st) {
-    constexpr int NWV = 16;
-    auto kern = sinkhorn_regress_kernel<TI, NWV, PPL>;
-    const size_t lds = (size_t)(2 + 2 * NWV) * (w + 1) * sizeof(float);
+    // 16 waves per row block where a lane's state (8 * NCH columns: values + two accumulator words each) fits 128 registers, else 8
+    constexpr int NWV = NCH == 1 ? 16 : 8;
+    auto kern = sinkhorn_regress_kernel<TI, NWV, GL, NCH>;
+    const size_t lds = (size_t)(2 + 2 * NWV) * ((w + 4) & ~3) * sizeof(float) + 16;
+    if (lds > 160 * 1024) return set_error("sinkhorn: w=%d needs %zu bytes of LDS (at most about w = 1200)", w, lds);
     static size_t attr_bytes_dev[kMaxDevices] = {};
     size_t& attr_bytes = attr_bytes_dev[current_device()];
     if (lds > attr_bytes) {
@@ -227,16 +347,22 @@ static int launch_sinkhorn(const void* cv, float* disp, float* conf, float* occ,
     return check_launch("sinkhorn_regress");
 }
 
+// lanes per row so that a row needs at most 3 chunks of 8 columns per lane: 16 lanes up to w = 384, 32 up to 768, 64 up to 1536
 template <typename TI>
 static int dispatch_ppl(const void* cv, float* disp, float* conf, float* occ, int32_t* amax, int rows, int w, int ot_iter,
                         int use_pos, hipStream_t st) {
-    constexpr int VEC = 16 / (int)sizeof(TI);
-    const int need = (w + 64 * VEC - 1) / (64 * VEC);          // 16-byte pieces per lane
-    if (need <= 1) return launch_sinkhorn<TI, 1>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);
-    if (need <= 2) return launch_sinkhorn<TI, 2>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);
-    if (need <= 3) return launch_sinkhorn<TI, 3>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);
-    if (need <= 4) return launch_sinkhorn<TI, 4>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);
-    return set_error("sinkhorn: w=%d too large (max %d)", w, 4 * 64 * VEC);
+#define S2M2_K2(GL)                                                                                                          \
+    {                                                                                                                        \
+        const int nch = (w + 8 * GL - 1) / (8 * GL);                                                                         \
+        if (nch <= 1) return launch_sinkhorn<TI, GL, 1>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
+        if (nch <= 2) return launch_sinkhorn<TI, GL, 2>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
+        if (nch <= 3) return launch_sinkhorn<TI, GL, 3>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
+    }
+    if (w <= 384) S2M2_K2(16)
+    if (w <= 768) S2M2_K2(32)
+    if (w <= 1536) S2M2_K2(64)
+#undef S2M2_K2
+    return set_error("sinkhorn: w=%d too large (max 1536)", w);
 }
 
 }  // namespace s2m2
