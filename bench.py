@@ -294,11 +294,15 @@ def main():
         h, w, C = a.height // 4, a.width // 4, model.feature_channels
         e = 2 if use_fp16 else 4
         k1_bytes = B * (2 * h * w * C * e + h * w * w * e)         # read both feature maps once + write cv once
+        k1_variant = "full volume (B,h,w,w)"
+        if eng.cv_band >= 0:                                       # opt-in banded store (S2M2_CV_BAND=1): only j <= i + band must be written
+            k1_bytes = B * (2 * h * w * C * e + h * e * sum(min(w, i + 1 + eng.cv_band) for i in range(w)))
+            k1_variant = f"banded volume j <= i + {eng.cv_band}"
         k1_us = 1e3 * sum(k1_ms) / max(1, len(k1_ms))
         achieved = k1_bytes / (k1_us * 1e-6) / 1e9 if k1_us > 0 else 0.0
         pairs = a.steps * B * world
         ms_per_pair_gpu = 1e3 * elapsed / (a.steps * B)             # one GPU's time per pair
-        traffic, traffic_src = pmc_traffic(a.model, a.height, a.width, use_fp16, B)
+        traffic, traffic_src = pmc_traffic(a.model, a.height, a.width, use_fp16, B) if eng.cv_band < 0 else (None, None)
         # ---- after the timed region: one instrumented eager forward (work meter + HIP events around every K4 launch)
         eng.k1_events = None
         hip.METER, hip.ATTN_EVENTS = {}, []
@@ -326,7 +330,7 @@ def main():
             "config": {"workload": f"{a.model}-model {a.width}x{a.height} refine_iter={a.refine_iter} use_positivity=True, "
                                    f"{B} pair(s) per GPU per step, random-init weights (seeded LeCun normal)",
                        "pairs_per_gpu": B, "parallelism": f"dp{world} (pairs sharded, RCCL gather of outputs to rank 0)"},
-            "roofline": {"kernel": "ln_corr_kernel (K1: LayerNorm + all-pairs correlation -> cost volume)", "bound": "hbm",
+            "roofline": {"kernel": "ln_corr_kernel (K1: LayerNorm + all-pairs correlation -> cost volume)", "bound": "hbm", "variant": k1_variant,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": k1_us,
                          "launches_timed": len(k1_ms)},

@@ -54,6 +54,15 @@ int s2m2_ln_corr(const void* feat, const float* ln_w, const float* ln_b, void* c
 int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, void* cv,
                        int B, int h, int w, int C, int feat_dtype, int cv_dtype, void* stream,
                        void* start_event, void* stop_event);
+/*
+ * Banded cost volume for use_positivity models: writes cv[b,y,i,j] only for j <= i + band (rounded up to
+ * the kernel's 64-column store granule); the rest of the buffer is left untouched.  With non-negative disparities nothing downstream
+ * reads beyond band = 11: the Sinkhorn mask removes j > i (submodules.py:211-214) and the +-4 tap lookups at both pyramid levels
+ * reach column i + 11 at most (submodules.py:39-60).  start_event / stop_event may be NULL.
+ */
+int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, void* cv,
+                        int B, int h, int w, int C, int feat_dtype, int cv_dtype, int band, void* stream,
+                        void* start_event, void* stop_event);
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);

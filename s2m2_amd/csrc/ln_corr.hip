@@ -128,7 +128,7 @@ template <> __device__ __forceinline__ void store_quad<float>(float* dst, float 
 template <typename CFG, typename T, typename TO>
 __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, TO* __restrict__ cv,
-                                                                 int B, int h, int w, int nstrip) {
+                                                                 int B, int h, int w, int nstrip, int band) {
     constexpr int dbg = S2M2_LNCORR_DBG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
@@ -293,7 +293,17 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
             const int jbase = c * TJ;
             int ntile = (w - jbase + 31) / 32;                    // 32-wide column tiles with data in this chunk
             ntile = ntile < NW ? ntile : NW;
-            const int npair = (ntile + 1) >> 1;
+            int npair = (ntile + 1) >> 1;
+            // banded volume (band >= 0, use_positivity models): only columns j <= i + band are ever read downstream (the masked
+            // Sinkhorn, the +-4 tap lookups at disparities >= 0), so this wave (rows i0 .. i0+31) stops at column i0 + 31 + band
+            if (band >= 0) {
+                const int last_col = i0 + 31 + band - jbase;
+                const int need = last_col < 0 ? 0 : last_col / 64 + 1;
+                npair = npair < need ? npair : need;
+                const int nt = 2 * npair;
+                ntile = ntile < nt ? ntile : nt;
+            }
+            if (npair > 0) {
             // The column tiles are taken two at a time (64 columns = 128-B row segments in the stores), starting at a
             // different pair per wave.  Software pipeline: the 16 MFMAs of pair p+1 (two independent accumulators,
             // interleaved) are issued BEFORE pair p is read back from the staging tile and stored, so the matrix
@@ -344,6 +354,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                 __builtin_amdgcn_wave_barrier();
                 K1_T(6 + (pp < 8 ? pp : 8));
             }
+            }
         }
         K1_T(15);
         if (c + 1 < nchunks) __syncthreads();                     // all readers done before Bs is overwritten
@@ -356,6 +367,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 // s2m2_ln_corr_timed: events attached to the next launch of the calling thread (hipExtLaunchKernel records them at the start and
 // at the end of the kernel's execution)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local int g_band = -1;                 // s2m2_ln_corr_banded: columns right of the diagonal that must be valid (-1: all)
 
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st);
@@ -393,10 +405,10 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     }
     if (g_ev_start || g_ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
-                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip);
+                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band);
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
-                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip);
+                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band);
     return check_launch("ln_corr");
 }
 
@@ -445,6 +457,15 @@ extern "C" int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const flo
     s2m2::g_ev_stop = static_cast<hipEvent_t>(stop_event);
     const int rc = s2m2_ln_corr(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream);
     s2m2::g_ev_start = s2m2::g_ev_stop = nullptr;
+    return rc;
+}
+
+extern "C" int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
+                                   int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
+    S2M2_REQUIRE(band >= 0, "ln_corr_banded: band=%d must be >= 0 (use s2m2_ln_corr for the full volume)", band);
+    s2m2::g_band = band;
+    const int rc = s2m2_ln_corr_timed(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream, start_event, stop_event);
+    s2m2::g_band = -1;
     return rc;
 }
 

@@ -93,6 +93,9 @@ class Engine:
         self._fusion_ok: Dict[int, bool] = {}
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
         self.use_frag = os.environ.get("S2M2_CONV_FRAG", "1") != "0"     # A/B switch: 0 = spatial layers on the v3 halo tiles (K order 0)
+        # opt-in: banded cost volume (columns j <= i + 11) for use_positivity models.  Off by default: the reference's DispInit hands
+        # out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward (measured: profiles/r02/kbench.txt)
+        self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
@@ -467,14 +470,14 @@ class Engine:
         return z[0], py[0], f2[:B], x8[:B]                                      # tokens (2B,h,w,C), pyramid 1/4, left 1/2 features, image
 
     @torch.no_grad()
-    def cost_volume(self, tr: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    def cost_volume(self, tr: Tensor, out: Optional[Tensor] = None, banded: bool = True) -> Tensor:
         """K1: LayerNorm + all-pairs correlation (submodules.py:216-217).  With ``k1_events`` set (bench.py) every launch carries a
         start / stop HIP event pair on its dispatch (hip.KernelTimer), collected in that list."""
         timer = None
         if self.k1_events is not None:
             timer = hip.KernelTimer()
             self.k1_events.append(timer)
-        return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer)
+        return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer, band=self.cv_band if banded else -1)
 
     @torch.no_grad()
     def finish(self, tr: Tensor, py0: Tensor, f2_left: Tensor, x8: Tensor, cv: Tensor, cap: Optional[dict] = None):
@@ -518,7 +521,7 @@ class Engine:
         tr, py0, f2_left, x8 = self.features(img0, img1)
         if cap is not None and "feature_tr_4x" in (cap.get("inject") or {}):           # parity tests only, see finish()
             tr = cap["inject"]["feature_tr_4x"].to(tr.device, tr.dtype).permute(0, 2, 3, 1).contiguous()
-        cv = self.cost_volume(tr)
+        cv = self.cost_volume(tr, banded=cap is None)             # captured runs hand out the full volume, like the reference
         return self.finish(tr, py0, f2_left, x8, cv, cap)
 
     def _conv0(self) -> Spec:

@@ -49,6 +49,7 @@ SIGNATURES = {
     "s2m2_ln_corr_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
     "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "s2m2_ln_corr_timed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_ln_corr_banded": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_event_create": (_i, [ctypes.POINTER(_vp)]),
     "s2m2_event_destroy": (_i, [_vp]),
     "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
@@ -144,8 +145,9 @@ class KernelTimer:
 
 
 def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype: Optional[torch.dtype] = None,
-            out: Optional[torch.Tensor] = None, timer: Optional[KernelTimer] = None) -> torch.Tensor:
-    """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w).  [A4]   timer: see KernelTimer."""
+            out: Optional[torch.Tensor] = None, timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
+    """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w).  [A4]   timer: see KernelTimer.  band >= 0: only
+    columns j <= i + band are written (s2m2_ln_corr_banded), the rest of ``cv`` keeps whatever it held."""
     _dev(feat, ln_w, ln_b)
     twoB, h, w, C = feat.shape
     B = twoB // 2
@@ -154,7 +156,12 @@ def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype
     if tuple(cv.shape) != (B, h, w, w) or not cv.is_contiguous():
         raise ValueError("ln_corr: out must be a contiguous (B,h,w,w) tensor")
     cv_dtype = cv.dtype
-    if timer is not None:
+    if band >= 0:
+        _check(load().s2m2_ln_corr_banded(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
+                                          B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], band, _stream(),
+                                          timer.start if timer is not None else None, timer.stop if timer is not None else None),
+               "s2m2_ln_corr_banded")
+    elif timer is not None:
         _check(load().s2m2_ln_corr_timed(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
                                          B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream(), timer.start, timer.stop), "s2m2_ln_corr_timed")
     else:
