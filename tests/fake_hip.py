@@ -15,7 +15,7 @@ def make():
     ns = types.SimpleNamespace(ACT_NONE=0, ACT_GELU=1, ACT_RELU=2, ACT_SIGMOID=3, ACT_TANH=4,
                                EPI_NONE=0, EPI_ADD=1, EPI_MUL=2, EPI_GRU=3, EPI_GATEMIX=4, EPI_DUALMIX=5, load=lambda: None)
 
-    def ln_corr(tokens, g, b, cv_dtype=None, out=None, timer=None):
+    def ln_corr(tokens, g, b, cv_dtype=None, out=None, timer=None, band=-1):
         return O.ln_corr(tokens.permute(0, 3, 1, 2).float(), g, b)
 
     def sinkhorn_regress(cv, pos, ot_iter=3, want_argmax=False):
