@@ -90,20 +90,21 @@ template <typename T> __device__ __forceinline__ Vec16<T> zero_vec() {
 // Aux tensors of the epilogue (residual / gate operands), one 16-byte piece per staged piece of this thread: requested right
 // after the K loop, so their latency runs under the activation math, the LDS staging and its barrier instead of in front of
 // every store.  Kept in registers only while that is cheap (at most 4 pieces per thread); larger tiles load inside the loop.
-template <typename CFG, typename T>
+template <typename CFG, typename T, int MAXNP = 4>
 struct AuxRegs {
     static constexpr int PCR = CFG::BN / CFG::VEC;                // pieces per staged row
     static constexpr int TOTAL = CFG::BM * PCR;
     static constexpr int NP = (TOTAL + CFG::NT - 1) / CFG::NT;    // pieces per thread
-    static constexpr bool ON = NP <= 4;
+    static constexpr bool ON = NP <= MAXNP;
     raw16_t a0[ON ? NP : 1], a1[ON ? NP : 1];
 
     // pix(r, m): global output pixel of staged row r (false: outside the image / past M)
-    template <typename PIX>
+    // ONE: the caller launches with one-operand epilogues only (a1 stays a constant zero: no registers)
+    template <bool ONE = false, typename PIX>
     __device__ __forceinline__ void prefetch(const ConvArgs& p, int tid, int n0, PIX pix) {
         if constexpr (ON) {
             if (p.epi == S2M2_EPI_NONE) return;
-            const bool two = p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX || p.epi == S2M2_EPI_DUALMIX;
+            const bool two = !ONE && (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX || p.epi == S2M2_EPI_DUALMIX);
 #pragma unroll
             for (int it = 0; it < NP; ++it) {
                 const int q = tid + CFG::NT * it, r = q / PCR, pcc = q - r * PCR;
@@ -119,9 +120,8 @@ struct AuxRegs {
 };
 
 // epilogue 2: the staged tile comes back as 16-byte pieces of whole pixel rows: aux combine, coalesced store
-template <typename CFG, typename T, typename PIX>
-__device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int tid, int n0, const AuxRegs<CFG, T>& aux, PIX pix) {
-    using AX = AuxRegs<CFG, T>;
+template <typename CFG, typename T, typename AX, typename PIX>
+__device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int tid, int n0, const AX& aux, PIX pix) {
     constexpr int VEC = CFG::VEC, PCR = AX::PCR;
     T* outp = static_cast<T*>(p.out);
 #pragma unroll
@@ -1086,7 +1086,7 @@ struct ConvCfgF {
     static_assert(NT % PPX == 0 && KS >= 2 && KS % 2 == 0, "loader geometry");
 };
 
-template <typename CFG, typename T>
+template <typename CFG, typename T, bool AUX>
 __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tiles_x, int tiles_y) {
     constexpr int BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, CH = CFG::CH, KS = CFG::KS, PH = CFG::PH, PW = CFG::PW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1166,6 +1166,15 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
 
     CoutRegs<CFG> bias;                                           // requested now, used after the K loop
     bias.load(p.bias, p.zero, p.Cout, n0, wv, lane);
+    // epilogue operand (residual / gate, one-operand epilogues): requested FIRST, as ordinary tracked loads, and parked in 32 registers
+    // through the K loop.  Being older than every ring request they never enter the ring's counted waits (requests complete in
+    // order; a tracked load the compiler moved below the ring's first requests would only make those waits conservative), and
+    // their latency runs beside the halo tile's.  (Requested after the K loop, 8 pieces per thread sat in front of the stores:
+    // +3.5 us per block, profiles/r02/frag_timeline.txt.)
+    const PatchPix pix{n, y0, x0, p.H, p.W};
+    using AX = AuxRegs<CFG, T, AUX ? 8 : 4>;
+    AX aux;
+    if constexpr (AUX) aux.template prefetch<true>(p, tid, n0, pix);
     float16_t acc[CFG::MT][CFG::NTL];
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i)
@@ -1180,6 +1189,34 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     __syncthreads();
     FRAG_T(1);
     int g = 0;                                                    // global k16 step = index of the fragment consumed next
+    auto tap_steps = [&](int ky, int kx) __attribute__((always_inline)) {          // the KS k16 steps of one tap
+        const T* a = Ah + (size_t)(ky * HW_ + l31 + kx) * RS + hi * 8;
+        Frag<T> xf[2][CFG::MT];                                   // pixel fragments, double buffered across k16 steps
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i) load_frag(xf[0][i], a + (size_t)i * HW_ * RS);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (kk + 1 < KS) {
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[(kk + 1) & 1][i], a + (size_t)i * HW_ * RS + (kk + 1) * 16);
+            }
+            // fragment g (slot kk) was requested KS - 1 steps ago; the KS - 2 requests made since then may still be in flight
+            wait_vmcnt<KS - 2>();
+            settle(ring[kk]);
+            Frag<T> wfr;
+            wfr.v = __builtin_bit_cast(half8_t, ring[kk]);
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i) mma32(acc[i][0], wfr, xf[kk & 1][i]);   // D[cout][pixel]
+            // refill the slot consumed one step ago (its MFMAs have long read their operands) with fragment g + KS - 1.
+            // UNCONDITIONAL: a branch around an untracked load makes the compiler merge the two register states with copies
+            // that read the slot while its load is in flight.  (Step 0 re-requests fragment KS - 1 into its own slot.)
+            {
+                const int f = g + KS - 1;
+                global_load16_async(ring[(kk + KS - 1) % KS], wf + (size_t)(f < nfrag ? f : nfrag - 1) * 64);
+            }
+            ++g;
+        }
+    };
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         if (chunk > 0) {
             wait_vmcnt<0>();                                      // ring loads land before tracked loads are mixed in (their data stays valid)
@@ -1190,32 +1227,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
         int ky = 0, kx = 0;
 #pragma unroll 1
         for (int tap = 0; tap < ntap; ++tap) {
-            const T* a = Ah + (size_t)(ky * HW_ + l31 + kx) * RS + hi * 8;
-            Frag<T> xf[2][CFG::MT];                               // pixel fragments, double buffered across k16 steps
-#pragma unroll
-            for (int i = 0; i < CFG::MT; ++i) load_frag(xf[0][i], a + (size_t)i * HW_ * RS);
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                if (kk + 1 < KS) {
-#pragma unroll
-                    for (int i = 0; i < CFG::MT; ++i) load_frag(xf[(kk + 1) & 1][i], a + (size_t)i * HW_ * RS + (kk + 1) * 16);
-                }
-                // fragment g (slot kk) was requested KS - 1 steps ago; the KS - 2 requests made since then may still be in flight
-                wait_vmcnt<KS - 2>();
-                settle(ring[kk]);
-                Frag<T> wfr;
-                wfr.v = __builtin_bit_cast(half8_t, ring[kk]);
-#pragma unroll
-                for (int i = 0; i < CFG::MT; ++i) mma32(acc[i][0], wfr, xf[kk & 1][i]);   // D[cout][pixel]
-                // refill the slot consumed one step ago (its MFMAs have long read their operands) with fragment g + KS - 1.
-                // UNCONDITIONAL: a branch around an untracked load makes the compiler merge the two register states with copies
-                // that read the slot while its load is in flight.  (Step 0 re-requests fragment KS - 1 into its own slot.)
-                {
-                    const int f = g + KS - 1;
-                    global_load16_async(ring[(kk + KS - 1) % KS], wf + (size_t)(f < nfrag ? f : nfrag - 1) * 64);
-                }
-                ++g;
-            }
+            tap_steps(ky, kx);
             if (++kx == p.KW) { kx = 0; ++ky; }
         }
     }
@@ -1227,14 +1239,11 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     FRAG_T(2);
     __syncthreads();                                              // the staging tile aliases the halo tile
     FRAG_T(3);
-    const PatchPix pix{n, y0, x0, p.H, p.W};
-    AuxRegs<CFG, T> aux;
-    aux.prefetch(p, tid, n0, pix);
     stage_tile_act<CFG, T>(p, acc, Cs, bias, 0, wv, lane);
     FRAG_T(4);
     __syncthreads();
     FRAG_T(5);
-    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);
+    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);                 // (!AUX: launched with epi == NONE only, no operand is read)
     FRAG_T(6);
 }
 
@@ -1448,18 +1457,20 @@ static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
         return set_error("conv2d: K order 2 (fragment stream) is an fp16 layout");
     } else {
         using CFG = ConvCfgF<T, BN, CH>;
-        auto kern = conv_frag_kernel<CFG, T>;
-        static bool attr_done_dev[kMaxDevices] = {};
-        bool& attr_done = attr_done_dev[current_device()];
+        const bool with_aux = a.epi != S2M2_EPI_NONE;            // epilogue operands: the variant that requests them under its last tap
+        auto kern = with_aux ? conv_frag_kernel<CFG, T, true> : conv_frag_kernel<CFG, T, false>;
+        static bool attr_done_dev[kMaxDevices][2] = {};
+        bool& attr_done = attr_done_dev[current_device()][with_aux];
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)CFG::LDS_BYTES) != hipSuccess)
                 return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
             attr_done = true;
         }
-        if (a.stride != 1 || a.shuffle2 || a.KH > 3 || a.KW > 3 || a.KH * a.KW < 2 || a.Cout % BN || a.Cin % 8 || a.ln_wsum ||
-            a.epi == S2M2_EPI_DUALMIX)
+        if (a.stride != 1 || a.shuffle2 || a.KH > 3 || a.KW > 3 || a.KH * a.KW < 2 || a.Cout % BN || a.Cin % 8 || a.ln_wsum)
             return set_error("conv2d: K order 2 needs a stride-1 3x3 / 3x1 / 1x3 layer with Cout a multiple of %d (Cout=%d)", BN, a.Cout);
+        if (a.epi == S2M2_EPI_DUALMIX || a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX)
+            return set_error("conv2d: K order 2 takes one-operand epilogues only (epi=%d has two)", a.epi);
         const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
         dim3 grid((unsigned)(a.N * tx * ty), (unsigned)(a.Cout / BN));
         hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty);

@@ -47,12 +47,19 @@ __device__ unsigned long long g_k1_trace[1024 * 16 * 16];
 
 namespace s2m2 {
 
-template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool PIPE_ = false>
+template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool PIPE_ = false, int TPW_ = 32>
 struct LnCorrCfg {
     static constexpr bool PIPE = PIPE_;                 // right tokens normalised in 4 rounds, column tiles stored as soon as their tokens exist
     static constexpr int C = C_;
     static constexpr int RIF = RIF_;                    // token rounds (8 tokens per wave each) kept in flight in registers
     static constexpr bool EARLY_B = EARLY_B_;           // right tokens of chunk 0 are requested together with the left ones
+    // right tokens each wave normalises per chunk.  32: a chunk is as wide as the block's left strips (whole rows in one chunk at
+    // C <= 128).  16 (wide C): the LDS a wave needs halves, so a block can hold a wave for EVERY left strip of a row and walk the
+    // right row in chunks of 16*NW tokens -- the right row is read and normalised once per row instead of once per strip
+    static constexpr int TPW = TPW_;
+    static constexpr int ROUNDS = TPW / 8;              // 8-token rounds per wave per chunk
+    static constexpr bool LEAN = TPW < 32 && sizeof(T) == 2;   // register-lean LayerNorm (normalize_store)
+    static constexpr bool ALLRES = RIF == ROUNDS;       // every round of a chunk resident in registers: the next chunk is prefetched
     static constexpr int VEC = 16 / sizeof(T);          // elements per 16-B piece
     static constexpr int PIECES = C / VEC;              // pieces per token
     static constexpr int LPT = 8;                       // lanes per token
@@ -62,13 +69,15 @@ struct LnCorrCfg {
     static constexpr int CRS = 64 + VECO;               // staging row stride (elements of TO): 2 tiles + 16 B pad
     static constexpr int KSTEPS = C / 16;
     static constexpr size_t GB_BYTES = 2 * C * sizeof(float);
-    static constexpr size_t WB_BYTES = (size_t)32 * RS * sizeof(T);      // per wave: its 32 normalised tokens
+    static constexpr size_t WB_BYTES = (size_t)TPW * RS * sizeof(T);     // per wave: its TPW normalised tokens
     static constexpr size_t WC_BYTES = (size_t)32 * CRS * sizeof(TO);    // per wave: 32 x 64 output staging
     static constexpr size_t lds_bytes(int nw) { return GB_BYTES + (size_t)nw * (WB_BYTES + WC_BYTES); }
     static constexpr int NWLDS = (int)((160 * 1024 - GB_BYTES) / (WB_BYTES + WC_BYTES));
-    static constexpr int NWMAX = NWLDS < NWCAP_ ? NWLDS : NWCAP_;      // waves per block: LDS bound, register bound
+    static constexpr int NWGRAN = 32 / TPW;             // waves per block come in multiples of this: chunks are whole 32-column tiles
+    static constexpr int NWMAX = (NWLDS < NWCAP_ ? NWLDS : NWCAP_) / NWGRAN * NWGRAN;   // waves per block: LDS bound, register bound
     static_assert(PIECES % LPT == 0 && LPT == 8, "C must be a multiple of 8 pieces; group8_sum assumes 8 lanes per token");
     static_assert(NWMAX >= 1, "LDS budget");
+    static_assert((TPW == 32 || TPW == 16) && ROUNDS % RIF == 0 && (!PIPE || TPW == 32), "token rounds");
 };
 
 // LayerNorm (eps 1e-5, biased variance, affine) one token spread over 8 lanes (PPL 16-B pieces per lane) in fp32 and
@@ -82,6 +91,47 @@ __device__ __forceinline__ void normalize_store(const Vec16<T> (&p)[CFG::PPL], T
     if (dbg & 4) {                                       // ablation: no LayerNorm arithmetic, plain copy
 #pragma unroll
         for (int q = 0; q < CFG::PPL; ++q) *reinterpret_cast<Vec16<T>*>(drow + (sub + CFG::LPT * q) * CFG::VEC) = p[q];
+        return;
+    }
+    if constexpr (CFG::LEAN) {
+        // wide C: the fp32 copy of the token (C / 8 registers per lane) is what pushes these configurations over the register budget
+        // of a block with one wave per left strip.  The three passes convert from the 16-bit pieces each time instead (the pieces are
+        // made opaque in between, or the compiler would keep the converted values after all); same operations in the same order as
+        // below, bit-identical results.
+        Vec16<T> pp[CFG::PPL];
+#pragma unroll
+        for (int q = 0; q < CFG::PPL; ++q) pp[q] = p[q];
+        auto opaque = [&]() {
+#pragma unroll
+            for (int q = 0; q < CFG::PPL; ++q) {
+                raw16_t r = __builtin_bit_cast(raw16_t, pp[q]);
+                asm volatile("" : "+v"(r));
+                pp[q] = __builtin_bit_cast(Vec16<T>, r);
+            }
+        };
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < CFG::PPL; ++q)
+#pragma unroll
+            for (int e = 0; e < CFG::VEC; ++e) s += to_f32(pp[q].v[e]);
+        const float mean = group8_sum(s) * inv_c;
+        opaque();
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < CFG::PPL; ++q)
+#pragma unroll
+            for (int e = 0; e < CFG::VEC; ++e) { const float d = to_f32(pp[q].v[e]) - mean; ss = __builtin_fmaf(d, d, ss); }
+        const float rstd = rsqrtf(group8_sum(ss) * inv_c + 1e-5f);
+        opaque();
+#pragma unroll
+        for (int q = 0; q < CFG::PPL; ++q) {
+            const int c0 = (sub + CFG::LPT * q) * CFG::VEC;
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < CFG::VEC; ++e)
+                o.v[e] = from_f32<T>(__builtin_fmaf((to_f32(pp[q].v[e]) - mean) * rstd, gb[c0 + e], gb[CFG::C + c0 + e]));
+            *reinterpret_cast<Vec16<T>*>(drow + c0) = o;
+        }
         return;
     }
     float x[CFG::PPL][CFG::VEC];
@@ -106,6 +156,16 @@ __device__ __forceinline__ void normalize_store(const Vec16<T> (&p)[CFG::PPL], T
         *reinterpret_cast<Vec16<T>*>(drow + c0) = o;
     }
 }
+
+// fragment pick-up under a divergent branch: the read is tied to its destination registers ("+v"), so the lanes outside the
+// branch keep their fragment without the compiler holding a second copy of the whole operand to select from.  The caller waits
+// (s_waitcnt lgkmcnt(0)): the compiler does not track this read.
+__device__ __forceinline__ void load_frag_keep(Frag<half_t>& f, const half_t* p) {
+    raw16_t r = __builtin_bit_cast(raw16_t, f.v);
+    asm volatile("ds_read_b128 %0, %1" : "+v"(r) : "v"(static_cast<unsigned>(reinterpret_cast<size_t>(p))));
+    f.v = __builtin_bit_cast(half8_t, r);
+}
+__device__ __forceinline__ void load_frag_keep(Frag<float>& f, const float* p) { load_frag(f, p); }   // (fp32 configurations have one group)
 
 template <typename CFG, typename T>
 __device__ __forceinline__ void load_token(Vec16<T> (&p)[CFG::PPL], const T* __restrict__ src, int tok, int w, int sub) {
@@ -136,8 +196,8 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NW = blockDim.x >> 6;
-    T* Bs = reinterpret_cast<T*>(smem + CFG::GB_BYTES);                               // [NW*32][RS] normalised right tokens
-    T* Wb = Bs + (size_t)wv * 32 * CFG::RS;                                           // this wave's 32 rows of it
+    T* Bs = reinterpret_cast<T*>(smem + CFG::GB_BYTES);                               // [NW*TPW][RS] normalised right tokens
+    T* Wb = Bs + (size_t)wv * CFG::TPW * CFG::RS;                                     // this wave's TPW rows of it
     TO* Wc = reinterpret_cast<TO*>(smem + CFG::GB_BYTES + (size_t)NW * CFG::WB_BYTES + (size_t)wv * CFG::WC_BYTES);
 
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -150,12 +210,12 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     const T* right = feat + ((size_t)((B + b) * h + y) * w) * CFG::C;
     TO* cvrow = cv + (size_t)row * w * w;
     const int sub = lane & 7, trow = lane >> 3;
-    const int TJ = NW * 32;                             // right pixels per chunk (the whole row when w <= TJ)
+    const int TJ = NW * CFG::TPW;                       // right pixels per chunk (the whole row when w <= TJ); a multiple of 32
     const int nchunks = (w + TJ - 1) / TJ;
     K1_T(0);
 
     // ---- everything this wave needs first is put in flight at once: 32 left tokens (+ 32 right tokens of chunk 0)
-    static_assert(!CFG::EARLY_B || CFG::RIF == 4, "EARLY_B needs all four rounds in registers");
+    static_assert(!CFG::EARLY_B || CFG::ALLRES, "EARLY_B needs every round of a chunk in registers");
     // (the LayerNorm affine goes to LDS first: __syncthreads() drains vmcnt, so no token load may be pending across it)
     for (int c = tid; c < CFG::C; c += blockDim.x) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
     __syncthreads();
@@ -171,7 +231,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         if (CFG::EARLY_B) {
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r)
-                load_token<CFG, T>(rawB[r], right, CFG::PIPE ? r * 8 * NW + wv * 8 + trow : wv * 32 + r * 8 + trow, w, sub);
+                load_token<CFG, T>(rawB[r], right, CFG::PIPE ? r * 8 * NW + wv * 8 + trow : wv * CFG::TPW + r * 8 + trow, w, sub);
         }
         // keep every request above in front of the arithmetic below: without this the scheduler sinks the right-token loads under
         // the LayerNorm of the left tokens (one full memory latency lost)
@@ -181,6 +241,8 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         // duplicates for a wave past the row end): any branch between the requests and their first use lets the optimiser sink
         // the loads into it, behind the other requests and behind the scheduling barrier above.
         {
+            // TPW-row scratch: the 32 tokens pass through it in 32 / TPW groups; the lanes whose token (lane & 31) belongs to the
+            // group pick their fragments up before the next group overwrites the rows
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
                 if (r0 > 0) {
@@ -189,14 +251,25 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                 }
 #pragma unroll
                 for (int r = 0; r < CFG::RIF; ++r)
-                    normalize_store<CFG, T>(rawA[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub, dbg);
-            }
-            __builtin_amdgcn_wave_barrier();
-            K1_T(3);
-            const T* ap = Wb + (size_t)(lane & 31) * CFG::RS + (lane >> 5) * 8;
+                    normalize_store<CFG, T>(rawA[r], Wb + (size_t)(((r0 + r) * 8 + trow) % CFG::TPW) * CFG::RS, gb, sub, dbg);
+                if ((r0 + CFG::RIF) % CFG::ROUNDS == 0) {         // a group of TPW tokens is complete
+                    const int grp = (r0 + CFG::RIF) / CFG::ROUNDS - 1;
+                    __builtin_amdgcn_wave_barrier();
+                    if (grp == 4 / CFG::ROUNDS - 1) K1_T(3);
+                    const T* ap = Wb + (size_t)((lane & 31) % CFG::TPW) * CFG::RS + (lane >> 5) * 8;
+                    if (grp == 0) {                               // every lane reads (the lanes of later groups pick up placeholders)
 #pragma unroll
-            for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
-            __builtin_amdgcn_wave_barrier();
+                        for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
+                    } else {
+                        if ((lane & 31) / CFG::TPW == grp) {
+#pragma unroll
+                            for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag_keep(afrag[kk], ap + kk * 16);
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
     }
 
@@ -271,10 +344,10 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 
     for (int c = 0; c < nchunks; ++c) {
         // right tokens of this chunk: each wave normalises its 32 into its slice, then prefetches its share of the next chunk
-        const int t0 = c * TJ + wv * 32;
+        const int t0 = c * TJ + wv * CFG::TPW;
 #pragma unroll
-        for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
-            if (!(CFG::RIF == 4 && (c > 0 || CFG::EARLY_B))) {
+        for (int r0 = 0; r0 < CFG::ROUNDS; r0 += CFG::RIF) {
+            if (!(CFG::ALLRES && (c > 0 || CFG::EARLY_B))) {
 #pragma unroll
                 for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, t0 + (r0 + r) * 8 + trow, w, sub);
             }
@@ -282,7 +355,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
             for (int r = 0; r < CFG::RIF; ++r)
                 normalize_store<CFG, T>(rawB[r], Wb + (size_t)((r0 + r) * 8 + trow) * CFG::RS, gb, sub, dbg);
         }
-        if (CFG::RIF == 4 && c + 1 < nchunks) {
+        if (CFG::ALLRES && c + 1 < nchunks) {
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, t0 + TJ + r * 8 + trow, w, sub);
         }
@@ -292,7 +365,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         if (wave_active && !(dbg & 8)) {
             const int jbase = c * TJ;
             int ntile = (w - jbase + 31) / 32;                    // 32-wide column tiles with data in this chunk
-            ntile = ntile < NW ? ntile : NW;
+            ntile = ntile < TJ / 32 ? ntile : TJ / 32;
             int npair = (ntile + 1) >> 1;
             // banded volume (band >= 0, use_positivity models): only columns j <= i + band are ever read downstream (the masked
             // Sinkhorn, the +-4 tap lookups at disparities >= 0), so this wave (rows i0 .. i0+31) stops at column i0 + 31 + band
@@ -375,7 +448,7 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
 // pipelined variant of a configuration (same tiling, PIPE = true) where it exists: all four token rounds resident in registers
 template <typename CFG> struct PipeOf { using type = void; };
 template <typename T, typename TO, int C, int NWCAP>
-struct PipeOf<LnCorrCfg<T, TO, C, NWCAP, 4, true, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, 4, true, true>; };
+struct PipeOf<LnCorrCfg<T, TO, C, NWCAP, 4, true, false, 32>> { using type = LnCorrCfg<T, TO, C, NWCAP, 4, true, true, 32>; };
 
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st) {
@@ -393,8 +466,10 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     // small problems: split rows into strips until the grid covers the chip (each strip re-normalises the right row)
     while (B * h * nstrip < 200 && nstrip < tiles && (tiles + nstrip) / (nstrip + 1) >= 2) ++nstrip;
     static const int force_nstrip = getenv("S2M2_LNCORR_NSTRIP") ? atoi(getenv("S2M2_LNCORR_NSTRIP")) : 0;   // tuning knob
-    if (force_nstrip > 0 && (tiles + force_nstrip - 1) / force_nstrip <= CFG::NWMAX) nstrip = force_nstrip;
-    const int nw = (tiles + nstrip - 1) / nstrip;
+    if (force_nstrip > 0 && ((tiles + force_nstrip - 1) / force_nstrip + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN <= CFG::NWMAX)
+        nstrip = force_nstrip;
+    int nw = (tiles + nstrip - 1) / nstrip;
+    nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;
     if constexpr (!CFG::PIPE && !std::is_void<typename PipeOf<CFG>::type>::value) {
         // measured (tools/k1_ab.py, c3 fp16): 24.2 us pipelined vs 21.3 us plain -- the extra barriers and the smaller store bursts cost
@@ -417,9 +492,9 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
 template <typename T, int C> struct LnCorrPick;
 template <> struct LnCorrPick<half_t, 64>  { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 64, 12, 4, true>; };
 template <> struct LnCorrPick<half_t, 128> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 128, 11, 4, true>; };
-template <> struct LnCorrPick<half_t, 192> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 192, 8, 4, false>; };
-template <> struct LnCorrPick<half_t, 256> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 256, 8, 2, false>; };
-template <> struct LnCorrPick<half_t, 384> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 384, 4, 2, false>; };
+template <> struct LnCorrPick<half_t, 192> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 192, 10, 2, true, false, 16>; };
+template <> struct LnCorrPick<half_t, 256> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 256, 10, 2, true, false, 16>; };
+template <> struct LnCorrPick<half_t, 384> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 384, 8, 2, true, false, 16>; };
 template <> struct LnCorrPick<float, 64>   { template <typename TO> using cfg = LnCorrCfg<float, TO, 64, 12, 4, true>; };
 template <> struct LnCorrPick<float, 128>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 128, 8, 4, false>; };
 template <> struct LnCorrPick<float, 192>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 192, 8, 2, false>; };

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
         const int imax = i0 + wv * RPW + RPW - 1;
         return (!use_pos || imax >= w) ? NCH : min(NCH, imax / CW + 1);
     };
-    int* flag = reinterpret_cast<int*>(pz + NWV * ns);     // fast column sweep lost a column (underflow): redo the pass exactly
+    // fast column sweep lost a column (underflow): redo the pass exactly.  Three flags used in turn: pass p raises flags[p % 3] and
+    // clears flags[(p + 1) % 3] for its successor, so a wave still reading the flag of pass p - 1 never sees it reset
+    int* flags = reinterpret_cast<int*>(pz + NWV * ns);
+    if (tid < 3) flags[tid] = 0;                           // (ordered before the first use by the barriers of pass 0)
 
     // ---- exact column sweep: v_j = log nu_j - LSE_i(S_ij + u_i) with lazy-maximum accumulators (pass 0, where u = 0, and the
     // fallback of the fast sweep below)
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
         for (int c = 0; c < NE; ++c) zc[c] = 0.f;
         const float vbin = v[w];
-        if (tid == 0) *flag = 0;
+        int* flag = flags + pass % 3;
+        if (tid == 0) flags[(pass + 1) % 3] = 0;
         raw16_t rcur[NCH][PPC], rnext[NCH][PPC];
 #pragma unroll
         for (int c = 0; c < NCH; ++c)

@@ -93,6 +93,7 @@ class Engine:
         self._fusion_ok: Dict[int, bool] = {}
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
         self.use_frag = os.environ.get("S2M2_CONV_FRAG", "1") != "0"     # A/B switch: 0 = spatial layers on the v3 halo tiles (K order 0)
+        self.frag_aux = os.environ.get("S2M2_FRAG_AUX", "0") == "1"      # opt-in: one-operand-epilogue layers on v5 too (measured 1 % slower end to end)
         # opt-in: banded cost volume (columns j <= i + 11) for use_positivity models.  Off by default: the reference's DispInit hands
         # out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward (measured: profiles/r02/kbench.txt)
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
@@ -107,8 +108,8 @@ class Engine:
     # ---- weight packing (once per engine) ------------------------------------------------------------
     def std(self, name: str, splits: Optional[Sequence[Tuple[int, int]]] = None, transposed: bool = False, frag: bool = True) -> Spec:
         """One nn.Conv2d / nn.Linear (or stride-1 nn.ConvTranspose2d when ``transposed``) as a K5 weight.  frag=False: the layer is
-        launched with a stride or with an aux-tensor epilogue (measured slower on the fragment-stream kernel: its 4-wave blocks expose the
-        aux latency, profiles/r02/frag_timeline.txt), keep K order 0."""
+        launched with a stride or with a two-operand epilogue (GRU blend: its operands do not fit the fragment-stream kernel's
+        register budget), keep K order 0."""
         key = (name, tuple(splits) if splits else None, transposed)
         s = self._packed.get(key)
         if s is None:
@@ -227,7 +228,7 @@ class Engine:
                 b = self.cconv(c2, [u])
         t = self.cconv(self.std(p + ".convs.0"), [z], act=hip.ACT_GELU)
         self.join(b, u)
-        return self.cconv(self.std(p + ".convs.2", frag=False), [t], epi=hip.EPI_ADD, aux0=b)
+        return self.cconv(self.std(p + ".convs.2", frag=self.frag_aux), [t], epi=hip.EPI_ADD, aux0=b)
 
     def dual_heads(self, p: str):
         """[gate.2 | fusion.2] stacked along K (the channel order of the hidden tensor) + the two biases"""
@@ -387,7 +388,7 @@ class Engine:
         for sfx in ("1", "2"):
             with self.fork():
                 z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
-            rh = self.cconv(self.std(f"{p}.convr{sfx}", frag=False), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
+            rh = self.cconv(self.std(f"{p}.convr{sfx}", frag=self.frag_aux), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
             self.join(z)
             h = self.cconv(self.std(f"{p}.convq{sfx}", frag=False), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
@@ -461,7 +462,7 @@ class Engine:
         f2 = self.cconv(self.std(p + ".conv1_down.2"), [t])
         f2 = hip.groupnorm_nhwc(f2, 8, self.p[p + ".norm1.weight"], self.p[p + ".norm1.bias"])
         t = self.cconv(self.std(p + ".conv2.0"), [f2], act=hip.ACT_GELU)
-        f2 = self.cconv(self.std(p + ".conv2.2", frag=False), [t], epi=hip.EPI_ADD, aux0=f2)
+        f2 = self.cconv(self.std(p + ".conv2.2", frag=self.frag_aux), [t], epi=hip.EPI_ADD, aux0=f2)
         f4 = self.cconv(self.std(p + ".conv2_down.0", frag=False), [f2], stride=2)
         py = self.unet("feat_pyramid", f4)
         z = py

@@ -105,11 +105,12 @@ def test_conv_vs_torch(hip, case, dtype):
 FRAG_CASES = [
     # N, H, W, [src channels], Cout, KH, KW, act, epi      (K order 2: weights as an MFMA fragment stream, conv_frag_kernel)
     (1, 17, 23, [128], 128, 3, 3, 1, 0),                   # ragged patch rows / columns
-    (2, 19, 70, [128, 128], 128, 1, 3, 4, 3),              # GRU pass (1x3) with two sources, two channel chunks, tanh + GRU epilogue
+    (2, 19, 70, [128, 128], 128, 1, 3, 4, 2),              # GRU pass (1x3) with two sources, two channel chunks, tanh * aux
     (1, 33, 19, [128, 128], 128, 3, 1, 3, 2),              # GRU pass (3x1), sigmoid * aux
     (1, 12, 20, [256], 256, 3, 3, 2, 1),                   # two cout blocks, residual add
     (1, 21, 37, [96, 64, 32], 384, 3, 3, 1, 0),            # Cin = 192: a source boundary inside a chunk, half-empty last chunk
     (1, 64, 76, [128], 128, 3, 3, 0, 0),                   # several patches per row, exact tiling
+    (2, 37, 45, [128], 256, 3, 3, 0, 1),                   # residual add without activation (ConvBlock2D's last conv), ragged, 2 cout blocks
     (1, 8, 40, [128, 128, 64, 64], 128, 3, 3, 1, 0),       # four sources, three chunks
 ]
 
@@ -154,6 +155,9 @@ def test_conv_frag_argument_checks(hip):
     x32 = x.float()
     with pytest.raises((RuntimeError, ValueError)):
         hip.conv2d([x32], w.float(), None, 3, 3, 128, korder=2)
+    a = torch.zeros(1, 8, 8, 128, device="cuda", dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="one-operand"):            # two-operand epilogues stay on the v3 tiles
+        hip.conv2d([x], w, None, 3, 3, 128, korder=2, epi=3, aux0=a, aux1=a)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])

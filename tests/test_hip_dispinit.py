@@ -170,8 +170,9 @@ def test_ln_corr_banded_equals_full_inside_the_band(hip, shape, dtype):
     inside = (j <= i + 11).expand(B, h, w, w)
     assert torch.equal(out[inside], full[inside])
     written = out != sentinel
-    # store granule: 64 columns x the 32 rows of a wave -> nothing beyond column (i | 31) + 11 rounded up to the next multiple of 64
-    limit = (((i | 31) + 11) // 64 + 1) * 64
+    # store granule: 64 columns (counted from the chunk's first column) x the 32 rows of a wave -> nothing is written 64 or more
+    # columns beyond the last column (i | 31) + 11 that the wave's rows need
+    limit = (i | 31) + 11 + 64
     assert not bool((written & (j >= limit).expand(B, h, w, w)).any())
     if w >= 256:
         assert float(written.float().mean()) < 0.75          # a real saving on wide rows
@@ -195,3 +196,16 @@ def test_forward_with_banded_cost_volume_is_bit_identical(monkeypatch):
         assert (m.engine(torch.float16).cv_band == 11) == (band == "1")
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,dtype,pos", [((1, 24, 160, 160), torch.float16, True), ((1, 8, 304, 304), torch.float16, False),
+                                             ((2, 6, 72, 72), torch.float32, True)])
+def test_sinkhorn_is_run_to_run_deterministic(hip, shape, dtype, pos):
+    """K2 keeps u, v, the column partials and the fallback flags in LDS across passes: 40 runs on the same volume must agree bit for
+    bit (tools/k2_determinism.py runs the longer version)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cv = (torch.randn(*shape, device="cuda", generator=g) * 8).to(dtype)
+    ref = [t.clone() for t in hip.sinkhorn_regress(cv, pos, 3, want_argmax=True)]
+    for _ in range(40):
+        out = hip.sinkhorn_regress(cv, pos, 3, want_argmax=True)
+        assert all(torch.equal(a, b) for a, b in zip(ref, out))
