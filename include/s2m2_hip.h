@@ -266,6 +266,8 @@ int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int C, long lon
  *                       of an NHWC tensor with pixel stride upd_stride
  *   s2m2_refine_update  in place: disp += dco[0]; conf = sigmoid(dco[8] + logit(conf, .01)); occ likewise with dco[9]
  *                       (refinenet.py:149-151); then clamp disp at 0 if use_positivity and occ *= (x - disp >= 0) (s2m2.py:177-180)
+ *   s2m2_refine_update_to  the same out of place (outputs may alias the inputs); small8_next != NULL also receives the mode-1
+ *                       side input of the next refinement iteration (= s2m2_refine_prep of the values just written, bit for bit)
  *   s2m2_tanh           y = tanh(x) on n elements (hidden = tanh(ctx), s2m2.py:166)
  *   s2m2_stem_mlp       the two 1x1 layers at the head of CNNEncoder on full-resolution pixels (submodules.py:68-71: conv0 =
  *                       Conv2d(3,16,1) - GELU - Conv2d(16,16,1)): x8 (npix,8) -> out (npix,16) = W1.gelu(W0.x + b0) + b1;
@@ -278,6 +280,9 @@ int s2m2_global_update(const void* upd, int upd_stride, const float* disp, const
                        int dtype, void* stream);
 int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf, float* occ, long long npix, int w, int use_positivity,
                        int dtype, void* stream);
+int s2m2_refine_update_to(const void* dco, int dco_stride, const float* disp, const float* conf, const float* occ, float* disp_out,
+                          float* conf_out, float* occ_out, void* small8_next, long long npix, int w, int use_positivity, int dtype,
+                          void* stream);
 int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream);
 int s2m2_stem_mlp(const void* x8, const float* w0, const float* b0, const float* w1, const float* b1, void* out, long long npix, int dtype,
                   void* stream);

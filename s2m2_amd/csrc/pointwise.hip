@@ -73,10 +73,13 @@ __global__ __launch_bounds__(256) void global_update_kernel(const T* __restrict_
     out[gid] = d;
 }
 
-// dco: (.., stride) with channel 0 = disparity delta, channels 8, 9 = confidence / occlusion logit deltas
+// dco: (.., stride) with channel 0 = disparity delta, channels 8, 9 = confidence / occlusion logit deltas.  Out of place (the outputs
+// may alias the inputs: every thread reads its own pixel before it writes it); small_next != nullptr: also the mode-1 side input
+// of the NEXT refinement iteration (what refine_prep_kernel would compute from the values just written).
 template <typename T>
-__global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict__ dco, int stride, float* __restrict__ disp,
-                                                            float* __restrict__ conf, float* __restrict__ occ, long long n, int w, int use_pos) {
+__global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict__ dco, int stride, const float* disp, const float* conf,
+                                                            const float* occ, float* disp_out, float* conf_out, float* occ_out,
+                                                            T* __restrict__ small_next, long long n, int w, int use_pos) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= n) return;
     const T* r = dco + gid * stride;
@@ -86,7 +89,16 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
     if (use_pos) d = fmaxf(d, 0.f);
     const float x = (float)(gid % w);
     o = (x - d >= 0.f) ? o : 0.f;
-    disp[gid] = d; conf[gid] = c; occ[gid] = o;
+    disp_out[gid] = d; conf_out[gid] = c; occ_out[gid] = o;
+    if (small_next) {
+        alignas(16) T s8[8];
+        s8[0] = from_f32<T>(d / 1e2f); s8[1] = from_f32<T>(logit_eps(c, 1e-2f)); s8[2] = from_f32<T>(logit_eps(o, 1e-2f));
+#pragma unroll
+        for (int k = 3; k < 8; ++k) s8[k] = from_f32<T>(0.f);
+        T* dst = small_next + gid * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = s8[k];
+    }
 }
 
 template <typename T>
@@ -145,15 +157,26 @@ extern "C" int s2m2_global_update(const void* upd, int upd_stride, const float* 
     return check_launch("global_update");
 }
 
-extern "C" int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf, float* occ, long long npix, int w,
-                                  int use_positivity, int dtype, void* stream) {
+extern "C" int s2m2_refine_update_to(const void* dco, int dco_stride, const float* disp, const float* conf, const float* occ,
+                                     float* disp_out, float* conf_out, float* occ_out, void* small8_next, long long npix, int w,
+                                     int use_positivity, int dtype, void* stream) {
     using namespace s2m2;
-    S2M2_REQUIRE(dco && disp && conf && occ && npix > 0 && w > 0 && dco_stride >= 10, "refine_update: bad arguments");
+    S2M2_REQUIRE(dco && disp && conf && occ && disp_out && conf_out && occ_out && npix > 0 && w > 0 && dco_stride >= 10,
+                 "refine_update: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == S2M2_F16) hipLaunchKernelGGL((refine_update_kernel<half_t>), grid1(npix), dim3(256), 0, st, (const half_t*)dco, dco_stride, disp, conf, occ, npix, w, use_positivity);
-    else if (dtype == S2M2_F32) hipLaunchKernelGGL((refine_update_kernel<float>), grid1(npix), dim3(256), 0, st, (const float*)dco, dco_stride, disp, conf, occ, npix, w, use_positivity);
+    if (dtype == S2M2_F16)
+        hipLaunchKernelGGL((refine_update_kernel<half_t>), grid1(npix), dim3(256), 0, st, (const half_t*)dco, dco_stride, disp, conf, occ,
+                           disp_out, conf_out, occ_out, (half_t*)small8_next, npix, w, use_positivity);
+    else if (dtype == S2M2_F32)
+        hipLaunchKernelGGL((refine_update_kernel<float>), grid1(npix), dim3(256), 0, st, (const float*)dco, dco_stride, disp, conf, occ,
+                           disp_out, conf_out, occ_out, (float*)small8_next, npix, w, use_positivity);
     else return set_error("refine_update: unsupported dtype %d", dtype);
     return check_launch("refine_update");
+}
+
+extern "C" int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf, float* occ, long long npix, int w,
+                                  int use_positivity, int dtype, void* stream) {
+    return s2m2_refine_update_to(dco, dco_stride, disp, conf, occ, disp, conf, occ, nullptr, npix, w, use_positivity, dtype, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -23,6 +23,7 @@
 // exceeds it by more than 40 (checked once per 8 elements with a wave vote), otherwise an element costs a subtract, an exp and an
 // add -- the exact sum of exp(x - m) for a fixed m, just not the tightest m.
 #include "common.h"
+#include <stdlib.h>
 
 namespace s2m2 {
 
@@ -362,6 +363,8 @@ static int dispatch_ppl(const void* cv, float* disp, float* conf, float* occ, in
         if (nch <= 2) return launch_sinkhorn<TI, GL, 2>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
         if (nch <= 3) return launch_sinkhorn<TI, GL, 3>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
     }
+    // (measured at w = 304: 32 lanes per row x 16 waves, 91.7 us, is no faster than 16 lanes x 8 waves, 90.4 us -- the row chain, not
+    // the number of resident waves, sets the pace)
     if (w <= 384) S2M2_K2(16)
     if (w <= 768) S2M2_K2(32)
     if (w <= 1536) S2M2_K2(64)

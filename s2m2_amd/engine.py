@@ -393,8 +393,10 @@ class Engine:
             h = self.cconv(self.std(f"{p}.convq{sfx}", frag=False), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
 
-    def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it):
-        """LocalRefiner.forward (refinenet.py:126-154) + the loop epilogue of s2m2.py:177-180 (clamp, occlusion mask)."""
+    def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it,
+                      small: Optional[Tensor] = None, want_small: bool = False):
+        """LocalRefiner.forward (refinenet.py:126-154) + the loop epilogue of s2m2.py:177-180 (clamp, occlusion mask).  small: the
+        (disp, conf, occ) side input if the previous iteration's epilogue already produced it; want_small: produce the next one."""
         B, _, h, w = disp.shape
         C = self.C
         corr = self.zeros("lr_corr", (B, h, w, 32))
@@ -407,7 +409,8 @@ class Engine:
         cf = self.cconv(self.merged(p + "|corrA", [(p + ".corr_feat1.0", 0, 1 / 16, False), (p + ".corr_feat2.0", 16, 1 / 16, False)], 32),
                         [corr], act=hip.ACT_GELU)
         f12 = self.cconv(self.merged(p + "|corrB", [(p + ".corr_feat1.2", 0, 1.0, False), (p + ".corr_feat2.2", 96, 1.0, False)], 192), [cf])
-        small = hip.refine_prep(disp, conf, occ, 1, self.dtype)
+        if small is None:
+            small = hip.refine_prep(disp, conf, occ, 1, self.dtype)
         dc = self.cconv(self.merged(p + "|dcA", [(p + ".disp_feat.0", 0, 1.0, False), (p + ".conf_occ_feat.0", 1, 1.0, False)], 8),
                         [small], act=hip.ACT_GELU)
         fd = self.cconv(self.std(p + ".disp_feat.2"), [dc[..., :96]])
@@ -420,7 +423,7 @@ class Engine:
                        [hn], act=hip.ACT_GELU)
         dco = self.cconv(self.merged(p + "|updB", [(p + ".disp_update.2", 0, 1.0, False), (p + ".conf_occ_update.2", C, 1.0, False)], 2 * C),
                          [u])
-        return (hn,) + hip.refine_update(dco, disp, conf, occ, self.use_positivity)
+        return (hn,) + tuple(hip.refine_update(dco, disp, conf, occ, self.use_positivity, want_small=want_small))
 
     # ---- upsampling masks ----------------------------------------------------------------------------
     def mask4x(self, p: str, hidden: Tensor, f2x: Tensor) -> Tensor:
@@ -504,8 +507,12 @@ class Engine:
         hidden = hip.tanh(ctx)
         if cap is not None:
             cap["ctx"] = ctx.permute(0, 3, 1, 2)
+        small = None
         for it in range(self.refine_iter):
-            hidden, disp, conf, occ = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, cap, it)
+            more = it + 1 < self.refine_iter                       # the epilogue also writes the next iteration's side input
+            res = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, cap, it, small=small, want_small=more)
+            hidden, disp, conf, occ = res[:4]
+            small = res[4] if more else None
             if cap is not None:
                 cap[f"disp_it{it}"], cap[f"conf_it{it}"], cap[f"occ_it{it}"] = disp, conf, occ
         m4 = self.mask4x("upsample_mask_4x_refine", hidden, f2_left)
@@ -586,6 +593,10 @@ class GraphRunner:
             self.ga.replay()
             eng.cost_volume(self.state[0], out=self.cv)                # eager between the two graphs: carries the timing events
             self.gb.replay()
+        base = self.out[0]._base                                   # the three maps are slices of one allocation (hip.convex_upsample)
+        if base is not None and all(o._base is base for o in self.out):
+            b = base.clone()                                       # one copy out of the graph's static output buffer
+            return tuple(b[k] for k in range(len(self.out)))
         return tuple(o.clone() for o in self.out)
 
 

@@ -69,6 +69,7 @@ SIGNATURES = {
     "s2m2_refine_prep": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_global_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_refine_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "s2m2_refine_update_to": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "s2m2_tanh": (_i, [_vp, _vp, _ll, _i, _vp]),
     "s2m2_stem_mlp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
     "s2m2_image_pad": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -407,7 +408,8 @@ def convex_upsample(maps, logits: torch.Tensor, factor: int, scales=None, logit_
     exp_l = (B, hs, ws) if logit_up2 else (B, Ho, Wo)
     if tuple(logits.shape[:3]) != exp_l:
         raise ValueError(f"convex_upsample: logits must be {exp_l + ('>=16',)}, got {tuple(logits.shape)}")
-    outs = [torch.empty((B, 1, Ho, Wo), device=logits.device, dtype=torch.float32) for _ in range(n)]
+    base = torch.empty((n, B, 1, Ho, Wo), device=logits.device, dtype=torch.float32)      # one allocation: callers can copy all maps at once
+    outs = [base[k] for k in range(n)]
     xp = (_vp * n)(*[m.data_ptr() for m in maps])
     op = (_vp * n)(*[o.data_ptr() for o in outs])
     sc = (ctypes.c_float * n)(*[float(v) for v in (scales or [1.0] * n)])
@@ -511,12 +513,18 @@ def global_update(upd: torch.Tensor, disp: torch.Tensor, conf: torch.Tensor, cla
     return out
 
 
-def refine_update(dco: torch.Tensor, disp: torch.Tensor, conf: torch.Tensor, occ: torch.Tensor, use_positivity: bool):
-    """dco (B,h,w,>=10) NHWC deltas; disp/conf/occ (B,1,h,w) fp32 -> new (disp, conf, occ) (fresh tensors)."""
-    disp, conf, occ = disp.clone(), conf.clone(), occ.clone()
-    _check(load().s2m2_refine_update(dco.data_ptr(), _nhwc(dco), disp.data_ptr(), conf.data_ptr(), occ.data_ptr(), disp.numel(),
-                                     disp.shape[-1], int(use_positivity), _DT[dco.dtype], _stream()), "s2m2_refine_update")
-    return disp, conf, occ
+def refine_update(dco: torch.Tensor, disp: torch.Tensor, conf: torch.Tensor, occ: torch.Tensor, use_positivity: bool,
+                  want_small: bool = False):
+    """dco (B,h,w,>=10) NHWC deltas; disp/conf/occ (B,1,h,w) fp32 -> new (disp, conf, occ) (fresh tensors) [, small (B,h,w,8): the
+    refine_prep(mode 1) side input of the next iteration, from the same launch]."""
+    _dev(disp, conf, occ)
+    outs = torch.empty((3,) + tuple(disp.shape), device=disp.device, dtype=torch.float32)
+    small = torch.empty((disp.shape[0], disp.shape[-2], disp.shape[-1], 8), device=disp.device, dtype=dco.dtype) if want_small else None
+    _check(load().s2m2_refine_update_to(dco.data_ptr(), _nhwc(dco), disp.data_ptr(), conf.data_ptr(), occ.data_ptr(),
+                                        outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+                                        small.data_ptr() if small is not None else None, disp.numel(), disp.shape[-1],
+                                        int(use_positivity), _DT[dco.dtype], _stream()), "s2m2_refine_update_to")
+    return (outs[0], outs[1], outs[2], small) if want_small else (outs[0], outs[1], outs[2])
 
 
 def tanh(x: torch.Tensor) -> torch.Tensor:

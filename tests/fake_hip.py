@@ -168,7 +168,8 @@ def make():
         d = mask * disp + (1 - mask) * (upd[..., 0].float().unsqueeze(1) * 1e2)
         return d.clamp(min=0) if clamp0 else d
 
-    def refine_update(dco, disp, conf, occ, use_positivity):
+    def refine_update(dco, disp, conf, occ, use_positivity, want_small=False):
+        dt = dco.dtype
         dco = dco.float()
         d = disp + dco[..., 0].unsqueeze(1)
         c = torch.sigmoid(dco[..., 8].unsqueeze(1) + torch.logit(conf, eps=1e-2))
@@ -176,7 +177,8 @@ def make():
         if use_positivity:
             d = d.clamp(min=0)
         xs = torch.arange(d.shape[-1], dtype=torch.float32).reshape(1, 1, 1, -1)
-        return d, c, o * (xs - d >= 0)
+        o = o * (xs - d >= 0)
+        return (d, c, o, refine_prep(d, c, o, 1, dt)) if want_small else (d, c, o)
 
     def tanh(x):
         return torch.tanh(x)

@@ -133,5 +133,15 @@ def test_refiner_pointwise_stages(hip, dtype):
     ro = torch.sigmoid(dco[..., 9].float().unsqueeze(1) + torch.logit(occ, eps=1e-2))
     ro = ro * (torch.arange(w, device="cuda").float().reshape(1, 1, 1, w) - rd >= 0)
     assert float((d2 - rd).abs().max()) < 1e-5 and float((c2 - rc).abs().max()) < 1e-5 and float((o2 - ro).abs().max()) < 1e-5
+    # the same launch can also write the next iteration's side input: bit-identical to refine_prep of its own outputs, and the
+    # in-place C entry (s2m2_refine_update) is the same kernel with the outputs aliased to the inputs
+    d3, c3, o3, small = hip.refine_update(dco, disp, conf, occ, True, want_small=True)
+    assert torch.equal(d3, d2) and torch.equal(c3, c2) and torch.equal(o3, o2)
+    assert torch.equal(small, hip.refine_prep(d2, c2, o2, 1, dtype))
+    di, ci, oi = disp.clone(), conf.clone(), occ.clone()
+    rc_ = hip.load().s2m2_refine_update(dco.data_ptr(), 16, di.data_ptr(), ci.data_ptr(), oi.data_ptr(), di.numel(), w, 1,
+                                        0 if dtype == torch.float32 else 1, None)
+    torch.cuda.synchronize()
+    assert rc_ == 0 and torch.equal(di, d2) and torch.equal(ci, c2) and torch.equal(oi, o2)
     x = torch.randn(3, 5, 7, 128, device="cuda", generator=g).to(dtype)
     assert float((hip.tanh(x).float() - torch.tanh(x.float())).abs().max()) < (1e-6 if dtype == torch.float32 else 1e-3)
