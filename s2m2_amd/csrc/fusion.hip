@@ -303,7 +303,10 @@ extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, lo
     // measured end to end (same-box A/B): 32-row tiles (the 64-row tile of C = 128 needs 234 VGPRs for its three accumulator sets
     // and runs one block per CU); 128-byte K chunks (half the barriers of 64-byte chunks, +1.3 %) wherever the tile still fits
     static const bool narrow = getenv("S2M2_FUSION_CHUNK64") != nullptr;   // A/B switch
+    static const int big = getenv("S2M2_FUSION_BM") ? atoi(getenv("S2M2_FUSION_BM")) : 0;   // experiment: 64- / 128-row tiles at C = 128
     if (dtype == S2M2_F16) {
+        if (C == 128 && big == 128 && rows >= 32768) return launch_fusion<half_t, 128, 128, 4, 8>(a, st);
+        if (C == 128 && big == 64 && rows >= 32768) return launch_fusion<half_t, 128, 64, 4, 8>(a, st);
         if (C == 128) return narrow ? launch_fusion<half_t, 128, 32, 4>(a, st) : launch_fusion<half_t, 128, 32, 4, 8>(a, st);
         if (rows > 8192) return launch_fusion<half_t, 256, 64, 8>(a, st);   // bulk rows: 64-row tiles (weights streamed once per 64 rows)
         return narrow ? launch_fusion<half_t, 256, 32, 8>(a, st) : launch_fusion<half_t, 256, 32, 8, 8>(a, st);
