@@ -39,6 +39,9 @@ __device__ __forceinline__ float fast_gelu(float x) {
     return __builtin_fmaf(-ax, q, fmaxf(x, 0.f));
 }
 template <int ACT> __device__ __forceinline__ float activate(float x) {
+#if defined(S2M2_GELU_ERF_FORM)                                  // A/B build: the round-1 form 0.5 x (1 + erf(x / sqrt 2))
+    if (ACT == S2M2_ACT_GELU) return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
+#endif
     if (ACT == S2M2_ACT_GELU) return fast_gelu(x);
     if (ACT == S2M2_ACT_RELU) return fmaxf(x, 0.f);
     if (ACT == S2M2_ACT_SIGMOID) return fast_rcp(1.0f + fast_exp(-x));

@@ -13,7 +13,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 for f in ("bench_N1.json", "bench_N1_banded.json", "kbench.txt", "convbench_3x3_cold.txt", "attnbench.txt", "k1_timeline.txt",
-          "frag_timeline.txt", "layer_ab_frag.txt", "layer_trace_eager.txt", "parity_c1_c3_c2.txt", "configs_all_models.txt"):
+          "frag_timeline.txt", "fusionbench.txt", "layer_ab_frag.txt", "layer_trace_eager.txt", "parity_c1_c3_c2.txt", "configs_all_models.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 copies = {"prof_bench/bench_kernel_stats.csv": "bench_c3_S_fp16_kernel_stats.csv", "prof_k1_c3/k1_kernel_stats.csv": "k1_only_c3_kernel_stats.csv",

@@ -25,6 +25,7 @@ cd $R
 timeout 600 python tools/kbench.py --iters 30 2>&1 | grep -v amdgpu.ids > $OUT/kbench.txt
 timeout 600 python tools/convbench.py --cold --only 3x --tiles 26,24 2>&1 | grep -v amdgpu.ids > $OUT/convbench_3x3_cold.txt
 timeout 300 python tools/attnbench.py 2>&1 | grep -v amdgpu.ids > $OUT/attnbench.txt
+timeout 200 python tools/fusionbench.py 2>&1 | grep -v amdgpu.ids > $OUT/fusionbench.txt
 S2M2_LIB_SUFFIX=_k1trace timeout 120 python tools/k1_trace.py c3 2>&1 | grep -v amdgpu.ids > $OUT/k1_timeline.txt
 S2M2_LIB_SUFFIX=_fragtrace timeout 120 python tools/frag_trace.py 2>&1 | grep -v amdgpu.ids > $OUT/frag_timeline.txt
 timeout 300 python tools/layer_trace.py --ab S2M2_CONV_FRAG=0,1 --iters 5 2>&1 | grep -v amdgpu.ids > $OUT/layer_ab_frag.txt

@@ -45,10 +45,8 @@ def child(cases, dtypes):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
         return child(sys.argv[2].split(","), sys.argv[3].split(","))
-    variants = [("barrier (r01)", {"S2M2_LNCORR_FLAGS": "0"})]
-    for direct in (0, 1):
-        for st in (0, 16, 32, 48):
-            variants.append((f"flags direct={direct} stagger={st}", {"S2M2_LNCORR_STAGGER": str(st), "S2M2_LNCORR_DIRECT": str(direct)}))
+    variants = [("one block per row (default)", {}),
+                ("two half-row blocks per row (S2M2_LNCORR_NSTRIP=2: 5 waves, 66 KB of LDS each)", {"S2M2_LNCORR_NSTRIP": "2"})]
     cases = sys.argv[1] if len(sys.argv) > 1 else "c2,c3,c3B4"
     dtypes = sys.argv[2] if len(sys.argv) > 2 else "fp16,fp32"
     for name, env in variants:
