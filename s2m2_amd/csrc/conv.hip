@@ -1066,14 +1066,15 @@ __device__ unsigned long long g_frag_trace[4096 * 4 * 8];
 #define FRAG_T(slot)
 #endif
 
-template <typename T, int BN_, int CH_>
+template <typename T, int BN_, int CH_, int PH_ = 4>
 struct ConvCfgF {
     static_assert(sizeof(T) == 2, "the fragment-stream kernel is fp16 only");
-    static constexpr int BM = 128, BN = BN_, PH = 4, PW = 32, WGM = 1, WGN = BN_ / 32;
+    // PH: patch rows (4: 128 pixels per block; 2: 64 pixels -- twice the blocks on the coarse pyramid levels, whose grids do not fill the chip)
+    static constexpr int BM = 32 * PH_, BN = BN_, PH = PH_, PW = 32, WGM = 1, WGN = BN_ / 32;
     static constexpr int NWAVES = WGN, NT = 64 * NWAVES;
     static constexpr int VEC = 8, CH = CH_, KS = CH_ / 16;       // channels per chunk, k16 steps per tap
     static constexpr int RS = CH + VEC;                  // LDS row stride (elements): 16 bytes of padding per halo pixel
-    static constexpr int WM = BM, WN = 32, MT = 4, NTL = 1;
+    static constexpr int WM = BM, WN = 32, MT = PH_, NTL = 1;
     static constexpr int MAXHALO = (PH + 2) * (PW + 2);
     static constexpr int PPX = CH / VEC;                 // 16-byte pieces per halo pixel
     static constexpr int RPI = NT / PPX;                 // halo pixels covered by one pass of the loader threads
@@ -1451,12 +1452,12 @@ static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
-template <typename T, int BN, int CH>
+template <typename T, int BN, int CH, int PH = 4>
 static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) != 2) {
         return set_error("conv2d: K order 2 (fragment stream) is an fp16 layout");
     } else {
-        using CFG = ConvCfgF<T, BN, CH>;
+        using CFG = ConvCfgF<T, BN, CH, PH>;
         const bool with_aux = a.epi != S2M2_EPI_NONE;            // epilogue operands: the variant that requests them under its last tap
         auto kern = with_aux ? conv_frag_kernel<CFG, T, true> : conv_frag_kernel<CFG, T, false>;
         static bool attr_done_dev[kMaxDevices][2] = {};
@@ -1507,7 +1508,17 @@ template <typename T>
 static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
     const long long M = (long long)a.N * a.Ho * a.Wo;
     const bool auto_tile = tile == 0;
-    if (a.korder == 2) return launch_conv_frag<T, 128, 128>(a, st);   // weights packed as a fragment stream: one kernel takes them
+    if (a.korder == 2) {                                          // weights packed as a fragment stream: one kernel takes them
+        // 64-pixel blocks where 128-pixel blocks would leave most of the 256 CUs without one (tile: 2 / 4 force the patch height)
+        static const int force_ph = getenv("S2M2_FRAG_PH") ? atoi(getenv("S2M2_FRAG_PH")) : 0;   // A/B switch
+        const long long blocks4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.Cout / 128);
+        const int ph = tile == 2 || tile == 4 ? tile : (force_ph == 2 || force_ph == 4) ? force_ph : (blocks4 <= 256 ? 2 : 4);
+        if constexpr (sizeof(T) == 2) {
+            return ph == 2 ? launch_conv_frag<T, 128, 128, 2>(a, st) : launch_conv_frag<T, 128, 128, 4>(a, st);
+        } else {
+            return launch_conv_frag<T, 128, 128, 4>(a, st);      // (reports the dtype error)
+        }
+    }
     static const long long t20_min = getenv("S2M2_T20_MIN") ? atoll(getenv("S2M2_T20_MIN")) : 300;   // tuning only
     static const int small_tile = getenv("S2M2_SMALL_TILE") ? atoi(getenv("S2M2_SMALL_TILE")) : 0;
     if (tile == 0) {                                              // measured on MI355X (tools/convbench.py, profiles/r01)

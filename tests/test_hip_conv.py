@@ -115,8 +115,9 @@ FRAG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("ph", [4, 2])            # patch height: 128- / 64-pixel blocks (the dispatcher picks by grid size)
 @pytest.mark.parametrize("case", FRAG_CASES)
-def test_conv_frag_stream(hip, case):
+def test_conv_frag_stream(hip, case, ph):
     N, H, W, cs, Cout, KH, KW, act, epi = case
     dtype = torch.float16
     g = torch.Generator(device="cuda").manual_seed(100 + FRAG_CASES.index(case))
@@ -136,7 +137,7 @@ def test_conv_frag_stream(hip, case):
         ref = (1 - a0.float()) * a1.float() + a0.float() * ref.half().float()
     wf = pack.pack_conv_frag(w, dtype, [(c, c) for c in cs])
     bp = pack.pack_bias(b, Cout)
-    out = hip.conv2d(srcs, wf, bp, KH, KW, Cout, act=act, epi=epi, aux0=a0, aux1=a1, korder=2)
+    out = hip.conv2d(srcs, wf, bp, KH, KW, Cout, act=act, epi=epi, aux0=a0, aux1=a1, korder=2, tile=ph)
     # same layer through the v3 halo tile (K order 0): both must agree with the reference, and with each other to fp16 rounding
     w0 = pack.pack_conv(w, dtype, [(c, c) for c in cs])
     out0 = hip.conv2d(srcs, w0, bp, KH, KW, Cout, act=act, epi=epi, aux0=a0, aux1=a1)
