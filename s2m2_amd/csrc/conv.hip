@@ -1087,7 +1087,8 @@ struct ConvCfgF {
     static_assert(NT % PPX == 0 && KS >= 2 && KS % 2 == 0, "loader geometry");
 };
 
-template <typename CFG, typename T, bool AUX>
+// AUX: epilogue operands parked in registers through the K loop: 0 none (epi == NONE), 1 one (add / mul), 2 two (GRU blend, gate mix)
+template <typename CFG, typename T, int AUX>
 __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tiles_x, int tiles_y) {
     constexpr int BN = CFG::BN, VEC = CFG::VEC, RS = CFG::RS, CH = CFG::CH, KS = CFG::KS, PH = CFG::PH, PW = CFG::PW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1173,9 +1174,9 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     // their latency runs beside the halo tile's.  (Requested after the K loop, 8 pieces per thread sat in front of the stores:
     // +3.5 us per block, profiles/r02/frag_timeline.txt.)
     const PatchPix pix{n, y0, x0, p.H, p.W};
-    using AX = AuxRegs<CFG, T, AUX ? 8 : 4>;
+    using AX = AuxRegs<CFG, T, AUX != 0 ? 8 : 4>;
     AX aux;
-    if constexpr (AUX) aux.template prefetch<true>(p, tid, n0, pix);
+    if constexpr (AUX != 0) aux.template prefetch<AUX == 1>(p, tid, n0, pix);
     float16_t acc[CFG::MT][CFG::NTL];
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i)
@@ -1458,10 +1459,13 @@ static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
         return set_error("conv2d: K order 2 (fragment stream) is an fp16 layout");
     } else {
         using CFG = ConvCfgF<T, BN, CH, PH>;
-        const bool with_aux = a.epi != S2M2_EPI_NONE;            // epilogue operands: the variant that requests them under its last tap
-        auto kern = with_aux ? conv_frag_kernel<CFG, T, true> : conv_frag_kernel<CFG, T, false>;
-        static bool attr_done_dev[kMaxDevices][2] = {};
-        bool& attr_done = attr_done_dev[current_device()][with_aux];
+        const bool two = a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX;
+        const int naux = a.epi == S2M2_EPI_NONE ? 0 : two ? 2 : 1;   // epilogue operands parked in registers
+        // (two operands of 8 pieces each do not fit the 128-pixel block's register budget: rejected below, the instantiation is a dummy)
+        auto kern = naux == 0 ? conv_frag_kernel<CFG, T, 0> : (naux == 2 && PH == 2) ? conv_frag_kernel<CFG, T, (PH == 2 ? 2 : 1)>
+                                                                                      : conv_frag_kernel<CFG, T, 1>;
+        static bool attr_done_dev[kMaxDevices][3] = {};
+        bool& attr_done = attr_done_dev[current_device()][naux];
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)CFG::LDS_BYTES) != hipSuccess)
@@ -1470,8 +1474,8 @@ static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
         }
         if (a.stride != 1 || a.shuffle2 || a.KH > 3 || a.KW > 3 || a.KH * a.KW < 2 || a.Cout % BN || a.Cin % 8 || a.ln_wsum)
             return set_error("conv2d: K order 2 needs a stride-1 3x3 / 3x1 / 1x3 layer with Cout a multiple of %d (Cout=%d)", BN, a.Cout);
-        if (a.epi == S2M2_EPI_DUALMIX || a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX)
-            return set_error("conv2d: K order 2 takes one-operand epilogues only (epi=%d has two)", a.epi);
+        if (a.epi == S2M2_EPI_DUALMIX || (PH == 4 && (a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX)))
+            return set_error("conv2d: K order 2 with 128-pixel blocks takes one-operand epilogues only (epi=%d has two)", a.epi);
         const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
         dim3 grid((unsigned)(a.N * tx * ty), (unsigned)(a.Cout / BN));
         hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty);
@@ -1512,7 +1516,10 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         // 64-pixel blocks where 128-pixel blocks would leave most of the 256 CUs without one (tile: 2 / 4 force the patch height)
         static const int force_ph = getenv("S2M2_FRAG_PH") ? atoi(getenv("S2M2_FRAG_PH")) : 0;   // A/B switch
         const long long blocks4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.Cout / 128);
-        const int ph = tile == 2 || tile == 4 ? tile : (force_ph == 2 || force_ph == 4) ? force_ph : (blocks4 <= 256 ? 2 : 4);
+        // layers with an epilogue operand: always 64-pixel blocks (4 operand pieces per thread instead of 8, 160 registers: three blocks per
+        // CU -- measured -190 us per pair against the v3 tiles, where the 128-pixel variant was +90 us)
+        const int ph = tile == 2 || tile == 4 ? tile : (force_ph == 2 || force_ph == 4) ? force_ph
+                       : (a.epi != S2M2_EPI_NONE || blocks4 <= 256) ? 2 : 4;
         if constexpr (sizeof(T) == 2) {
             return ph == 2 ? launch_conv_frag<T, 128, 128, 2>(a, st) : launch_conv_frag<T, 128, 128, 4>(a, st);
         } else {

@@ -93,7 +93,10 @@ class Engine:
         self._fusion_ok: Dict[int, bool] = {}
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
         self.use_frag = os.environ.get("S2M2_CONV_FRAG", "1") != "0"     # A/B switch: 0 = spatial layers on the v3 halo tiles (K order 0)
-        self.frag_aux = os.environ.get("S2M2_FRAG_AUX", "0") == "1"      # opt-in: one-operand-epilogue layers on v5 too (measured 1 % slower end to end)
+        # epilogue-operand layers on the v5 kernel (64-pixel blocks): "1" (default) one-operand epilogues (residual add, r * h), "2" also the
+        # two-operand GRU blend (measured +35 us per pair: 176 registers, two blocks per CU), "0" none (v3 tiles)
+        self.frag_aux = os.environ.get("S2M2_FRAG_AUX", "1") != "0"
+        self.frag_aux2 = os.environ.get("S2M2_FRAG_AUX", "1") == "2"
         # opt-in: banded cost volume (columns j <= i + 11) for use_positivity models.  Off by default: the reference's DispInit hands
         # out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward (measured: profiles/r02/kbench.txt)
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
@@ -108,8 +111,7 @@ class Engine:
     # ---- weight packing (once per engine) ------------------------------------------------------------
     def std(self, name: str, splits: Optional[Sequence[Tuple[int, int]]] = None, transposed: bool = False, frag: bool = True) -> Spec:
         """One nn.Conv2d / nn.Linear (or stride-1 nn.ConvTranspose2d when ``transposed``) as a K5 weight.  frag=False: the layer is
-        launched with a stride or with a two-operand epilogue (GRU blend: its operands do not fit the fragment-stream kernel's
-        register budget), keep K order 0."""
+        launched with a stride (or S2M2_FRAG_AUX=0 keeps the epilogue-operand layers on the v3 tiles), keep K order 0."""
         key = (name, tuple(splits) if splits else None, transposed)
         s = self._packed.get(key)
         if s is None:
@@ -390,7 +392,7 @@ class Engine:
                 z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
             rh = self.cconv(self.std(f"{p}.convr{sfx}", frag=self.frag_aux), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
             self.join(z)
-            h = self.cconv(self.std(f"{p}.convq{sfx}", frag=False), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
+            h = self.cconv(self.std(f"{p}.convq{sfx}", frag=self.frag_aux2), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
 
     def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it,

@@ -111,6 +111,7 @@ FRAG_CASES = [
     (1, 21, 37, [96, 64, 32], 384, 3, 3, 1, 0),            # Cin = 192: a source boundary inside a chunk, half-empty last chunk
     (1, 64, 76, [128], 128, 3, 3, 0, 0),                   # several patches per row, exact tiling
     (2, 37, 45, [128], 256, 3, 3, 0, 1),                   # residual add without activation (ConvBlock2D's last conv), ragged, 2 cout blocks
+    (2, 19, 70, [128, 128], 128, 1, 3, 4, 3),              # GRU pass (1x3): tanh + GRU blend, two epilogue operands (64-pixel blocks only)
     (1, 8, 40, [128, 128, 64, 64], 128, 3, 3, 1, 0),       # four sources, three chunks
 ]
 
@@ -119,6 +120,8 @@ FRAG_CASES = [
 @pytest.mark.parametrize("case", FRAG_CASES)
 def test_conv_frag_stream(hip, case, ph):
     N, H, W, cs, Cout, KH, KW, act, epi = case
+    if epi == 3 and ph == 4:
+        pytest.skip("two-operand epilogues run on 64-pixel blocks only")
     dtype = torch.float16
     g = torch.Generator(device="cuda").manual_seed(100 + FRAG_CASES.index(case))
     srcs = [torch.randn(N, H, W, c, device="cuda", generator=g).to(dtype) for c in cs]
@@ -157,8 +160,8 @@ def test_conv_frag_argument_checks(hip):
     with pytest.raises((RuntimeError, ValueError)):
         hip.conv2d([x32], w.float(), None, 3, 3, 128, korder=2)
     a = torch.zeros(1, 8, 8, 128, device="cuda", dtype=torch.float16)
-    with pytest.raises(RuntimeError, match="one-operand"):            # two-operand epilogues stay on the v3 tiles
-        hip.conv2d([x], w, None, 3, 3, 128, korder=2, epi=3, aux0=a, aux1=a)
+    with pytest.raises(RuntimeError, match="one-operand"):            # two-operand epilogues: 64-pixel blocks only
+        hip.conv2d([x], w, None, 3, 3, 128, korder=2, epi=3, aux0=a, aux1=a, tile=4)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
