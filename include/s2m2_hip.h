@@ -152,6 +152,10 @@ typedef struct s2m2_conv_desc {
     float ln_eps;
     int ksplit;             /* S2M2_EPI_DUALMIX: first K index (channel of `in`) of the second layer; multiple of 64 */
     const float* bias2;     /* S2M2_EPI_DUALMIX: bias of the second layer (fp32, Cout) or NULL */
+    int pool2;              /* 1: the layer is nn.AvgPool2d(2) followed by this 1x1 layer (down_conv of Unet / MRT, reference unet.py:24-29,
+                               stacked_MRT.py:21-26): a GEMM row is the mean of input pixels (2y, 2x) .. (2y+1, 2x+1), formed and rounded
+                               to the I/O dtype exactly as s2m2_resample2x mode 0 does; output (N, H/2, W/2, Cout).  Needs KH = KW = 1,
+                               stride 1, korder 0, no shuffle2 / ln_wsum / DUALMIX. */
 } s2m2_conv_desc;
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
 

@@ -57,6 +57,7 @@ struct ConvArgs {
     float ln_eps;
     int ksplit;                 // S2M2_EPI_DUALMIX: K index where the second GEMM (second accumulator, bias2) starts
     const float* bias2;
+    int pool2;                  // 1x1 layer behind AvgPool2d(2): a row is the mean of 4 input pixels (stride = 2, Ho = H / 2, Wo = W / 2)
 };
 
 template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8, int NPF_ = 1, int NWAVES_ = 4>
@@ -227,9 +228,10 @@ struct KCursor {
 //    one 64-bit select between the real address and a 16-byte zero block (zero padding, K / Cout / M tails) -- no branches;
 //  * kernel-argument arrays are never indexed with a runtime value (that becomes memory loads + vmcnt(0) in front of every tile):
 //    the per-lane source is picked with masked telescoping sums over scalars.
-template <typename CFG, typename T>
+template <typename CFG, typename T, bool POOL = false>
 struct ConvLoader {
     static constexpr bool V1A = (S2M2_ASYNC_LOADS & 2) != 0;
+    static constexpr int NQ = POOL ? 4 : 1;    // POOL (AvgPool2d(2) folded into a 1x1 layer): a piece is the mean of the pieces of 4 pixels
     static constexpr int VEC = CFG::VEC, BK = CFG::BK, RS = CFG::RS, BN = CFG::BN;
     int pc, lrow, Ktot;
     int apix[CFG::A_IT];                       // input pixel (n*H + y)*W + x of the window centre
@@ -238,7 +240,7 @@ struct ConvLoader {
     KCursor<4 * VEC> cur;                      // K position of this thread's piece: channel within the tap, tap coordinates
     const T *s0, *s1, *s2, *s3;                // sources / strides / cumulative channel counts as named scalars
     int st0, st1, st2, st3, c0n, c1n, c2n;
-    raw16_t ra[CFG::NPF][CFG::A_IT], rb[CFG::NPF][CFG::B_IT];
+    raw16_t ra[CFG::NPF][CFG::A_IT * NQ], rb[CFG::NPF][CFG::B_IT];
 
     __device__ __forceinline__ void init(const ConvArgs& p, int tid, long long m0, int n0, long long M, int Ktot_) {
         pc = tid % CFG::PPR; lrow = tid / CFG::PPR; Ktot = Ktot_;
@@ -296,8 +298,17 @@ struct ConvLoader {
 #pragma unroll
         for (int it = 0; it < CFG::A_IT; ++it) {
             const unsigned e = __umul24((unsigned)(apix[it] + tapoff), ss) + c;      // pixel < 2^24, stride < 2^24, numel < 2^31
-            const T* src = (tapmask[it] & tapbit) ? sp + e : zp;
-            global_load16_async<V1A>(ra[slot][it], src);
+            const bool ok = (tapmask[it] & tapbit) != 0;
+            const T* src = ok ? sp + e : zp;
+            if constexpr (!POOL) {
+                global_load16_async<V1A>(ra[slot][it], src);
+            } else {                                              // pixels (2y, 2x), (2y, 2x+1), (2y+1, 2x), (2y+1, 2x+1): all inside (H, W >= 2*Ho, 2*Wo)
+                const unsigned dx = ok ? ss : 0u, dy = ok ? (unsigned)p.W * ss : 0u;
+                global_load16_async<V1A>(ra[slot][4 * it + 0], src);
+                global_load16_async<V1A>(ra[slot][4 * it + 1], src + dx);
+                global_load16_async<V1A>(ra[slot][4 * it + 2], src + dy);
+                global_load16_async<V1A>(ra[slot][4 * it + 3], src + dy + dx);
+            }
         }
         const int koff = kt * BK;
 #pragma unroll
@@ -310,14 +321,25 @@ struct ConvLoader {
 
     // the loads of a K tile are untracked (common.h: global_load16_async): every fetch issues exactly A_IT + B_IT of them (tiles past
     // the end of K read the zero page), so "the tile in `slot` has landed" = at most (NPF-1) younger tiles outstanding
-    static constexpr int LOADS_PER_TILE = CFG::A_IT + CFG::B_IT;
+    static constexpr int LOADS_PER_TILE = CFG::A_IT * NQ + CFG::B_IT;
     __device__ __forceinline__ void stash(T* a, T* b, int slot) {
         wait_vmcnt<(CFG::NPF - 1) * LOADS_PER_TILE, V1A>();
 #pragma unroll
         for (int it = 0; it < CFG::A_IT; ++it) {
-            settle(ra[slot][it]);
             const int r = lrow + CFG::RPI * it;
-            if (r < CFG::BM) *reinterpret_cast<raw16_t*>(a + (size_t)r * RS + pc * VEC) = ra[slot][it];
+            if constexpr (!POOL) {
+                settle(ra[slot][it]);
+                if (r < CFG::BM) *reinterpret_cast<raw16_t*>(a + (size_t)r * RS + pc * VEC) = ra[slot][it];
+            } else {                                              // the mean exactly as K7's AvgPool kernel forms and rounds it (upsample.hip)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) settle(ra[slot][4 * it + q]);
+                const Vec16<T> va = __builtin_bit_cast(Vec16<T>, ra[slot][4 * it + 0]), vb = __builtin_bit_cast(Vec16<T>, ra[slot][4 * it + 1]);
+                const Vec16<T> vc = __builtin_bit_cast(Vec16<T>, ra[slot][4 * it + 2]), vd = __builtin_bit_cast(Vec16<T>, ra[slot][4 * it + 3]);
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>((to_f32(va.v[e]) + to_f32(vb.v[e]) + to_f32(vc.v[e]) + to_f32(vd.v[e])) * 0.25f);
+                if (r < CFG::BM) *reinterpret_cast<Vec16<T>*>(a + (size_t)r * RS + pc * VEC) = o;
+            }
         }
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) {
@@ -331,7 +353,7 @@ struct ConvLoader {
 #pragma unroll
         for (int f = 0; f < CFG::NPF; ++f) {
 #pragma unroll
-            for (int it = 0; it < CFG::A_IT; ++it) settle(ra[f][it]);
+            for (int it = 0; it < CFG::A_IT * NQ; ++it) settle(ra[f][it]);
 #pragma unroll
             for (int it = 0; it < CFG::B_IT; ++it) settle(rb[f][it]);
         }
@@ -339,7 +361,8 @@ struct ConvLoader {
 };
 
 // MODE 0: plain; 1: pre-LayerNorm folded in (ln_wsum); 2: two GEMMs over consecutive K ranges of the same rows into two accumulators,
-// combined by the S2M2_EPI_DUALMIX epilogue (the gate and fusion heads of FeatureFusion in one launch)
+// combined by the S2M2_EPI_DUALMIX epilogue (the gate and fusion heads of FeatureFusion in one launch); 3: AvgPool2d(2) folded into the
+// A-operand load of a 1x1 layer (pool2: the down_conv of Unet / MRT, unet.py / stacked_MRT.py `nn.AvgPool2d(2), nn.Conv2d(., ., 1)`)
 template <typename CFG, typename T, int MODE = 0>
 __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     constexpr bool LN = MODE == 1, DUAL = MODE == 2;
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
     const int nkt = (Ktot + BK - 1) / BK;
 
     // ---- loader: this thread moves piece column `pc` of rows lrow + 32*it (see ConvLoader)
-    ConvLoader<CFG, T> ld;
+    ConvLoader<CFG, T, MODE == 3> ld;
     ld.init(p, tid, m0, n0, M, Ktot);
 
     float16_t acc[CFG::MT][CFG::NTL];
@@ -1526,6 +1549,10 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
             return launch_conv_frag<T, 128, 128, 4>(a, st);      // (reports the dtype error)
         }
     }
+    if (a.pool2) {                                                // AvgPool2d(2) + 1x1 (the coarse grids): 64x64 tiles, 64- / 128-byte K rows
+        if (tile == 2 || (tile != 6 && a.Cin > 512)) return launch_conv<T, 64, 64, 2, 8, 1, 4, 3>(a, st);
+        return launch_conv<T, 64, 64, 2, 4, 1, 4, 3>(a, st);
+    }
     static const long long t20_min = getenv("S2M2_T20_MIN") ? atoll(getenv("S2M2_T20_MIN")) : 300;   // tuning only
     static const int small_tile = getenv("S2M2_SMALL_TILE") ? atoi(getenv("S2M2_SMALL_TILE")) : 0;
     if (tile == 0) {                                              // measured on MI355X (tools/convbench.py, profiles/r01)
@@ -1662,6 +1689,13 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
                      (d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_GELU),
                      "conv2d: pre-LayerNorm needs a 1x1 stride-1 layer with act NONE or GELU and ln_eps > 0");
     a.stride = d->stride; a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
+    a.pool2 = d->pool2;
+    if (d->pool2) {
+        S2M2_REQUIRE(d->pool2 == 1 && d->KH == 1 && d->KW == 1 && d->stride == 1 && !d->shuffle2 && !d->korder && !d->ln_wsum &&
+                     d->epi != S2M2_EPI_DUALMIX && d->H >= 2 && d->W >= 2,
+                     "conv2d: pool2 needs a plain 1x1 stride-1 layer on an input of at least 2x2 pixels");
+        a.stride = 2; a.Ho = d->H / 2; a.Wo = d->W / 2;           // AvgPool2d(2): floor; rows read pixels (2y, 2x) .. (2y+1, 2x+1)
+    }
     S2M2_REQUIRE(d->korder >= 0 && d->korder <= 2, "conv2d: korder=%d (0, 1 or 2)", d->korder);
     S2M2_REQUIRE(d->korder != 1 || a.Cin % (d->dtype == S2M2_F16 ? 32 : 16) == 0, "conv2d: korder 1 needs Cin=%d to be a multiple of 64 bytes of channels", a.Cin);
     S2M2_REQUIRE(d->korder != 2 || d->dtype == S2M2_F16, "conv2d: korder 2 (fragment stream) is an fp16 layout");

@@ -92,6 +92,7 @@ class Engine:
         self.fuse_fusion = os.environ.get("S2M2_FUSE_FUSION", "1") != "0"  # A/B switch: 0 = FeatureFusion as K5 launches instead of K10
         self._fusion_ok: Dict[int, bool] = {}
         self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
+        self.fuse_pool = os.environ.get("S2M2_FUSE_POOL", "1") != "0"    # A/B switch: 0 = AvgPool2d(2) of the down_convs as its own K7 launch
         self.use_frag = os.environ.get("S2M2_CONV_FRAG", "1") != "0"     # A/B switch: 0 = spatial layers on the v3 halo tiles (K order 0)
         # epilogue-operand layers on the v5 kernel (64-pixel blocks): "1" (default) one-operand epilogues (residual add, r * h), "2" also the
         # two-operand GRU blend (measured +35 us per pair: 176 registers, two blocks per CU), "0" none (v3 tiles)
@@ -207,7 +208,12 @@ class Engine:
 
     # ---- building blocks -----------------------------------------------------------------------------
     def down(self, p: str, x: Tensor) -> Tensor:
-        return self.cconv(self.std(p + ".1"), [hip.resample2x(x, 0)])
+        """nn.AvgPool2d(2) -> Conv2d 1x1 (unet.py:24-29, stacked_MRT.py:21-26): the pooling is folded into the GEMM's operand load (same
+        mean, rounded to the activation dtype like the stand-alone K7 launch it replaces)."""
+        spec = self.std(p + ".1")
+        if self.fuse_pool and spec[2] == 1 and spec[3] == 1 and x.shape[1] >= 2 and x.shape[2] >= 2:
+            return self.cconv(spec, [x], pool2=True)
+        return self.cconv(spec, [hip.resample2x(x, 0)])
 
     def up(self, p: str, x: Tensor) -> Tensor:
         """nn.Upsample(bilinear x2) -> Conv2d 1x1 (unet.py:32-37, stacked_MRT.py:29-34).  A 1x1 layer commutes with the bilinear

@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
                 ("out", _vp), ("out_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Cout", _i),
                 ("act", _i), ("epi", _i), ("aux0", _vp), ("aux1", _vp), ("aux0_stride", _i), ("aux1_stride", _i),
                 ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("korder", _i), ("stride", _i),
-                ("ln_wsum", _vp), ("ln_eps", ctypes.c_float), ("ksplit", _i), ("bias2", _vp)]
+                ("ln_wsum", _vp), ("ln_eps", ctypes.c_float), ("ksplit", _i), ("bias2", _vp), ("pool2", _i)]
 
 
 class ChainDesc(ctypes.Structure):
@@ -218,11 +218,12 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
            epi: int = EPI_NONE, aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0,
            stride: int = 1, korder: int = 0, ln_wsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-           ksplit: int = 0, bias2: Optional[torch.Tensor] = None) -> torch.Tensor:
+           ksplit: int = 0, bias2: Optional[torch.Tensor] = None, pool2: bool = False) -> torch.Tensor:
     """Implicit-GEMM convolution / linear layer (s2m2_conv2d).  srcs: list of (N,H,W,Cs) tensors, concatenated along C;
     weight: packed (Cout, KH*KW*sum(Cs)) (see s2m2_amd.pack); bias fp32 (Cout) or None.  Returns (N,H,W,Cout), or
     (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM.  ln_wsum (fp32 (Cout) row sums of the packed weight): the 1x1 layer
-    is preceded by LayerNorm(Cin, no affine, eps=ln_eps) of the raw input rows, folded into the kernel."""
+    is preceded by LayerNorm(Cin, no affine, eps=ln_eps) of the raw input rows, folded into the kernel.  pool2: the 1x1 layer is preceded
+    by AvgPool2d(2), folded into its operand load -> (N, H//2, W//2, Cout)."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     d = ConvDesc()
@@ -243,6 +244,8 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cout or not bias.is_contiguous()):
         raise ValueError("conv2d: bias must be fp32 (Cout)")
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+    if pool2:
+        ho, wo = h // 2, w // 2
     exp_shape = (n, 2 * h, 2 * w, shuffle2) if shuffle2 else (n, ho, wo, Cout)
     if out is None:
         out = torch.empty(exp_shape, device=x0.device, dtype=dt)
@@ -266,6 +269,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
     d.tile = tile
     d.stride = stride
     d.korder = korder
+    d.pool2 = int(pool2)
     if ln_wsum is not None:
         if ln_wsum.dtype != torch.float32 or ln_wsum.numel() != Cout or not ln_wsum.is_contiguous():
             raise ValueError("conv2d: ln_wsum must be fp32 (Cout)")

@@ -29,10 +29,13 @@ def make():
         buf[..., off2:off2 + T] = c2.permute(0, 2, 3, 1).to(buf.dtype)
 
     def conv2d(srcs, weight, bias, KH, KW, Cout, act=0, epi=0, aux0=None, aux1=None, out=None, out_scale=1.0, shuffle2=0, tile=0,
-               stride=1, ln_wsum=None, ln_eps=1e-5, ksplit=0, bias2=None):
+               stride=1, ln_wsum=None, ln_eps=1e-5, ksplit=0, bias2=None, pool2=False):
         if isinstance(srcs, torch.Tensor):
             srcs = [srcs]
         x = torch.cat([s.float() for s in srcs], -1)
+        if pool2:
+            assert KH == 1 and KW == 1 and stride == 1
+            x = F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).to(srcs[0].dtype).float()
         n, h, w, cin = x.shape
         if epi == 5:                                                 # DUALMIX: two 1x1 layers over consecutive channel ranges
             assert KH == 1 and KW == 1 and act == 3 and 0 < ksplit < cin

@@ -292,3 +292,27 @@ def test_dual_gemm_gate_mix(hip, dtype, tile, shape):
     tol = 1e-4 if dtype == torch.float32 else 8e-3
     assert float((y.float() - ref).abs().max()) < tol
     assert float((y.float() - y2.float()).abs().max()) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 32, 38, 128, 256), (1, 9, 15, 256, 256), (2, 64, 76, 128, 128), (1, 2, 2, 128, 128), (1, 16, 24, 640, 128)])
+def test_conv_pool2_equals_avgpool_then_conv(hip, shape, dtype):
+    """pool2 (AvgPool2d(2) folded into the operand load of a 1x1 layer, the down_convs of unet.py:24-29 / stacked_MRT.py:21-26): bit-identical
+    to the stand-alone K7 pooling launch followed by the same layer, odd sizes drop the last row / column like nn.AvgPool2d."""
+    N, H, W, cin, cout = shape
+    g = torch.Generator(device="cuda").manual_seed(H * W + cin)
+    x = torch.randn(N, H, W, cin, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(cout, cin, 1, 1, device="cuda", generator=g) / math.sqrt(cin)).to(dtype)
+    b = torch.randn(cout, device="cuda", generator=g) * 0.1
+    wp, bp = pack.pack_conv(w, dtype), pack.pack_bias(b, cout)
+    fused = hip.conv2d([x], wp, bp, 1, 1, cout, act=1, pool2=True)
+    pooled = hip.resample2x(x[:, :H // 2 * 2, :W // 2 * 2].contiguous(), 0)       # (the K7 launch takes even sizes only)
+    assert tuple(pooled.shape) == (N, H // 2, W // 2, cin)
+    ref = hip.conv2d([pooled], wp, bp, 1, 1, cout, act=1, tile=6 if cin <= 512 else 2)
+    torch.cuda.synchronize()
+    assert tuple(fused.shape) == (N, H // 2, W // 2, cout)
+    assert torch.equal(fused, ref)
+    tref = F.gelu(F.conv2d(F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2).to(dtype).float(), w.float(), b)).permute(0, 2, 3, 1)
+    assert float((fused.float() - tref).abs().max()) < (2e-2 if dtype == torch.float16 else 2e-4)
+    with pytest.raises(RuntimeError, match="pool2"):
+        hip.conv2d([x], pack.pack_conv(torch.zeros(cout, cin, 3, 3), dtype), None, 3, 3, cout, pool2=True)
