@@ -1,0 +1,68 @@
+"""fp16 deployment mode against the REFERENCE's own fp16 run.
+
+tests/golden/e2e_S_640x480_fp16_autocast.npz holds the outputs of the unmodified reference at BASELINE configs[1]'s geometry (S model,
+640x480, refine_iter 3) run the way its run_stereo_matching runs it (model_utils.py:74-82: torch.amp.autocast(device_type=device.type,
+dtype=float16)) with device cpu -- the one fp16 mode of the reference that exists in the build container -- and of its fp32 run beside
+them (tests/golden/make_golden_fp16.py).  CPU autocast rounds at other points than CUDA autocast (and than the HIP kernels), so fp16 runs
+can only be compared statistically: the yardstick is how far the reference's fp16 run is from its own fp32 run.  Pinned here:
+
+* the oracle's fp16 mode (the autocast emulation the HIP fp16 tests are judged against) is as close to the reference's fp16 outputs as the
+  reference's fp32 run is                                                                                     (CPU, this container);
+* the HIP fp16 forward (the benchmarked mode) is as close to the reference's fp16 outputs as the reference's fp32 run is       (GPU).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2m2_oracle as O
+from s2m2_amd.weights import seeded_state_dict, synthetic_pair
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e2e_S_640x480_fp16_autocast.npz")
+MARGIN = 1.5          # measured: oracle fp16 0.6-0.9 x the yardstick on every statistic below
+
+
+def _q(d, p):
+    return float(d.flatten().kthvalue(max(1, int(p * d.numel())))[0])
+
+
+def _stats(a, b):
+    d = (torch.as_tensor(np.asarray(a)).float() - torch.as_tensor(np.asarray(b)).float()).abs()
+    return float(d.median()), _q(d, 0.9), _q(d, 0.99)
+
+
+def _setup():
+    g = np.load(GOLD)
+    C, ntr, H, W, B, pos, ri, disparity, seed = [int(v) for v in g["cfg"]]
+    sd = seeded_state_dict(C, 1, ntr, seed)
+    left, right = synthetic_pair(H, W, B, disparity, seed)
+    return g, sd, C, ntr, ri, bool(pos), left, right
+
+
+def _check(outs, g, what):
+    for k, name in enumerate(("disp", "occ", "conf")):
+        yard = _stats(g[name + "_fp16"], g[name + "_fp32"])          # the reference's fp16 run against its own fp32 run
+        mine = _stats(outs[k].cpu(), g[name + "_fp16"])
+        for stat, m, y in zip(("median", "p90", "p99"), mine, yard):
+            assert m <= MARGIN * y + 1e-6, f"{what} {name} {stat}: {m:.4g} vs reference fp16-fp32 spread {y:.4g}"
+
+
+def test_oracle_fp16_mode_sits_inside_the_references_own_fp16_spread():
+    g, sd, C, ntr, ri, pos, left, right = _setup()
+    torch.set_num_threads(min(8, torch.get_num_threads()))
+    o16 = O.forward(sd, left, right, pos, ri, False, {}, precision="fp16")
+    _check(o16, g, "oracle fp16")
+    # and the fp32 oracle reproduces the reference's fp32 outputs of the same run (the fp32 pin, at this size)
+    o32 = O.forward(sd, left, right, pos, ri, False, {}, precision="fp32")
+    assert _stats(o32[0], g["disp_fp32"])[2] < 1e-3                   # p99 of |disp| error in px
+    assert _stats(o32[1], g["occ_fp32"])[2] < 1e-3 and _stats(o32[2], g["conf_fp32"])[2] < 1e-3   # (stored as fp16: 5e-4 resolution)
+
+
+@pytest.mark.gpu
+def test_hip_fp16_mode_sits_inside_the_references_own_fp16_spread():
+    import parity_util as PU
+    g, sd, C, ntr, ri, pos, left, right = _setup()
+    hout, _ = PU.hip_forward(sd, C, ntr, ri, left, right, True)
+    assert all(torch.isfinite(t).all() for t in hout)
+    _check(hout, g, "HIP fp16")
