@@ -134,6 +134,10 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     // clears flags[(p + 1) % 3] for its successor, so a wave still reading the flag of pass p - 1 never sees it reset
     int* flags = reinterpret_cast<int*>(pz + NWV * ns);
     if (tid < 3) flags[tid] = 0;                           // (ordered before the first use by the barriers of pass 0)
+    // the padding of v (entries n .. ns-1) is never written by the sweeps but IS read: the 16-byte read of v that holds the dustbin entry
+    // v[w] also covers v[w+1 .. w+3], added to masked (-inf) columns -- whatever the previous kernel left in LDS there (+inf / NaN patterns)
+    // would turn exp(-inf + garbage - m) into NaN and poison the row sum
+    if (tid < ns - n) { v[n + tid] = 0.f; u[n + tid] = 0.f; }
 
     // ---- exact column sweep: v_j = log nu_j - LSE_i(S_ij + u_i) with lazy-maximum accumulators (pass 0, where u = 0, and the
     // fallback of the fast sweep below)
