@@ -1,0 +1,56 @@
+"""Host-side weight packing (s2m2_amd/pack.py) checked on the CPU against the layouts include/s2m2_hip.h documents."""
+import torch
+
+from s2m2_amd import pack
+
+
+def test_pack_conv_k_order_0_and_padding():
+    w = torch.arange(16 * 11 * 3 * 3, dtype=torch.float32).reshape(16, 11, 3, 3)
+    p = pack.pack_conv(w, torch.float32)
+    assert tuple(p.shape) == (16, 3 * 3 * 16)                                   # Cin 11 -> 16 (multiples of 8), K = (ky, kx, c)
+    q = p.reshape(16, 3, 3, 16)
+    assert torch.equal(q[..., :11], w.permute(0, 2, 3, 1)) and float(q[..., 11:].abs().max()) == 0
+    # two sources, individually padded: channels of source 1 start at the padded end of source 0
+    p2 = pack.pack_conv(w, torch.float32, [(3, 8), (8, 8)]).reshape(16, 3, 3, 16)
+    assert torch.equal(p2[..., :3], w.permute(0, 2, 3, 1)[..., :3]) and torch.equal(p2[..., 8:16], w.permute(0, 2, 3, 1)[..., 3:11])
+    assert float(p2[..., 3:8].abs().max()) == 0
+    assert tuple(pack.pack_conv(w[:10], torch.float32).shape) == (16, 144)      # Cout 10 -> 16 zero rows
+    assert float(pack.pack_bias(torch.ones(10), 10)[10:].abs().max()) == 0
+
+
+def test_pack_conv_frag_is_the_documented_fragment_stream():
+    """K order 2 (s2m2_conv_desc.korder): [Cout/32][chunk][tap][k16 step][lane][8], lane l = cout 32t + l % 32,
+    channel 128 c + 16 s + 8 (l // 32) + e, zero beyond Cin."""
+    cout, cin, kh, kw = 128, 192, 3, 1
+    w = torch.randn(cout, cin, kh, kw).half()
+    assert pack.frag_eligible(cout, cin, kh, kw, torch.float16)
+    f = pack.pack_conv_frag(w, torch.float16)
+    nchunk = 2
+    assert tuple(f.shape) == (cout, kh * kw * nchunk * 128)
+    s = f.reshape(cout // 32, nchunk, kh * kw, 8, 64, 8)
+    for t, c, tap, st, lane, e in [(0, 0, 0, 0, 0, 0), (3, 1, 2, 3, 63, 7), (1, 0, 1, 7, 31, 5), (2, 1, 0, 4, 40, 2), (0, 1, 2, 7, 63, 7)]:
+        co, ch = 32 * t + lane % 32, 128 * c + 16 * st + 8 * (lane // 32) + e
+        want = w[co, ch, tap // kw, tap % kw] if ch < cin else torch.tensor(0.0).half()
+        assert s[t, c, tap, st, lane, e] == want, (t, c, tap, st, lane, e)
+    # every real weight appears exactly once, the rest is padding
+    assert abs(float(s.float().abs().sum()) - float(w.float().abs().sum())) < 1e-2 * float(w.float().abs().sum())
+    assert not pack.frag_eligible(64, 128, 3, 3, torch.float16) and not pack.frag_eligible(128, 64, 3, 3, torch.float16)
+    assert not pack.frag_eligible(128, 128, 1, 1, torch.float16) and not pack.frag_eligible(128, 128, 3, 3, torch.float32)
+
+
+def test_transposed_conv_packings():
+    w = torch.randn(6, 10, 3, 3)                                                 # ConvTranspose2d weight (Cin, Cout, KH, KW), stride 1
+    c = pack.convT_s1_as_conv(w)
+    x = torch.randn(1, 6, 7, 9)
+    ref = torch.nn.functional.conv_transpose2d(x, w, padding=1)
+    assert float((torch.nn.functional.conv2d(x, c, padding=1) - ref).abs().max()) < 1e-5
+    w2 = torch.randn(8, 5, 2, 2)                                                 # ConvTranspose2d(k=2, s=2)
+    g, cp = pack.pack_convT_2x2s2(w2, torch.float32)
+    assert cp == 8 and tuple(g.shape) == (32, 8)
+    y = torch.nn.functional.conv_transpose2d(torch.randn(1, 8, 3, 4), w2, stride=2)
+    assert tuple(y.shape) == (1, 5, 6, 8)
+    xin = torch.randn(1, 8, 3, 4)
+    y = torch.nn.functional.conv_transpose2d(xin, w2, stride=2)
+    z = torch.einsum("rk,nkyx->nryx", g, xin).reshape(1, 2, 2, 8, 3, 4)          # rows ordered (dy, dx, c')
+    z = z.permute(0, 3, 4, 1, 5, 2).reshape(1, 8, 6, 8)[:, :5]
+    assert float((z - y).abs().max()) < 1e-5
