@@ -30,6 +30,9 @@ enum { S2M2_F32 = 0, S2M2_F16 = 1 };
 /* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
 int s2m2_version(void);
 const char* s2m2_last_error(void);
+/* test aid (not part of the path): fills the LDS of every CU with quiet-NaN patterns, so that a kernel launched next that reads an LDS word it
+ * never wrote produces NaNs instead of silently using stale data (tests/test_hip_lds_poison.py, opt-in) */
+int s2m2_debug_poison_lds(void* stream);
 
 /* Name of the device kernel s2m2_ln_corr dispatches to for this configuration (for rocprof matching). */
 const char* s2m2_ln_corr_kernel_name(int C, int feat_dtype, int cv_dtype);

@@ -36,7 +36,31 @@ const void* zero_page() {
     return p;
 }
 
+// test aid: leaves quiet-NaN bit patterns in the whole LDS of every CU.  LDS is not cleared between kernels, so a kernel that reads a word
+// it (or its predecessor in the same launch) never wrote sees whatever ran before it -- usually harmless values, which is how such a read
+// survives testing (round 2: the padding behind K2's dustbin entry).  Running this first makes the stale data poisonous.
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink, int words) {
+    extern __shared__ unsigned lds[];
+    for (int i = threadIdx.x; i < words; i += 256) lds[i] = 0x7fc00000u;
+    __syncthreads();
+    if (sink && lds[(threadIdx.x * 37) % words] != 0x7fc00000u) sink[0] = 1u;      // keeps the stores alive
+}
+
 }  // namespace s2m2
+
+extern "C" int s2m2_debug_poison_lds(void* stream) {
+    using namespace s2m2;
+    constexpr int kBytes = 160 * 1024;                            // one block owns a CU's whole LDS; 4 blocks per CU's worth of grid
+    static bool attr_done_dev[kMaxDevices] = {};
+    bool& attr_done = attr_done_dev[current_device()];
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) != hipSuccess)
+            return set_error("debug_poison_lds: cannot reserve %d bytes of LDS", kBytes);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), kBytes, static_cast<hipStream_t>(stream), (unsigned*)nullptr, kBytes / 4);
+    return check_launch("debug_poison_lds");
+}
 
 extern "C" int s2m2_version(void) { return 100; }          // 0.1.0
 extern "C" const char* s2m2_last_error(void) { return s2m2::g_err; }

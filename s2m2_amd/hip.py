@@ -69,6 +69,7 @@ SIGNATURES = {
     "s2m2_refine_prep": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_global_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_refine_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
+    "s2m2_debug_poison_lds": (_i, [_vp]),
     "s2m2_refine_update_to": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "s2m2_tanh": (_i, [_vp, _vp, _ll, _i, _vp]),
     "s2m2_stem_mlp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
@@ -496,6 +497,11 @@ def image_prep(img0: torch.Tensor, img1: torch.Tensor, dtype: torch.dtype) -> to
     _check(load().s2m2_image_prep(img0.data_ptr(), img1.data_ptr(), x8.data_ptr(), B, H, W, _IMG_DT[img0.dtype], _DT[dtype], _stream()),
            "s2m2_image_prep")
     return x8
+
+
+def poison_lds() -> None:
+    """Test aid: quiet-NaN patterns in the LDS of every CU (s2m2_debug_poison_lds), on the current stream."""
+    _check(load().s2m2_debug_poison_lds(_stream()), "s2m2_debug_poison_lds")
 
 
 def refine_prep(disp: torch.Tensor, conf: torch.Tensor, occ: Optional[torch.Tensor], mode: int, dtype: torch.dtype) -> torch.Tensor:
