@@ -12,6 +12,13 @@ from s2m2_amd.weights import seeded_state_dict, synthetic_pair
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("S2M2_TEST_LDS_POISON") != "1", reason="opt-in: S2M2_TEST_LDS_POISON=1")]
 
 
+@pytest.fixture(scope="module")
+def hip():
+    from s2m2_amd import hip as h
+    h.load()
+    return h
+
+
 def test_forward_is_unchanged_when_every_kernel_starts_on_poisoned_lds(hip):
     from s2m2_amd.model import S2M2
     sd = seeded_state_dict(128, 1, 1, 0)
