@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--refine-iter", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 640x480 block measured after the timed region")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--dry", action="store_true", help="CPU/gloo plumbing check of the multi-rank path: no GPU, no model")
     return ap.parse_args()
@@ -123,6 +124,43 @@ def cpu_baseline(model_type, H, W, refine_iter):
                                  "(same ATen CPU kernels; the oracle skips nn.Module dispatch and the (N,N,32) PE gather)",
             "sample": f"1 pair {W}x{H} {model_type}-model fp32 refine_iter={refine_iter} per run, oracle/s2m2_oracle.py (torch CPU ops): "
                       f"1 warm-up, 1 run per thread count, median of 3 at the best count"}
+
+
+def secondary_640x480(model, eng, dev, use_fp16, refine_iter, model_type, steps=50, warmup=3):
+    """north_star's second size (BASELINE configs[1]: 640x480, refine_iter 3, one pair) measured in the SAME run on rank 0's GPU after
+    the headline's timed region: hipGraph replay, K1 with its own start / stop events on the dispatch.  Not part of `value`."""
+    import torch
+    from s2m2_amd.weights import noise_pair
+    H, W = 480, 640
+    left, right = (t.to(dev) for t in noise_pair(H, W, 1, seed=7))
+    eng.k1_events = []
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+            return model(left, right)
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    eng.k1_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k1_us = [t.elapsed_us() for t in eng.k1_events]
+    eng.k1_events = None
+    h, w, C = H // 4, W // 4, model.feature_channels
+    e = 2 if use_fp16 else 4
+    k1_bytes = 2 * h * w * C * e + h * w * w * e
+    us = sum(k1_us) / max(1, len(k1_us))
+    gbs = k1_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    return {"workload": f"{model_type}-model {W}x{H} refine_iter={refine_iter} use_positivity=True, 1 pair per step, n_gpus=1 (rank 0)",
+            "value": steps / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "dtype": "f16" if use_fp16 else "f32",
+            "roofline": {"kernel": "ln_corr_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": us, "launches_timed": len(k1_us),
+                         "note": "h = 120 image rows = 120 workgroups on 256 CUs: this size cannot fill the chip with one pair"}}
 
 
 def pmc_traffic(model_type, H, W, use_fp16, B):
@@ -285,8 +323,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     k1_ms = [t.elapsed_us() * 1e-3 for t in eng.k1_events]
+    own_elapsed = elapsed
+    per_rank_ms = [1e3 * elapsed / a.steps]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                                  # per-rank step time: a straggler is visible in the line
+        per_rank_ms = [1e3 * float(x.item()) / a.steps for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -347,6 +390,9 @@ def main():
                         "flops_by_family": {k: v[0] / B for k, v in meter.items()}, "launches_by_family": {k: v[1] for k, v in meter.items()},
                         "note": "2 flops per multiply-accumulate of every GEMM-shaped launch, padded channel counts; per GPU"},
         }
+        line["per_rank_ms_per_step"] = [round(x, 4) for x in per_rank_ms]
+        if not a.no_secondary and (a.height, a.width) != (480, 640):
+            line["secondary"] = secondary_640x480(model, eng, dev, use_fp16, a.refine_iter, a.model)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.model, a.height, a.width, a.refine_iter)
         print(json.dumps(line), flush=True)

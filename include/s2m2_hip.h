@@ -31,8 +31,11 @@ enum { S2M2_F32 = 0, S2M2_F16 = 1 };
 int s2m2_version(void);
 const char* s2m2_last_error(void);
 /* test aid (not part of the path): fills the LDS of every CU with quiet-NaN patterns, so that a kernel launched next that reads an LDS word it
- * never wrote produces NaNs instead of silently using stale data (tests/test_hip_lds_poison.py, opt-in) */
+ * never wrote produces NaNs instead of silently using stale data (tests/test_hip_lds_poison.py) */
 int s2m2_debug_poison_lds(void* stream);
+/* measurement aid (not part of the path): writes {shader-clock ticks (s_memtime), 100 MHz real-time ticks (s_memrealtime)} as two
+ * uint64 to device memory `out`; two probes around a region of a stream give the average engine clock it ran at (tools/clock_probe.py) */
+int s2m2_debug_clock_probe(void* out, void* stream);
 
 /* Name of the device kernel s2m2_ln_corr dispatches to for this configuration (for rocprof matching). */
 const char* s2m2_ln_corr_kernel_name(int C, int feat_dtype, int cv_dtype);
@@ -66,6 +69,17 @@ int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, v
 int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, void* cv,
                         int B, int h, int w, int C, int feat_dtype, int cv_dtype, int band, void* stream,
                         void* start_event, void* stop_event);
+/*
+ * [A4] the correlation alone, on tokens that are ALREADY LayerNorm'ed (DispInit's layer_norm folded into the launch that produced them:
+ *   the ln_out rows of s2m2_mlp_chain) -- K1 without statistics and affine, the batched product R . L^T and its stores:
+ *   tokens (2B, h, w, C) NHWC dtype token_dtype;  cv[b,y,i,j] = < tokens[b,y,i,:], tokens[B+b,y,j,:] > at
+ *       cv + ((b*h + y)*w + i)*cv_pitch + j,   cv_pitch >= w, a multiple of 8 (0 = w).  A pitch that is a multiple of 64 fp16 / 32
+ *   fp32 elements (w = 304 -> 320) makes every 64-column store granule a whole 128-byte line; s2m2_sinkhorn_regress and
+ *   s2m2_cv_lookup read the same pitch.  band >= 0: as s2m2_ln_corr_banded (-1: full volume); start / stop events as
+ *   s2m2_ln_corr_timed (may be NULL).
+ */
+int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
+              void* stream, void* start_event, void* stop_event);
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);
@@ -73,7 +87,7 @@ int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microsecon
 /*
  * [A5+A6] Sinkhorn optimal transport with dustbins + argmax + 5-tap window regression
  *   (DispInit._optimal_transport/_sinkhorn submodules.py:169-201, regression :225-241, logsumexp_stable :147-152)
- *   cv      (B, h, w, w) dtype cv_dtype (read only)
+ *   cv      (B, h, w, w) dtype cv_dtype (read only), volume rows cv_pitch elements apart (0 = w; a multiple of 8)
  *   disp, conf, occ  (B, h, w) fp32 out  (disp = i - soft-argmax, 1/4-res pixels; occ = row mass of masked P)
  *   argmax  (B, h, w) int32 out or NULL  (first maximal j wins)
  *   use_positivity: entries j > i are masked (the reference fills -1e4, which underflows to exactly 0 in fp32)
@@ -81,13 +95,13 @@ int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microsecon
  */
 size_t s2m2_sinkhorn_workspace_bytes(int B, int h, int w, int cv_dtype);
 int s2m2_sinkhorn_regress(const void* cv, float* disp, float* conf, float* occ, int32_t* argmax,
-                          int B, int h, int w, int ot_iter, int use_positivity, int cv_dtype,
+                          int B, int h, int w, int ot_iter, int use_positivity, int cv_dtype, int cv_pitch,
                           void* workspace, void* stream);
 
 /*
  * [A9+A10] two-level cost-volume lookup, radius r (CostVolume.__init__/__call__, submodules.py:23-60,
  *   bilinear_sampler :7-17).  Level 1 (cv averaged over pairs of j) is computed on the fly, never stored.
- *   cv    (B, h, w, w) dtype cv_dtype;  disp (B, h, w) fp32
+ *   cv    (B, h, w, w) dtype cv_dtype, volume rows cv_pitch elements apart (0 = w);  disp (B, h, w) fp32
  *   corr1, corr2  fp32 (or fp16 when out_dtype = S2M2_F16) with element (b,y,i,k) at
  *       base + ((b*h + y)*w + i)*pix_stride + k*tap_stride      k = 0..2r  <->  dx = k - r
  *   (planar (B,2r+1,h,w) of the reference: pix_stride=1, tap_stride=h*w with base offset b*(2r+1)*h*w handled by
@@ -97,7 +111,7 @@ int s2m2_sinkhorn_regress(const void* cv, float* disp, float* conf, float* occ, 
  */
 int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2,
                    int B, int h, int w, int radius, int cv_dtype, int out_dtype,
-                   long long batch_stride, long long pix_stride, long long tap_stride, void* stream);
+                   long long batch_stride, long long pix_stride, long long tap_stride, int cv_pitch, void* stream);
 
 /*
  * [A2,A3,A7,A8,A11,A12,A14,A15] implicit-GEMM convolution / linear layer with fused concatenation and epilogues.
@@ -190,6 +204,15 @@ typedef struct s2m2_chain_desc {
     int carry;
     float ln_eps;
     int dtype;
+    /* optional second output of the last stage: ln_out rows = LayerNorm(out rows) * ln_gamma + ln_beta over the C channels (fp32
+       statistics of the rounded `out` rows, biased variance, eps ln_out_eps, result rounded to the I/O dtype).  Folds DispInit's
+       layer_norm (submodules.py:165,216) into the launch that produces feature_tr_4x; consumed by s2m2_corr.  NULL: none.
+       Needs C * sizeof(dtype) / 16 in {16, 32, 64} (fp16: C = 128 / 256 / 512; fp32: C = 128 / 256). */
+    void* ln_out;
+    long long ln_out_stride;
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_out_eps;
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);
 int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
@@ -253,6 +276,13 @@ int s2m2_attention(const void* q, const void* k, const void* v, void* out, long 
                    long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
                    int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
                    int grid_w, int grid_h, int dtype, void* stream);
+/*
+ * Plans the launch s2m2_attention would make for (nb, heads, N = Nq = Nk, D, dtype) -- head-dim instantiation, and for the PE variant
+ *   (grid_w, grid_h > 0; 0, 0 = no positional encoding) the marginal-bin tiles, waves per block and the 160 KB LDS budget -- without
+ *   launching.  1 = supported, 0 = not (s2m2_last_error names the limit).  Lets the host reject a geometry BEFORE the first launch of a
+ *   forward (token grids above 96 x 96 cells = images above 3072 px per side have no PE instantiation).
+ */
+int s2m2_attention_supported(int nb, int heads, int N, int D, int grid_w, int grid_h, int dtype);
 
 /*
  * [A2,A3] 2x resampling of an NHWC activation: mode 0 = nn.AvgPool2d(2) (unet.py:25-30, stacked_MRT.py:22-27), mode 1 =

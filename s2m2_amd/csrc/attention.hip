@@ -37,6 +37,7 @@ struct AttnArgs {
     float scale;
     // positional encoding (PE variant only)
     const float* px; const float* py; void* pe_out; long long spe; int gw, gh;
+    int dry;                            // host side only: plan the launch (tile variant, waves, LDS) and return without launching
 };
 
 template <typename T, int DP_, bool PE_, int MINW_ = 4, bool KSPLIT_ = false, int NXT_ = 2, int NYT_ = 1>
@@ -451,34 +452,39 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     }
 }
 
+constexpr size_t kLdsBytes = 160 * 1024;
+
 template <typename T, int DP, bool PE, int MINW, bool KSPLIT, int NXT, int NYT>
 static int launch_attn_t(const AttnArgs& a, int nw, hipStream_t st) {
     using CFG = AttnCfg<T, DP, PE, MINW, KSPLIT, NXT, NYT>;
     auto kern = attention_kernel<CFG, T>;
     size_t lds = CFG::K_BYTES + CFG::V_BYTES;
     if (KSPLIT) lds = lds > CFG::MERGE_BYTES ? lds : CFG::MERGE_BYTES;
-    if (PE)                                                       // tables + (w + h | 1) marginal bins per query of every wave
-        lds = CFG::PE_OFF + ((size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 + (size_t)nw * 32 * CFG::SM) * sizeof(float);
-    if (lds > 160 * 1024) return set_error("attention: %zu bytes of LDS needed", lds);
-    static size_t attr_bytes_dev[kMaxDevices] = {};
-    size_t& attr_bytes = attr_bytes_dev[current_device()];
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return set_error("attention: cannot reserve %zu bytes of LDS", lds);
-        attr_bytes = lds;
+    if (PE) {                                                     // tables + (w + h | 1) marginal bins per query of every wave
+        auto need = [&](int n) { return CFG::PE_OFF + ((size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 + (size_t)n * 32 * CFG::SM) * sizeof(float); };
+        // large token grids: fewer waves per block until tables + bins fit next to the K/V stages (the block count follows nw below;
+        // the key-split mode always runs its four waves)
+        if (!KSPLIT) while (need(nw) > kLdsBytes && nw > MINW) --nw;
+        lds = need(nw);
     }
+    if (lds > kLdsBytes) return set_error("attention: %zu bytes of LDS needed (head dim %d, %d x %d token grid)", lds, a.D, a.gw, a.gh);
+    if (a.dry) return 0;
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), lds, lds_granted, "attention")) return 1;
     const int ntq = (a.Nq + 31) / 32;
     const int nblk = KSPLIT ? ntq : (ntq + nw - 1) / nw;
     hipLaunchKernelGGL(kern, dim3(nblk, a.nb * a.heads), dim3(nw * 64), lds, st, a);
     return check_launch("attention");
 }
 
-// PE variant: bin tiles sized for the token grid -- (2, 1) covers grids up to 64 x 32 (the 1/32 grid of 2048 x 1024 images), (3, 3) up to
-// 96 x 96 (3072 x 3072); without PE the two parameters are inert
+// PE variant: bin tiles sized for the token grid -- (2, 1) covers grids up to 64 x 32 (the 1/32 grid of 2048 x 1024 images), (3, 2) up to
+// 96 x 64 (3072 x 2048: BASELINE's XL 2432 x 2048 pair is 76 x 64), (3, 3) up to 96 x 96 (3072 x 3072); without PE the two parameters are
+// inert.  engine.check_limits asks s2m2_attention_supported before the first launch of a forward.
 template <typename T, int DP, bool PE, int MINW, bool KSPLIT = false>
 static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
     if constexpr (PE) {
         if (a.gw <= 64 && a.gh <= 32) return launch_attn_t<T, DP, PE, MINW, KSPLIT, 2, 1>(a, nw, st);
+        if (a.gw <= 96 && a.gh <= 64) return launch_attn_t<T, DP, PE, MINW, KSPLIT, 3, 2>(a, nw, st);
         if (a.gw <= 96 && a.gh <= 96) return launch_attn_t<T, DP, PE, MINW, KSPLIT, 3, 3>(a, nw, st);
         return set_error("attention: positional-encoding grid %d x %d exceeds 96 x 96 cells", a.gw, a.gh);
     } else {
@@ -533,12 +539,12 @@ static int dispatch_attn(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace s2m2
 
-extern "C" int s2m2_attention(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
-                              long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
-                              int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
-                              int grid_w, int grid_h, int dtype, void* stream) {
+static int attention_entry(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
+                           long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
+                           int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
+                           int grid_w, int grid_h, int dtype, void* stream, int dry) {
     using namespace s2m2;
-    S2M2_REQUIRE(q && k && v && out, "attention: null pointer");
+    S2M2_REQUIRE(dry || (q && k && v && out), "attention: null pointer");
     S2M2_REQUIRE(nb > 0 && heads > 0 && Nq > 0 && Nk > 0 && D > 0 && D % 8 == 0, "attention: bad shape nb=%d heads=%d Nq=%d Nk=%d D=%d", nb, heads, Nq, Nk, D);
     S2M2_REQUIRE(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && out_stride % 4 == 0, "attention: strides must be multiples of 8");
     S2M2_REQUIRE(!swap_halves || (nb % 2 == 0 && Nq == Nk), "attention: swap_halves needs an even batch and Nq == Nk");
@@ -550,9 +556,27 @@ extern "C" int s2m2_attention(const void* q, const void* k, const void* v, void*
     AttnArgs a;
     a.q = q; a.k = k; a.v = v; a.out = out; a.sq = q_stride; a.sk = k_stride; a.sv = v_stride; a.so = out_stride;
     a.nb = nb; a.heads = heads; a.Nq = Nq; a.Nk = Nk; a.D = D; a.swap = swap_halves; a.scale = scale;
-    a.px = pe_x; a.py = pe_y; a.pe_out = pe_out; a.spe = pe_stride; a.gw = grid_w; a.gh = grid_h;
+    a.px = pe_x; a.py = pe_y; a.pe_out = pe_out; a.spe = pe_stride; a.gw = grid_w; a.gh = grid_h; a.dry = dry;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == S2M2_F16) return pe ? dispatch_attn<half_t, true>(a, st) : dispatch_attn<half_t, false>(a, st);
     if (dtype == S2M2_F32) return pe ? dispatch_attn<float, true>(a, st) : dispatch_attn<float, false>(a, st);
     return set_error("attention: unsupported dtype %d", dtype);
+}
+
+extern "C" int s2m2_attention(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
+                              long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
+                              int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
+                              int grid_w, int grid_h, int dtype, void* stream) {
+    return attention_entry(q, k, v, out, q_stride, k_stride, v_stride, out_stride, nb, heads, Nq, Nk, D, scale, swap_halves, pe_x, pe_y,
+                           pe_out, pe_stride, grid_w, grid_h, dtype, stream, 0);
+}
+
+extern "C" int s2m2_attention_supported(int nb, int heads, int N, int D, int grid_w, int grid_h, int dtype) {
+    // the same planning code as the launch (head-dim instantiation, PE bin tiles, waves per block, LDS budget) without the launch;
+    // grid_w = grid_h = 0: no positional encoding.  1 = supported, 0 = not (s2m2_last_error says why)
+    static const float dummy = 0.f;
+    const bool pe = grid_w > 0 || grid_h > 0;
+    const int c = heads * ((D + 7) / 8 * 8);
+    return attention_entry(nullptr, nullptr, nullptr, nullptr, 3 * c, 3 * c, 3 * c, c, nb, heads, N, N, D, 1.0f, 0, pe ? &dummy : nullptr,
+                           pe ? &dummy : nullptr, pe ? const_cast<float*>(&dummy) : nullptr, heads * 32, grid_w, grid_h, dtype, nullptr, 1) == 0;
 }

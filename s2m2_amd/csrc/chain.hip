@@ -35,6 +35,13 @@ struct ChainArgs {
     int res_stage, carry;
     float ln_eps;
     const void* zero;
+    // second output (last stage): LayerNorm with affine of the rows just produced (DispInit's layer_norm folded into the launch
+    // that writes feature_tr_4x, so that K1 starts its MFMAs on normalised tokens)
+    void* ln_out;
+    long long ln_out_stride;
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_out_eps;
 };
 
 template <typename T, int C_, int BM_, int NST_, int NW_, int WP_ = 4>
@@ -212,6 +219,15 @@ struct ChainStage {
             }
         } else {                                                   // coalesced store of the staged tile (+ carry, + res)
             T* outp = static_cast<T*>(p.out);
+            // LayerNorm output: a row's PPR pieces sit in PPR consecutive lanes of one wave (NT % PPR == 0, PPR in {16, 32, 64}:
+            // checked on the host), and a thread's piece column is the same for every `it`
+            const bool ln2 = p.ln_out != nullptr;
+            float g2[VEC], b2[VEC];
+            if (ln2) {
+                const int pcx = tid % CFG::PPR;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { g2[e] = p.ln_gamma[pcx * VEC + e]; b2[e] = p.ln_beta[pcx * VEC + e]; }
+            }
 #pragma unroll
             for (int it = 0; it < CFG::X_IT; ++it) {
                 const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
@@ -228,6 +244,25 @@ struct ChainStage {
                     for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
                 }
                 if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + pcx * VEC) = v;
+                if (ln2) {                                         // block-uniform
+                    // statistics of the STORED (rounded) row, two passes in fp32 like K1 / nn.LayerNorm: biased variance, eps inside
+                    float x[VEC], sum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { x[e] = to_f32(v.v[e]); sum += x[e]; }
+#pragma unroll
+                    for (int o = 1; o < CFG::PPR; o <<= 1) sum += __shfl_xor(sum, o);
+                    const float mean = sum * (1.0f / (float)C);
+                    float sq = 0.f;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) { x[e] -= mean; sq = __builtin_fmaf(x[e], x[e], sq); }
+#pragma unroll
+                    for (int o = 1; o < CFG::PPR; o <<= 1) sq += __shfl_xor(sq, o);
+                    const float rstd = rsqrtf(sq * (1.0f / (float)C) + p.ln_out_eps);
+                    Vec16<T> o;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
+                    if (m < p.rows) *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
+                }
             }
         }
     }
@@ -276,14 +311,8 @@ template <typename T, int C, int BM, int NST, int NW, int WP = 4>
 static int launch_chain(const ChainArgs& a, hipStream_t st) {
     using CFG = ChainCfg<T, C, BM, NST, NW, WP>;
     auto kern = mlp_chain_kernel<CFG, T>;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[current_device()];
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)CFG::LDS_BYTES) != hipSuccess)
-            return set_error("mlp_chain: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
-        attr_done = true;
-    }
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "mlp_chain")) return 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)((a.rows + BM - 1) / BM)), dim3(CFG::NT), CFG::LDS_BYTES, st, a);
     return check_launch("mlp_chain");
 }
@@ -332,6 +361,13 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     }
     S2M2_REQUIRE(!any_ln || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
     a.res_stage = d->res_stage; a.carry = d->carry; a.ln_eps = d->ln_eps;
+    a.ln_out = d->ln_out; a.ln_out_stride = d->ln_out_stride; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out_eps = d->ln_out_eps;
+    if (d->ln_out) {
+        const int ppr = d->C * (d->dtype == S2M2_F16 ? 2 : 4) / 16;      // 16-byte pieces per row = lanes that share a row in the store pass
+        S2M2_REQUIRE(ppr == 16 || ppr == 32 || ppr == 64, "mlp_chain: ln_out needs a row of 16, 32 or 64 pieces (C=%d has %d)", d->C, ppr);
+        S2M2_REQUIRE(d->ln_gamma && d->ln_beta && d->ln_out_eps > 0.f && d->ln_out_stride >= d->C && d->ln_out_stride % 8 == 0,
+                     "mlp_chain: ln_out needs gamma, beta, a positive eps and a row stride that is a multiple of 8");
+    }
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "mlp_chain: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);

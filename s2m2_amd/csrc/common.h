@@ -21,6 +21,10 @@ int check_launch(const char* what);             // hipGetLastError() -> set_erro
 constexpr int kMaxDevices = 32;
 int current_device();                           // hipGetDevice(), clamped to [0, kMaxDevices)
 const void* zero_page();                        // 256 zero bytes in the current device's memory (allocated on first use, never freed)
+// Raises the dynamic-LDS limit of kernel `func` on the current device to at least `bytes` (hipFuncSetAttribute), once per size:
+// `granted` is the caller's per-instantiation cache (a zero-initialised static array of kMaxDevices entries).  Serialised by one
+// process-wide mutex: forward() may be called from any thread, and two modules on the same device share these caches.
+int reserve_lds(const void* func, size_t bytes, size_t* granted, const char* what);
 
 #define S2M2_REQUIRE(cond, ...)                        \
     do {                                               \

@@ -1425,14 +1425,8 @@ template <typename T, int BM, int BN, int WGM, int PPR = 8, int NPF = 1, int NWA
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfg<T, BM, BN, WGM, PPR, NPF, NWAVES>;
     auto kern = conv_igemm_kernel<CFG, T, MODE>;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[current_device()];
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)CFG::LDS_BYTES) != hipSuccess)
-            return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
-        attr_done = true;
-    }
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "conv2d")) return 1;
     const long long M = (long long)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
     hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a);
@@ -1443,14 +1437,8 @@ template <typename T, int BM, int BN, int KP, int NS>
 static int launch_conv2(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfg2<T, BM, BN, KP, NS>;
     auto kern = conv_igemm2_kernel<CFG, T>;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[current_device()];
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)CFG::LDS_BYTES) != hipSuccess)
-            return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
-        attr_done = true;
-    }
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "conv2d")) return 1;
     const long long M = (long long)a.N * a.Ho * a.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((a.Cout + BN - 1) / BN));
     hipLaunchKernelGGL(kern, grid, dim3(256), CFG::LDS_BYTES, st, a);
@@ -1461,14 +1449,8 @@ template <typename T, int BN, int NWAVES = 4, int WGM = 2, int DW = 1>
 static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     using CFG = ConvCfgH<T, BN, NWAVES, WGM, DW>;
     auto kern = conv_halo_kernel<CFG, T>;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[current_device()];
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)CFG::LDS_BYTES) != hipSuccess)
-            return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
-        attr_done = true;
-    }
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "conv2d")) return 1;
     if (a.stride != 1 || a.shuffle2 || a.korder || a.KH > 3 || a.KW > 3) return set_error("conv2d: the halo tile needs a stride-1 kernel of at most 3x3 taps in K order 0");
     const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
     dim3 grid((unsigned)(a.N * tx * ty), (unsigned)((a.Cout + BN - 1) / BN));
@@ -1487,14 +1469,8 @@ static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
         // (two operands of 8 pieces each do not fit the 128-pixel block's register budget: rejected below, the instantiation is a dummy)
         auto kern = naux == 0 ? conv_frag_kernel<CFG, T, 0> : (naux == 2 && PH == 2) ? conv_frag_kernel<CFG, T, (PH == 2 ? 2 : 1)>
                                                                                       : conv_frag_kernel<CFG, T, 1>;
-        static bool attr_done_dev[kMaxDevices][3] = {};
-        bool& attr_done = attr_done_dev[current_device()][naux];
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)CFG::LDS_BYTES) != hipSuccess)
-                return set_error("conv2d: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
-            attr_done = true;
-        }
+        static size_t lds_granted[3][kMaxDevices] = {};                 // per instantiation and epilogue-operand variant
+        if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted[naux], "conv2d")) return 1;
         if (a.stride != 1 || a.shuffle2 || a.KH > 3 || a.KW > 3 || a.KH * a.KW < 2 || a.Cout % BN || a.Cin % 8 || a.ln_wsum)
             return set_error("conv2d: K order 2 needs a stride-1 3x3 / 3x1 / 1x3 layer with Cout a multiple of %d (Cout=%d)", BN, a.Cout);
         if (a.epi == S2M2_EPI_DUALMIX || (PH == 4 && (a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX)))
@@ -1513,13 +1489,8 @@ static int launch_conv_pw(const ConvArgs& a, hipStream_t st) {
     if (a.KH != 1 || a.KW != 1 || a.stride != 1) return set_error("conv2d: the pointwise kernel needs a 1x1 stride-1 layer");
     const size_t lds = CFG::lds_bytes(a.Cin);
     if (lds > 160 * 1024) return set_error("conv2d: pointwise kernel: Cin=%d needs %zu bytes of LDS", a.Cin, lds);
-    static size_t attr_bytes_dev[kMaxDevices] = {};
-    size_t& attr_bytes = attr_bytes_dev[current_device()];
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return set_error("conv2d: cannot reserve %zu bytes of LDS", lds);
-        attr_bytes = lds;
-    }
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), lds, lds_granted, "conv2d")) return 1;
     const long long M = (long long)a.N * a.H * a.W;
     const int ntiles = (int)((M + CFG::BM - 1) / CFG::BM);
     const int per_cu = (int)(160 * 1024 / lds) < 4 ? (int)(160 * 1024 / lds) : 4;      // co-resident blocks per CU

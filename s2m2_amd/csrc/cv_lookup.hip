@@ -28,7 +28,7 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ cv, const float* __restrict__ disp,
                                                         TO* __restrict__ corr1, TO* __restrict__ corr2, int B, int h, int w,
                                                         int radius, long long batch_stride, long long pix_stride,
-                                                        long long tap_stride) {
+                                                        long long tap_stride, int pitch) {
     const int T = 2 * radius + 1;
     const long long total = (long long)B * h * w * 2 * T;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ c
     const int k = level ? t - T : t;
     const float d = disp[pix];
     const float dx = (float)(k - radius);
-    const TI* img = cv + (size_t)rowid * w * w;           // (w rows = left pixel i) x (w cols = right pixel j)
+    const TI* img = cv + (size_t)rowid * w * pitch;       // (w rows = left pixel i, `pitch` elements apart) x (w cols = right pixel j)
 
     float x, wsf;
     int ws;
@@ -60,14 +60,14 @@ __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ c
         const int x0 = (int)x0f, y0 = (int)y0f;
         const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
         if (y0 >= 0 && y0 < w) {
-            const TI* r0 = img + (size_t)y0 * w;
+            const TI* r0 = img + (size_t)y0 * pitch;
             const float a = level ? fetch<TI, 1>(r0, x0, ws) : fetch<TI, 0>(r0, x0, ws);
             const float c = level ? fetch<TI, 1>(r0, x0 + 1, ws) : fetch<TI, 0>(r0, x0 + 1, ws);
             out = out + a * w00;
             out = out + c * w01;
         }
         if (y0 + 1 >= 0 && y0 + 1 < w && wy != 0.0f) {
-            const TI* r1 = img + (size_t)(y0 + 1) * w;
+            const TI* r1 = img + (size_t)(y0 + 1) * pitch;
             const float a = level ? fetch<TI, 1>(r1, x0, ws) : fetch<TI, 0>(r1, x0, ws);
             const float c = level ? fetch<TI, 1>(r1, x0 + 1, ws) : fetch<TI, 0>(r1, x0 + 1, ws);
             out = out + a * w10;
@@ -80,11 +80,11 @@ __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ c
 
 template <typename TI, typename TO>
 static int launch_lookup(const void* cv, const float* disp, void* c1, void* c2, int B, int h, int w, int radius, long long bs,
-                         long long ps, long long ts, hipStream_t st) {
+                         long long ps, long long ts, int pitch, hipStream_t st) {
     const long long total = (long long)B * h * w * 2 * (2 * radius + 1);
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL((cv_lookup_kernel<TI, TO>), dim3(blocks), dim3(256), 0, st, static_cast<const TI*>(cv), disp,
-                       static_cast<TO*>(c1), static_cast<TO*>(c2), B, h, w, radius, bs, ps, ts);
+                       static_cast<TO*>(c1), static_cast<TO*>(c2), B, h, w, radius, bs, ps, ts, pitch);
     return check_launch("cv_lookup");
 }
 
@@ -92,15 +92,17 @@ static int launch_lookup(const void* cv, const float* disp, void* c1, void* c2, 
 
 extern "C" int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2, int B, int h, int w, int radius,
                               int cv_dtype, int out_dtype, long long batch_stride, long long pix_stride, long long tap_stride,
-                              void* stream) {
+                              int cv_pitch, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(cv && disp && corr1 && corr2, "cv_lookup: null pointer");
     S2M2_REQUIRE(B > 0 && h > 0 && w > 1 && radius >= 0 && radius <= 16, "cv_lookup: bad arguments");
     S2M2_REQUIRE(w % 2 == 0, "cv_lookup: w=%d must be even", w);
+    if (cv_pitch == 0) cv_pitch = w;
+    S2M2_REQUIRE(cv_pitch >= w, "cv_lookup: cv_pitch=%d must be at least w=%d", cv_pitch, w);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (cv_dtype == S2M2_F16 && out_dtype == S2M2_F16) return launch_lookup<half_t, half_t>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
-    if (cv_dtype == S2M2_F16 && out_dtype == S2M2_F32) return launch_lookup<half_t, float>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
-    if (cv_dtype == S2M2_F32 && out_dtype == S2M2_F32) return launch_lookup<float, float>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
-    if (cv_dtype == S2M2_F32 && out_dtype == S2M2_F16) return launch_lookup<float, half_t>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, st);
+    if (cv_dtype == S2M2_F16 && out_dtype == S2M2_F16) return launch_lookup<half_t, half_t>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, cv_pitch, st);
+    if (cv_dtype == S2M2_F16 && out_dtype == S2M2_F32) return launch_lookup<half_t, float>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, cv_pitch, st);
+    if (cv_dtype == S2M2_F32 && out_dtype == S2M2_F32) return launch_lookup<float, float>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, cv_pitch, st);
+    if (cv_dtype == S2M2_F32 && out_dtype == S2M2_F16) return launch_lookup<float, half_t>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, cv_pitch, st);
     return set_error("cv_lookup: unsupported dtypes cv=%d out=%d", cv_dtype, out_dtype);
 }

@@ -264,14 +264,8 @@ template <typename T, int C, int BM, int NW, int WP = 4>
 static int launch_fusion(const FusionArgs& a, hipStream_t st) {
     using CFG = FusionCfg<T, C, BM, NW, WP>;
     auto kern = feature_fusion_kernel<CFG, T>;
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[current_device()];
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)CFG::LDS_BYTES) != hipSuccess)
-            return set_error("feature_fusion: cannot reserve %zu bytes of LDS", CFG::LDS_BYTES);
-        attr_done = true;
-    }
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "feature_fusion")) return 1;
     hipLaunchKernelGGL(kern, dim3((unsigned)((a.rows + BM - 1) / BM)), dim3(CFG::NT), CFG::LDS_BYTES, st, a);
     return check_launch("feature_fusion");
 }

@@ -47,8 +47,11 @@ __device__ unsigned long long g_k1_trace[1024 * 16 * 16];
 
 namespace s2m2 {
 
-template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool PIPE_ = false, int TPW_ = 32>
+template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool PIPE_ = false, int TPW_ = 32, bool PRENORM_ = false>
 struct LnCorrCfg {
+    // PRENORM: the tokens arrive normalised (s2m2_corr: DispInit's LayerNorm was folded into the launch that produced them, the
+    // second output of s2m2_mlp_chain) -- no statistics, no affine, the kernel is the batched R . L^T product and its stores
+    static constexpr bool PRENORM = PRENORM_;
     static constexpr bool PIPE = PIPE_;                 // right tokens normalised in 4 rounds, column tiles stored as soon as their tokens exist
     static constexpr int C = C_;
     static constexpr int RIF = RIF_;                    // token rounds (8 tokens per wave each) kept in flight in registers
@@ -88,7 +91,7 @@ template <typename CFG, typename T>
 __device__ __forceinline__ void normalize_store(const Vec16<T> (&p)[CFG::PPL], T* __restrict__ drow,
                                                 const float* __restrict__ gb, int sub, int dbg = 0) {
     constexpr float inv_c = 1.0f / CFG::C;
-    if (dbg & 4) {                                       // ablation: no LayerNorm arithmetic, plain copy
+    if (CFG::PRENORM || (dbg & 4)) {                     // normalised input (or ablation): plain copy into the padded LDS row
 #pragma unroll
         for (int q = 0; q < CFG::PPL; ++q) *reinterpret_cast<Vec16<T>*>(drow + (sub + CFG::LPT * q) * CFG::VEC) = p[q];
         return;
@@ -188,7 +191,7 @@ template <> __device__ __forceinline__ void store_quad<float>(float* dst, float 
 template <typename CFG, typename T, typename TO>
 __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, TO* __restrict__ cv,
-                                                                 int B, int h, int w, int nstrip, int band) {
+                                                                 int B, int h, int w, int nstrip, int band, int pitch) {
     constexpr int dbg = S2M2_LNCORR_DBG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     const bool wave_active = i0 < w;
     const T* left = feat + ((size_t)(b * h + y) * w) * CFG::C;
     const T* right = feat + ((size_t)((B + b) * h + y) * w) * CFG::C;
-    TO* cvrow = cv + (size_t)row * w * w;
+    TO* cvrow = cv + (size_t)row * w * pitch;           // volume rows `pitch` elements apart (>= w; 64-element multiples = whole 128-B lines)
     const int sub = lane & 7, trow = lane >> 3;
     const int TJ = NW * CFG::TPW;                       // right pixels per chunk (the whole row when w <= TJ); a multiple of 32
     const int nchunks = (w + TJ - 1) / TJ;
@@ -217,8 +220,10 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     // ---- everything this wave needs first is put in flight at once: 32 left tokens (+ 32 right tokens of chunk 0)
     static_assert(!CFG::EARLY_B || CFG::ALLRES, "EARLY_B needs every round of a chunk in registers");
     // (the LayerNorm affine goes to LDS first: __syncthreads() drains vmcnt, so no token load may be pending across it)
-    for (int c = tid; c < CFG::C; c += blockDim.x) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
-    __syncthreads();
+    if constexpr (!CFG::PRENORM) {
+        for (int c = tid; c < CFG::C; c += blockDim.x) { gb[c] = gamma[c]; gb[CFG::C + c] = beta[c]; }
+        __syncthreads();
+    }
     K1_T(1);
     Vec16<T> rawB[CFG::RIF][CFG::PPL];
     Frag<T> afrag[CFG::KSTEPS];
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                         const int i = i0 + rr;
                         const int j = j0 + pc * CFG::VECO;
                         const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                        if (i < w && j < w && j < jlim && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
+                        if (i < w && j < w && j < jlim && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * pitch + j) = v;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                     const int i = i0 + rr;
                     const int j = j0 + pc * CFG::VECO;
                     const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                    if (i < w && j < w && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * w + j) = v;
+                    if (i < w && j < w && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * pitch + j) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
                 K1_T(6 + (pp < 8 ? pp : 8));
@@ -441,9 +446,15 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 // at the end of the kernel's execution)
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static thread_local int g_band = -1;                 // s2m2_ln_corr_banded: columns right of the diagonal that must be valid (-1: all)
+static thread_local int g_pitch = 0;                 // s2m2_corr: elements between volume rows (0: w)
 
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st);
+
+// normalised-input variant of a configuration (same tiling)
+template <typename CFG> struct PrenormOf;
+template <typename T, typename TO, int C, int NWCAP, int RIF, bool EB, bool PIPE, int TPW>
+struct PrenormOf<LnCorrCfg<T, TO, C, NWCAP, RIF, EB, PIPE, TPW, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, RIF, EB, PIPE, TPW, true>; };
 
 // pipelined variant of a configuration (same tiling, PIPE = true) where it exists: all four token rounds resident in registers
 template <typename CFG> struct PipeOf { using type = void; };
@@ -453,14 +464,8 @@ struct PipeOf<LnCorrCfg<T, TO, C, NWCAP, 4, true, false, 32>> { using type = LnC
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st) {
     auto kern = ln_corr_kernel<CFG, T, TO>;
-    static bool attr_done_dev[kMaxDevices] = {};                       // per instantiation
-    bool& attr_done = attr_done_dev[current_device()];
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)CFG::lds_bytes(CFG::NWMAX)) != hipSuccess)
-            return set_error("ln_corr: cannot reserve %zu bytes of LDS", CFG::lds_bytes(CFG::NWMAX));
-        attr_done = true;
-    }
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::lds_bytes(CFG::NWMAX), lds_granted, "ln_corr")) return 1;
     const int tiles = (w + 31) / 32;                     // 32-pixel row tiles = waves needed per image row
     int nstrip = (tiles + CFG::NWMAX - 1) / CFG::NWMAX;
     // small problems: split rows into strips until the grid covers the chip (each strip re-normalises the right row)
@@ -471,6 +476,7 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     int nw = (tiles + nstrip - 1) / nstrip;
     nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;
+    const int pitch = g_pitch > 0 ? g_pitch : w;
     if constexpr (!CFG::PIPE && !std::is_void<typename PipeOf<CFG>::type>::value) {
         // measured (tools/k1_ab.py, c3 fp16): 24.2 us pipelined vs 21.3 us plain -- the extra barriers and the smaller store bursts cost
         // more than the overlap returns, so the pipelined variant stays an opt-in experiment
@@ -480,10 +486,10 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     }
     if (g_ev_start || g_ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
-                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band);
+                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch);
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
-                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band);
+                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch);
     return check_launch("ln_corr");
 }
 
@@ -501,10 +507,15 @@ template <> struct LnCorrPick<float, 192>  { template <typename TO> using cfg = 
 template <> struct LnCorrPick<float, 256>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 256, 4, 2, false>; };
 template <> struct LnCorrPick<float, 384>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 384, 4, 1, false>; };
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool PRENORM = false>
 static int dispatch_c(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, int C, hipStream_t st) {
     switch (C) {
-#define S2M2_CASE(CC) case CC: return launch_ln_corr<typename LnCorrPick<T, CC>::template cfg<TO>, T, TO>(feat, g, bta, cv, B, h, w, st);
+#define S2M2_CASE(CC)                                                                                                        \
+    case CC: {                                                                                                               \
+        using BASE = typename LnCorrPick<T, CC>::template cfg<TO>;                                                           \
+        using CFG = typename std::conditional<PRENORM, typename PrenormOf<BASE>::type, BASE>::type;                          \
+        return launch_ln_corr<CFG, T, TO>(feat, g, bta, cv, B, h, w, st);                                                    \
+    }
         S2M2_CASE(64) S2M2_CASE(128) S2M2_CASE(192) S2M2_CASE(256) S2M2_CASE(384)
 #undef S2M2_CASE
         default: return set_error("ln_corr: unsupported channel count C=%d (supported: 64,128,192,256,384)", C);
@@ -541,6 +552,29 @@ extern "C" int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const fl
     s2m2::g_band = band;
     const int rc = s2m2_ln_corr_timed(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream, start_event, stop_event);
     s2m2::g_band = -1;
+    return rc;
+}
+
+extern "C" int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
+                         void* stream, void* start_event, void* stop_event) {
+    using namespace s2m2;
+    S2M2_REQUIRE(tokens && cv, "corr: null pointer");
+    S2M2_REQUIRE(B > 0 && h > 0 && w > 0 && w % 8 == 0, "corr: bad shape B=%d h=%d w=%d (w a multiple of 8)", B, h, w);
+    if (cv_pitch == 0) cv_pitch = w;
+    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "corr: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    g_ev_start = static_cast<hipEvent_t>(start_event);
+    g_ev_stop = static_cast<hipEvent_t>(stop_event);
+    g_band = band >= 0 ? band : -1;
+    g_pitch = cv_pitch;
+    int rc;
+    if (token_dtype == S2M2_F16 && cv_dtype == S2M2_F16) rc = dispatch_c<half_t, half_t, true>(tokens, nullptr, nullptr, cv, B, h, w, C, st);
+    else if (token_dtype == S2M2_F16 && cv_dtype == S2M2_F32) rc = dispatch_c<half_t, float, true>(tokens, nullptr, nullptr, cv, B, h, w, C, st);
+    else if (token_dtype == S2M2_F32 && cv_dtype == S2M2_F32) rc = dispatch_c<float, float, true>(tokens, nullptr, nullptr, cv, B, h, w, C, st);
+    else rc = set_error("corr: unsupported dtype pair tokens=%d cv=%d", token_dtype, cv_dtype);
+    g_ev_start = g_ev_stop = nullptr;
+    g_band = -1;
+    g_pitch = 0;
     return rc;
 }
 

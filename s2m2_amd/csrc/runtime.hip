@@ -1,6 +1,8 @@
 // Host-side runtime glue of libs2m2_hip.so: version, thread-local error text, launch checks.
 #include "common.h"
 
+#include <mutex>
+
 namespace s2m2 {
 
 static thread_local char g_err[512] = "";
@@ -27,8 +29,25 @@ int current_device() {
 
 // 256 zero bytes per device (source of the padding / tail pieces of the GEMM loaders), allocated on the first call on that device
 // -- before any graph capture: the engine warms up eagerly
+static std::mutex& host_mutex() {
+    static std::mutex m;
+    return m;
+}
+
+int reserve_lds(const void* func, size_t bytes, size_t* granted, const char* what) {
+    std::lock_guard<std::mutex> lock(host_mutex());
+    size_t& g = granted[current_device()];
+    if (bytes > g) {
+        if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+            return set_error("%s: cannot reserve %zu bytes of LDS", what, bytes);
+        g = bytes;
+    }
+    return 0;
+}
+
 const void* zero_page() {
     static void* z[kMaxDevices] = {};
+    std::lock_guard<std::mutex> lock(host_mutex());
     void*& p = z[current_device()];
     if (!p) {
         if (hipMalloc(&p, 256) != hipSuccess || hipMemset(p, 0, 256) != hipSuccess) p = nullptr;
@@ -46,18 +65,30 @@ __global__ __launch_bounds__(256) void poison_lds_kernel(unsigned* sink, int wor
     if (sink && lds[(threadIdx.x * 37) % words] != 0x7fc00000u) sink[0] = 1u;      // keeps the stores alive
 }
 
+// measurement aid: one lane stamps the shader-clock counter (s_memtime: ticks at the CU's CURRENT engine clock) and the constant 100 MHz
+// real-time counter (s_memrealtime).  Two probes on one stream around a region give the average engine clock the region ran at --
+// how tools/clock_probe.py tells a clock-limited (power-managed) in-forward kernel time from an idle-chip micro-benchmark.
+__global__ void clock_probe_kernel(unsigned long long* out) {
+    if (threadIdx.x == 0) {
+        out[0] = __builtin_amdgcn_s_memtime();
+        out[1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 }  // namespace s2m2
+
+extern "C" int s2m2_debug_clock_probe(void* out, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(out, "debug_clock_probe: null pointer");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<unsigned long long*>(out));
+    return check_launch("debug_clock_probe");
+}
 
 extern "C" int s2m2_debug_poison_lds(void* stream) {
     using namespace s2m2;
     constexpr int kBytes = 160 * 1024;                            // one block owns a CU's whole LDS; 4 blocks per CU's worth of grid
-    static bool attr_done_dev[kMaxDevices] = {};
-    bool& attr_done = attr_done_dev[current_device()];
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(poison_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kBytes) != hipSuccess)
-            return set_error("debug_poison_lds: cannot reserve %d bytes of LDS", kBytes);
-        attr_done = true;
-    }
+    static size_t granted[kMaxDevices] = {};
+    if (reserve_lds(reinterpret_cast<const void*>(poison_lds_kernel), kBytes, granted, "debug_poison_lds")) return 1;
     hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), kBytes, static_cast<hipStream_t>(stream), (unsigned*)nullptr, kBytes / 4);
     return check_launch("debug_poison_lds");
 }

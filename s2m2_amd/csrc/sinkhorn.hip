@@ -70,7 +70,7 @@ template <int GL> __device__ __forceinline__ int group_min_i(int x) {
 template <typename TI, int NWV, int GL, int NCH>
 __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __restrict__ cv, float* __restrict__ disp,
                                                                     float* __restrict__ conf, float* __restrict__ occ,
-                                                                    int32_t* __restrict__ amax, int w, int ot_iter, int use_pos) {
+                                                                    int32_t* __restrict__ amax, int w, int ot_iter, int use_pos, int pitch) {
     constexpr int VEC = 16 / sizeof(TI);
     constexpr int PPC = 8 / VEC;                           // 16-byte pieces per lane and chunk (8 columns)
     constexpr int CW = 8 * GL;                             // columns per chunk
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = lane / GL, pl = lane % GL;             // row group inside the wave, position inside the group
-    const TI* S = cv + (size_t)blockIdx.x * w * w;
+    const TI* S = cv + (size_t)blockIdx.x * w * pitch;          // volume rows `pitch` elements apart (>= w, multiple of 8)
     const float log_row = -__logf(2.0f * w);               // log(1/(2w))   marginal of a regular row/column
     const float log_bin = __logf(0.5f);                    // log(w/(2w))   marginal of the dustbin
     const float log2w = __logf(2.0f * w);
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 
     // row i (i == w: the dustbin row, S = 0, never masked): raw 16-byte pieces of the lane's columns j = c*CW + pl*8 + 0..7
     auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
-        const TI* Si = S + (size_t)(i < w ? i : 0) * w;
+        const TI* Si = S + (size_t)(i < w ? i : 0) * pitch;
         const int jend = i < w ? (use_pos ? i + 1 : w) : 0;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                 bj = group_min_i<GL>(best == bmax ? bj : 0x7fffffff);
                 const float mass = srow * gsc;
                 // 5 taps around the argmax, evaluated by lanes 0..4 of the group (zero outside [0,w) and in the masked triangle)
-                const TI* Si = S + (size_t)i * w;
+                const TI* Si = S + (size_t)i * pitch;
                 const int jj = bj + pl - 2;
                 float pk = 0.f;
                 if (pl < 5 && jj >= 0 && jj < jend) pk = __expf(to_f32(Si[jj]) + ci + v[jj]);
@@ -339,33 +339,28 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 
 template <typename TI, int GL, int NCH>
 static int launch_sinkhorn(const void* cv, float* disp, float* conf, float* occ, int32_t* amax, int rows, int w, int ot_iter,
-                           int use_pos, hipStream_t st) {
+                           int use_pos, int pitch, hipStream_t st) {
     // 16 waves per row block where a lane's state (8 * NCH columns: values + two accumulator words each) fits 128 registers, else 8
     constexpr int NWV = NCH == 1 ? 16 : 8;
     auto kern = sinkhorn_regress_kernel<TI, NWV, GL, NCH>;
     const size_t lds = (size_t)(2 + 2 * NWV) * ((w + 4) & ~3) * sizeof(float) + 16;
     if (lds > 160 * 1024) return set_error("sinkhorn: w=%d needs %zu bytes of LDS (at most about w = 1200)", w, lds);
-    static size_t attr_bytes_dev[kMaxDevices] = {};
-    size_t& attr_bytes = attr_bytes_dev[current_device()];
-    if (lds > attr_bytes) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return set_error("sinkhorn: cannot reserve %zu bytes of LDS", lds);
-        attr_bytes = lds;
-    }
-    hipLaunchKernelGGL(kern, dim3(rows), dim3(NWV * 64), lds, st, static_cast<const TI*>(cv), disp, conf, occ, amax, w, ot_iter, use_pos);
+    static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
+    if (reserve_lds(reinterpret_cast<const void*>(kern), lds, lds_granted, "sinkhorn")) return 1;
+    hipLaunchKernelGGL(kern, dim3(rows), dim3(NWV * 64), lds, st, static_cast<const TI*>(cv), disp, conf, occ, amax, w, ot_iter, use_pos, pitch);
     return check_launch("sinkhorn_regress");
 }
 
 // lanes per row so that a row needs at most 3 chunks of 8 columns per lane: 16 lanes up to w = 384, 32 up to 768, 64 up to 1536
 template <typename TI>
 static int dispatch_ppl(const void* cv, float* disp, float* conf, float* occ, int32_t* amax, int rows, int w, int ot_iter,
-                        int use_pos, hipStream_t st) {
+                        int use_pos, int pitch, hipStream_t st) {
 #define S2M2_K2(GL)                                                                                                          \
     {                                                                                                                        \
         const int nch = (w + 8 * GL - 1) / (8 * GL);                                                                         \
-        if (nch <= 1) return launch_sinkhorn<TI, GL, 1>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
-        if (nch <= 2) return launch_sinkhorn<TI, GL, 2>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
-        if (nch <= 3) return launch_sinkhorn<TI, GL, 3>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, st);          \
+        if (nch <= 1) return launch_sinkhorn<TI, GL, 1>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
+        if (nch <= 2) return launch_sinkhorn<TI, GL, 2>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
+        if (nch <= 3) return launch_sinkhorn<TI, GL, 3>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
     }
     // (measured at w = 304: 32 lanes per row x 16 waves, 91.7 us, is no faster than 16 lanes x 8 waves, 90.4 us -- the row chain, not
     // the number of resident waves, sets the pace)
@@ -384,14 +379,16 @@ extern "C" size_t s2m2_sinkhorn_workspace_bytes(int B, int h, int w, int cv_dtyp
 }
 
 extern "C" int s2m2_sinkhorn_regress(const void* cv, float* disp, float* conf, float* occ, int32_t* argmax, int B, int h, int w,
-                                     int ot_iter, int use_positivity, int cv_dtype, void* workspace, void* stream) {
+                                     int ot_iter, int use_positivity, int cv_dtype, int cv_pitch, void* workspace, void* stream) {
     using namespace s2m2;
     (void)workspace;
     S2M2_REQUIRE(cv && disp && conf && occ, "sinkhorn: null pointer");
     S2M2_REQUIRE(B > 0 && h > 0 && w > 0 && ot_iter >= 1, "sinkhorn: bad arguments B=%d h=%d w=%d ot_iter=%d", B, h, w, ot_iter);
     S2M2_REQUIRE(w % 8 == 0, "sinkhorn: w=%d must be a multiple of 8 (image width multiple of 32)", w);
+    if (cv_pitch == 0) cv_pitch = w;
+    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "sinkhorn: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (cv_dtype == S2M2_F16) return dispatch_ppl<half_t>(cv, disp, conf, occ, argmax, B * h, w, ot_iter, use_positivity, st);
-    if (cv_dtype == S2M2_F32) return dispatch_ppl<float>(cv, disp, conf, occ, argmax, B * h, w, ot_iter, use_positivity, st);
+    if (cv_dtype == S2M2_F16) return dispatch_ppl<half_t>(cv, disp, conf, occ, argmax, B * h, w, ot_iter, use_positivity, cv_pitch, st);
+    if (cv_dtype == S2M2_F32) return dispatch_ppl<float>(cv, disp, conf, occ, argmax, B * h, w, ot_iter, use_positivity, cv_pitch, st);
     return set_error("sinkhorn: unsupported cv dtype %d", cv_dtype);
 }

@@ -52,8 +52,10 @@ MAX_PIXELS = 1 << 24            # K5 addresses N*H*W pixels of one tensor with 2
 LDS_BYTES = 160 * 1024
 
 
-def check_limits(H: int, W: int, C: int) -> None:
-    """Geometry limits of the kernel library, validated before the first launch (they raise inside the C ABI otherwise)."""
+def check_limits(H: int, W: int, C: int, B: int = 1, dtype: Optional[torch.dtype] = None) -> None:
+    """Geometry limits of the kernel library, validated before the first launch (they raise inside the C ABI otherwise).  With a
+    dtype the positional-encoding attention of the feature pyramid (2B images, 8 heads of C/4 channels on the 1/32 token grid:
+    marginal-bin tiles + sinc tables next to the K/V stages in 160 KB of LDS) is planned by the library itself."""
     if C not in (64, 128, 192, 256, 384):
         raise ValueError(f"feature_channels={C}: K1 is instantiated for 64, 128, 192, 256 and 384 channels")
     if 2 * H * W >= MAX_PIXELS:
@@ -61,6 +63,11 @@ def check_limits(H: int, W: int, C: int) -> None:
     w = W // 4
     if (2 + 2 * 16) * (w + 1) * 4 > LDS_BYTES:
         raise ValueError(f"image width {W}: K2 keeps a cost-volume row's potentials in LDS, at most {4 * (LDS_BYTES // 136 - 1)} px wide")
+    if dtype is not None:
+        gh, gw = H // 32, W // 32
+        ok, why = hip.attention_supported(2 * min(B, max_batch(H, W)), 8, gh * gw, C // 4, dtype, grid=(gw, gh))
+        if not ok:
+            raise ValueError(f"{W}x{H}: the positional-encoding attention at 1/32 resolution does not take a {gw}x{gh} token grid ({why})")
 
 
 def max_batch(H: int, W: int) -> int:
@@ -101,6 +108,9 @@ class Engine:
         # opt-in: banded cost volume (columns j <= i + 11) for use_positivity models.  Off by default: the reference's DispInit hands
         # out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward (measured: profiles/r02/kbench.txt)
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
+        self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
+        self.cv_aligned = os.environ.get("S2M2_CV_ALIGNED", "1") != "0"  # A/B switch: 0 = dense cost-volume rows (pitch = w)
+        self._tokens_normed: Optional[Tensor] = None
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
@@ -319,14 +329,18 @@ class Engine:
             self._wsum[wp.data_ptr()] = ws
         return ws
 
-    def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor) -> Tensor:
+    def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor, ln_out=None) -> Tensor:
         """z' = z + proj(o);  z' + ffn.2(GELU(ffn.0(LayerNorm(z')))) (attentions.py:311-321,347-355): one K9 launch when the width
-        is supported, else three K5 launches (pre-LN folded into the first FFN layer)."""
+        is supported, else three K5 launches (pre-LN folded into the first FFN layer).  ln_out = (gamma, beta, eps): the K9 launch also
+        writes LayerNorm(result) * gamma + beta (kept in ``self._tokens_normed`` for K1, see features())."""
         c = z.shape[-1]
         proj, f0, f2 = self.std(pa + ".attn.proj"), self.std(pf + ".ffn.0"), self.std(pf + ".ffn.2")
         if self.use_chain and self.chain_ok(c):
-            return hip.mlp_chain(o, [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)),
-                                     (f2[0], f2[1], hip.ACT_NONE, None)], res=z, res_stage=0, carry=True)
+            stages = [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)), (f2[0], f2[1], hip.ACT_NONE, None)]
+            if ln_out is not None and hip.mlp_chain_ln_out_supported(c, self.dtype):
+                out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out)
+                return out
+            return hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True)
         z = self.cconv(proj, [o], epi=hip.EPI_ADD, aux0=z)
         if self.fuse_ln:
             hdn = self.cconv(f0, [z], ln=True, act=hip.ACT_GELU)
@@ -340,11 +354,11 @@ class Engine:
             ok = self._chain_ok[c] = hip.mlp_chain_supported(c, self.dtype)
         return ok
 
-    def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False) -> Tensor:
-        """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321)."""
+    def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False, ln_out=None) -> Tensor:
+        """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321).  ln_out: see attn_ffn (last launch of the block)."""
         if (p + ".cross_attn.attn.q.weight") in self.p:
             z = self.attn_ffn(p + ".cross_attn", p + ".ffn_c", self.attn_core(p + ".cross_attn", z, nh, two_d, True, False), z)
-        return self.attn_ffn(p + ".self_attn", p + ".ffn", self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe), z)
+        return self.attn_ffn(p + ".self_attn", p + ".ffn", self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe), z, ln_out=ln_out)
 
     def _count(self, prefix: str) -> int:
         n = 0
@@ -368,7 +382,7 @@ class Engine:
         n0 = self.conv_block(p + ".dec0", self.fusion_up(p + ".concat_conv0", z0, p + ".up_conv0", n1))
         return n0, n1, n2, z3
 
-    def mrt(self, p: str, z0: Tensor, z1: Tensor, z2: Tensor, z3: Tensor):
+    def mrt(self, p: str, z0: Tensor, z1: Tensor, z2: Tensor, z3: Tensor, ln_out=None):
         z0 = self.attn_block(p + ".enc_attn0", z0, 1, False)
         z1 = self.attn_block(p + ".enc_attn1", self.fusion(p + ".down_concat1", z1, self.down(p + ".down_conv0", z0)), 2, False)
         z2 = self.attn_block(p + ".enc_attn2", self.fusion(p + ".down_concat2", z2, self.down(p + ".down_conv1", z1)), 4, False)
@@ -379,7 +393,7 @@ class Engine:
             z3 = self.attn_block(f"{p}.dec_attn3s.{i}", z3, 8, True)
         z2 = self.attn_block(p + ".dec_attn2", self.fusion_up(p + ".up_concat2", z2, p + ".up_conv2", z3), 4, False)
         z1 = self.attn_block(p + ".dec_attn1", self.fusion_up(p + ".up_concat1", z1, p + ".up_conv1", z2), 2, False)
-        z0 = self.attn_block(p + ".dec_attn0", self.fusion_up(p + ".up_concat0", z0, p + ".up_conv0", z1), 1, False)
+        z0 = self.attn_block(p + ".dec_attn0", self.fusion_up(p + ".up_concat0", z0, p + ".up_conv0", z1), 1, False, ln_out=ln_out)
         return z0, z1, z2, z3
 
     # ---- refiners ------------------------------------------------------------------------------------
@@ -477,19 +491,35 @@ class Engine:
         f4 = self.cconv(self.std(p + ".conv2_down.0", frag=False), [f2], stride=2)
         py = self.unet("feat_pyramid", f4)
         z = py
+        # DispInit's LayerNorm (submodules.py:165,216) is folded into the launch that writes feature_tr_4x -- the last K9 chain of the
+        # last transformer -- as a second output; K1 then is the correlation alone (hip.corr).  A/B switch S2M2_FUSE_K1LN=0: K1 with
+        # its own LayerNorm (hip.ln_corr), as for the widths whose chain has no LayerNorm output (C = 192, 384).
+        self._tokens_normed = None
         for i in range(self.ntr):
-            z = self.mrt(f"transformer.uformer_list.{i}", *z)
+            last = i == self.ntr - 1 and self.fuse_k1ln
+            z = self.mrt(f"transformer.uformer_list.{i}", *z, ln_out=(self.ln_w, self.ln_b, 1e-5) if last else None)
         return z[0], py[0], f2[:B], x8[:B]                                      # tokens (2B,h,w,C), pyramid 1/4, left 1/2 features, image
 
     @torch.no_grad()
-    def cost_volume(self, tr: Tensor, out: Optional[Tensor] = None, banded: bool = True) -> Tensor:
-        """K1: LayerNorm + all-pairs correlation (submodules.py:216-217).  With ``k1_events`` set (bench.py) every launch carries a
-        start / stop HIP event pair on its dispatch (hip.KernelTimer), collected in that list."""
+    def cost_volume(self, tr: Tensor, out: Optional[Tensor] = None, banded: bool = True, normed: Optional[Tensor] = None) -> Tensor:
+        """K1: LayerNorm + all-pairs correlation (submodules.py:216-217); ``normed``: the tokens already normalised by the launch
+        that produced ``tr`` (features()) -> the correlation alone.  The volume's rows start on 128-byte lines (hip.cv_alloc; a
+        ``[..., :w]`` view of a padded allocation that K2 / K3 read with its pitch).  With ``k1_events`` set (bench.py) every launch
+        carries a start / stop HIP event pair on its dispatch (hip.KernelTimer), collected in that list."""
         timer = None
         if self.k1_events is not None:
             timer = hip.KernelTimer()
             self.k1_events.append(timer)
-        return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer, band=self.cv_band if banded else -1)
+        band = self.cv_band if banded else -1
+        if normed is not None:
+            if out is None:
+                out = self.cv_buffer(tr)
+            return hip.corr(normed, out=out, timer=timer, band=band)
+        return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer, band=band)
+
+    def cv_buffer(self, tr: Tensor) -> Tensor:
+        twoB, h, w, _ = tr.shape
+        return hip.cv_alloc(twoB // 2, h, w, tr.dtype, tr.device, aligned=self.cv_aligned)
 
     @torch.no_grad()
     def finish(self, tr: Tensor, py0: Tensor, f2_left: Tensor, x8: Tensor, cv: Tensor, cap: Optional[dict] = None):
@@ -535,9 +565,11 @@ class Engine:
     @torch.no_grad()
     def run(self, img0: Tensor, img1: Tensor, cap: Optional[dict] = None):
         tr, py0, f2_left, x8 = self.features(img0, img1)
+        normed = self._tokens_normed
         if cap is not None and "feature_tr_4x" in (cap.get("inject") or {}):           # parity tests only, see finish()
             tr = cap["inject"]["feature_tr_4x"].to(tr.device, tr.dtype).permute(0, 2, 3, 1).contiguous()
-        cv = self.cost_volume(tr, banded=cap is None)             # captured runs hand out the full volume, like the reference
+            normed = None                                         # injected tokens: K1 normalises them itself
+        cv = self.cost_volume(tr, banded=cap is None, normed=normed)   # captured runs hand out the full volume, like the reference
         return self.finish(tr, py0, f2_left, x8, cv, cap)
 
     def _conv0(self) -> Spec:
@@ -585,8 +617,9 @@ class GraphRunner:
             with torch.cuda.graph(self.ga, capture_error_mode=mode):
                 self.state = eng.features(self.l, self.r)
             tr = self.state[0]
-            self.cv = torch.empty((B, tr.shape[1], tr.shape[2], tr.shape[2]), device=dev, dtype=tr.dtype)
-            eng.cost_volume(tr, out=self.cv)
+            self.normed = eng._tokens_normed
+            self.cv = eng.cv_buffer(tr) if self.normed is not None else torch.empty((B, tr.shape[1], tr.shape[2], tr.shape[2]), device=dev, dtype=tr.dtype)
+            eng.cost_volume(tr, out=self.cv, normed=self.normed)
             self.gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.gb, pool=self.ga.pool(), capture_error_mode=mode):
                 self.out = eng.finish(*self.state, self.cv)
@@ -599,7 +632,7 @@ class GraphRunner:
         else:
             eng = self.eng
             self.ga.replay()
-            eng.cost_volume(self.state[0], out=self.cv)                # eager between the two graphs: carries the timing events
+            eng.cost_volume(self.state[0], out=self.cv, normed=self.normed)   # eager between the two graphs: carries the timing events
             self.gb.replay()
         base = self.out[0]._base                                   # the three maps are slices of one allocation (hip.convex_upsample)
         if base is not None and all(o._base is base for o in self.out):

@@ -39,7 +39,8 @@ class ChainDesc(ctypes.Structure):
     """mirror of s2m2_chain_desc (include/s2m2_hip.h)"""
     _fields_ = [("x", _vp), ("res", _vp), ("out", _vp), ("x_stride", _ll), ("res_stride", _ll), ("out_stride", _ll), ("rows", _ll),
                 ("C", _i), ("nstage", _i), ("weight", _vp * 3), ("bias", _vp * 3), ("ln_wsum", _vp * 3), ("act", _i * 3),
-                ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i)]
+                ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
+                ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -54,8 +55,9 @@ SIGNATURES = {
     "s2m2_event_destroy": (_i, [_vp]),
     "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "s2m2_sinkhorn_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
-    "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
-    "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _vp]),
+    "s2m2_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
     "s2m2_mlp_chain_supported": (_i, [_i, _i]),
     "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
@@ -64,12 +66,14 @@ SIGNATURES = {
     "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _ll, _i, _vp]),
     "s2m2_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _ll,
                             _i, _i, _i, _vp]),
+    "s2m2_attention_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "s2m2_resample2x": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _ll, _i, _i, _vp]),
     "s2m2_image_prep": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "s2m2_refine_prep": (_i, [_vp, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_global_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _vp]),
     "s2m2_refine_update": (_i, [_vp, _i, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "s2m2_debug_poison_lds": (_i, [_vp]),
+    "s2m2_debug_clock_probe": (_i, [_vp, _vp]),
     "s2m2_refine_update_to": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _i, _i, _vp]),
     "s2m2_tanh": (_i, [_vp, _vp, _ll, _i, _vp]),
     "s2m2_stem_mlp": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
@@ -173,22 +177,60 @@ def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype
     return cv
 
 
+def _cv_pitch(cv: torch.Tensor, what: str) -> int:
+    """(B,h,w,w) cost volume, columns contiguous, volume rows ``pitch`` elements apart (a padded allocation viewed ``[..., :w]``, or
+    plain contiguous: pitch = w), image rows and batch entries dense behind that."""
+    if cv.dim() != 4 or not cv.is_cuda or cv.shape[2] != cv.shape[3]:
+        raise ValueError(f"{what}: cv must be a (B,h,w,w) device tensor, got {tuple(cv.shape)}")
+    B, h, w, _ = cv.shape
+    pitch = cv.stride(2)
+    if cv.stride(3) != 1 or pitch < w or pitch % 8 or (h > 1 and cv.stride(1) != w * pitch) or (B > 1 and cv.stride(0) != h * w * pitch):
+        raise ValueError(f"{what}: cv strides {cv.stride()} are not a row-padded (B,h,w,w) volume")
+    return pitch
+
+
+def cv_alloc(B: int, h: int, w: int, dtype: torch.dtype, device, aligned: bool = True) -> torch.Tensor:
+    """(B,h,w,w) cost volume whose rows start on 128-byte lines: allocated (B,h,w,pitch) with pitch = w rounded up to 128 bytes and
+    returned as the ``[..., :w]`` view (K1's 64-column store granules are then whole lines: no partial-line writes)."""
+    per = 128 // (2 if dtype == torch.float16 else 4)
+    pitch = (w + per - 1) // per * per if aligned else w
+    return torch.empty((B, h, w, pitch), device=device, dtype=dtype)[..., :w]
+
+
+def corr(tokens: torch.Tensor, cv_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
+         timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
+    """tokens (2B,h,w,C) ALREADY LayerNorm'ed (left = first B) -> cv (B,h,w,w), a row-padded view (cv_alloc) unless ``out`` is given.
+    [A4 without the LayerNorm: s2m2_corr]"""
+    _dev(tokens)
+    twoB, h, w, C = tokens.shape
+    B = twoB // 2
+    cv = out if out is not None else cv_alloc(B, h, w, cv_dtype or tokens.dtype, tokens.device)
+    if tuple(cv.shape) != (B, h, w, w):
+        raise ValueError("corr: out must be a (B,h,w,w) tensor")
+    pitch = _cv_pitch(cv, "corr")
+    _check(load().s2m2_corr(tokens.data_ptr(), cv.data_ptr(), B, h, w, C, pitch, _DT[tokens.dtype], _DT[cv.dtype], band, _stream(),
+                            timer.start if timer is not None else None, timer.stop if timer is not None else None), "s2m2_corr")
+    _meter("ln_corr", 2.0 * B * h * w * w * C)
+    return cv
+
+
 def sinkhorn_regress(cv: torch.Tensor, use_positivity: bool, ot_iter: int = 3, want_argmax: bool = False):
-    """cv (B,h,w,w) -> disp, conf, occ (B,1,h,w) fp32 [, argmax (B,h,w) int32].  [A5+A6]"""
-    _dev(cv)
+    """cv (B,h,w,w) (row-padded views accepted) -> disp, conf, occ (B,1,h,w) fp32 [, argmax (B,h,w) int32].  [A5+A6]"""
+    pitch = _cv_pitch(cv, "sinkhorn_regress")
     B, h, w, _ = cv.shape
     out = torch.empty((3, B, 1, h, w), device=cv.device, dtype=torch.float32)
     am = torch.empty((B, h, w), device=cv.device, dtype=torch.int32) if want_argmax else None
     _check(load().s2m2_sinkhorn_regress(cv.data_ptr(), out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                         am.data_ptr() if am is not None else None, B, h, w, ot_iter, int(use_positivity),
-                                        _DT[cv.dtype], None, _stream()), "s2m2_sinkhorn_regress")
+                                        _DT[cv.dtype], pitch, None, _stream()), "s2m2_sinkhorn_regress")
     return (out[0], out[1], out[2], am) if want_argmax else (out[0], out[1], out[2])
 
 
 def cv_lookup(cv: torch.Tensor, disp: torch.Tensor, radius: int = 4, channels_last: bool = False,
               out_dtype: torch.dtype = torch.float32) -> Tuple[torch.Tensor, torch.Tensor]:
     """cv (B,h,w,w), disp (B,1,h,w) fp32 -> corr1, corr2: (B,2r+1,h,w) planar or (B,h,w,2r+1) channels-last.  [A9+A10]"""
-    _dev(cv, disp)
+    _dev(disp)
+    pitch = _cv_pitch(cv, "cv_lookup")
     B, h, w, _ = cv.shape
     T = 2 * radius + 1
     if channels_last:
@@ -200,7 +242,7 @@ def cv_lookup(cv: torch.Tensor, disp: torch.Tensor, radius: int = 4, channels_la
         c1, c2 = both[0], both[1]
         bs, ps, ts = T * h * w, 1, h * w
     _check(load().s2m2_cv_lookup(cv.data_ptr(), disp.float().data_ptr(), c1.data_ptr(), c2.data_ptr(), B, h, w, radius,
-                                 _DT[cv.dtype], _DT[out_dtype], bs, ps, ts, _stream()), "s2m2_cv_lookup")
+                                 _DT[cv.dtype], _DT[out_dtype], bs, ps, ts, pitch, _stream()), "s2m2_cv_lookup")
     return c1, c2
 
 
@@ -303,11 +345,17 @@ def mlp_chain_supported(C: int, dtype: torch.dtype) -> bool:
     return bool(load().s2m2_mlp_chain_supported(C, _DT[dtype]))
 
 
+def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
+    """the optional LayerNorm output of mlp_chain needs a row of 16 / 32 / 64 16-byte pieces"""
+    return mlp_chain_supported(C, dtype) and C * (2 if dtype == torch.float16 else 4) // 16 in (16, 32, 64)
+
+
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
-              ln_eps: float = 1e-5) -> torch.Tensor:
+              ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
-    res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages."""
+    res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
+    ln_out = (gamma fp32 (C), beta fp32 (C), eps): also return LayerNorm(out) * gamma + beta  -> (out, normalised)."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_chain")
     d = ChainDesc()
@@ -334,9 +382,17 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
         d.res, d.res_stride = res.data_ptr(), _token_rows(res, "mlp_chain")[1]
     out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
     d.out, d.out_stride = out.data_ptr(), C
+    normed = None
+    if ln_out is not None:
+        gam, bet, eps = ln_out
+        _dev(gam, bet)
+        if gam.dtype != torch.float32 or bet.dtype != torch.float32 or gam.numel() != C or bet.numel() != C:
+            raise ValueError(f"mlp_chain: ln_out gamma / beta must be fp32 ({C})")
+        normed = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+        d.ln_out, d.ln_out_stride, d.ln_gamma, d.ln_beta, d.ln_out_eps = normed.data_ptr(), C, gam.data_ptr(), bet.data_ptr(), float(eps)
     _check(load().s2m2_mlp_chain(ctypes.byref(d), _stream()), "s2m2_mlp_chain")
     _meter("mlp_chain", 2.0 * rows * C * C * len(stages))
-    return out
+    return out if normed is None else (out, normed)
 
 
 def feature_fusion_supported(C: int, dtype: torch.dtype) -> bool:
@@ -462,6 +518,14 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, swa
     return (out, pe_out) if pe is not None else out
 
 
+def attention_supported(nb: int, heads: int, N: int, D: int, dtype: torch.dtype, grid: Optional[Tuple[int, int]] = None) -> Tuple[bool, str]:
+    """Would s2m2_attention take this launch?  grid = (w, h) of the token grid for the PE variant.  -> (ok, reason)."""
+    gw, gh = grid if grid is not None else (0, 0)
+    lib = load()
+    ok = bool(lib.s2m2_attention_supported(nb, heads, N, D, gw, gh, _DT[dtype]))
+    return ok, ("" if ok else lib.s2m2_last_error().decode())
+
+
 def resample2x(x: torch.Tensor, mode: int) -> torch.Tensor:
     """(N,H,W,C) -> AvgPool2d(2) (mode 0) or bilinear x2, align_corners=False (mode 1)."""
     n, h, w, c = x.shape
@@ -474,12 +538,13 @@ def resample2x(x: torch.Tensor, mode: int) -> torch.Tensor:
 def cv_lookup_into(cv: torch.Tensor, disp: torch.Tensor, buf: torch.Tensor, off1: int, off2: int, radius: int = 4) -> None:
     """K3 writing straight into channel slots of a wider NHWC tensor: taps of level 0 -> buf[..., off1:off1+2r+1], level 1 ->
     buf[..., off2:off2+2r+1] (buf (B,h,w,Cb) contiguous; the other channels are left untouched)."""
-    _dev(cv, disp, buf)
+    _dev(disp, buf)
+    pitch = _cv_pitch(cv, "cv_lookup")
     B, h, w, _ = cv.shape
     cb = buf.shape[-1]
     es = buf.element_size()
     _check(load().s2m2_cv_lookup(cv.data_ptr(), disp.data_ptr(), buf.data_ptr() + off1 * es, buf.data_ptr() + off2 * es, B, h, w,
-                                 radius, _DT[cv.dtype], _DT[buf.dtype], h * w * cb, cb, 1, _stream()), "s2m2_cv_lookup")
+                                 radius, _DT[cv.dtype], _DT[buf.dtype], h * w * cb, cb, 1, pitch, _stream()), "s2m2_cv_lookup")
 
 
 _IMG_DT = {torch.float32: 0, torch.float16: 1, torch.uint8: 2}
@@ -497,6 +562,12 @@ def image_prep(img0: torch.Tensor, img1: torch.Tensor, dtype: torch.dtype) -> to
     _check(load().s2m2_image_prep(img0.data_ptr(), img1.data_ptr(), x8.data_ptr(), B, H, W, _IMG_DT[img0.dtype], _DT[dtype], _stream()),
            "s2m2_image_prep")
     return x8
+
+
+def clock_probe(out: torch.Tensor) -> None:
+    """Measurement aid: out (2,) int64 device tensor <- {shader-clock ticks, 100 MHz real-time ticks} when the stream reaches this point."""
+    _dev(out)
+    _check(load().s2m2_debug_clock_probe(out.data_ptr(), _stream()), "s2m2_debug_clock_probe")
 
 
 def poison_lds() -> None:

@@ -142,7 +142,7 @@ class S2M2(nn.Module):
         if img0.shape[-1] % 32 or img0.shape[-2] % 32:
             raise ValueError("image height and width must be multiples of 32 (pad with image_pad first)")
         from .engine import GraphRunner, check_limits, max_batch
-        check_limits(img0.shape[2], img0.shape[3], self.feature_channels)
+        check_limits(img0.shape[2], img0.shape[3], self.feature_channels, img0.shape[0], dtype)
         nb = max_batch(img0.shape[2], img0.shape[3])
         if img0.shape[0] > nb:                                   # K5 indexes pixels with 24 bits: large batches run in slices
             if capture is not None:

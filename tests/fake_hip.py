@@ -18,6 +18,19 @@ def make():
     def ln_corr(tokens, g, b, cv_dtype=None, out=None, timer=None, band=-1):
         return O.ln_corr(tokens.permute(0, 3, 1, 2).float(), g, b)
 
+    def corr(tokens, cv_dtype=None, out=None, timer=None, band=-1):                  # tokens already normalised (K9's second output)
+        t = tokens.float()
+        B = t.shape[0] // 2
+        cv = torch.einsum("bhic,bhjc->bhij", t[:B], t[B:])
+        if out is not None:
+            out.copy_(cv)
+            return out
+        return cv
+
+    def cv_alloc(B, h, w, dtype, device, aligned=True):
+        pitch = (w + 31) // 32 * 32 if aligned else w
+        return torch.empty((B, h, w, pitch), dtype=dtype, device=device)[..., :w]     # the row-padded view the kernels see
+
     def sinkhorn_regress(cv, pos, ot_iter=3, want_argmax=False):
         d, c, o, ind = O.regress(O.sinkhorn_prob(cv.float(), pos, ot_iter))
         return (d, c, o, ind.int()) if want_argmax else (d, c, o)
@@ -71,7 +84,10 @@ def make():
     def mlp_chain_supported(C, dtype):
         return C in (128, 256)
 
-    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5):
+    def mlp_chain_ln_out_supported(C, dtype):
+        return C in (128, 256)
+
+    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None):
         t, ys = x.float(), []
         for s, (w, b, act, wsum) in enumerate(stages):
             a = F.layer_norm(t, (t.shape[-1],), eps=ln_eps) if wsum is not None else t
@@ -84,6 +100,9 @@ def make():
                 y = y + ys[0]
             ys.append(y)
             t = y
+        if ln_out is not None:
+            g, b, eps = ln_out
+            return t.to(x.dtype), F.layer_norm(t.to(x.dtype).float(), (t.shape[-1],), g, b, eps).to(x.dtype)
         return t.to(x.dtype)
 
     def feature_fusion_supported(C, dtype):
@@ -186,6 +205,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
     return ns

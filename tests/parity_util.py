@@ -106,3 +106,18 @@ def hip_forward(sd, C: int, ntr: int, refine_iter: int, left: torch.Tensor, righ
 def select(rows, names) -> Dict[str, Dict[str, float]]:
     d = {n: s for n, _, s in rows}
     return {n: d[n] for n in names if n in d}
+
+
+def lookup_from_checker_disparity(ocap: Dict[str, torch.Tensor], refine_iter: int) -> Dict[str, float]:
+    """K3 judged at OPERATOR tolerance inside an end-to-end comparison: the lookups of iteration k are recomputed by the HIP kernel
+    from the checker's OWN cost volume and the checker's own disparity entering iteration k (disp_g, then disp_it{k-1}), so that the
+    disparity error of the stages upstream (times a cost slope of ~100 per px) is not part of what is compared.  -> max |err| per map."""
+    from s2m2_amd import hip
+    out = {}
+    cv = ocap["cv"].float().cuda()
+    for it in range(refine_iter):
+        d = (ocap["disp_g"] if it == 0 else ocap[f"disp_it{it - 1}"]).float().cuda()
+        c1, c2 = hip.cv_lookup(cv, d, 4)
+        out[f"corr1_it{it}"] = float((c1.cpu() - ocap[f"corr1_it{it}"].float()).abs().max())
+        out[f"corr2_it{it}"] = float((c2.cpu() - ocap[f"corr2_it{it}"].float()).abs().max())
+    return out

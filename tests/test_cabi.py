@@ -35,8 +35,8 @@ def test_version_and_error_reporting(lib):
     assert lib.s2m2_version() >= 100
     assert lib.s2m2_ln_corr(None, None, None, None, 1, 1, 8, 128, 1, 1, None) != 0
     assert b"null pointer" in lib.s2m2_last_error()
-    assert lib.s2m2_sinkhorn_regress(None, None, None, None, None, 1, 1, 8, 3, 1, 1, None, None) != 0
-    assert lib.s2m2_cv_lookup(None, None, None, None, 1, 1, 8, 4, 1, 0, 0, 0, 0, None) != 0
+    assert lib.s2m2_sinkhorn_regress(None, None, None, None, None, 1, 1, 8, 3, 1, 1, 0, None, None) != 0
+    assert lib.s2m2_cv_lookup(None, None, None, None, 1, 1, 8, 4, 1, 0, 0, 0, 0, 0, None) != 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -81,3 +81,21 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 60, 128, 4096, 4096, 4096, 4096, 4096, 4, 4, hip.F16, None) != 0
     assert b"whole number" in lib.s2m2_last_error()
     assert lib.s2m2_stem_mlp(None, None, None, None, None, None, 8, hip.F16, None) != 0
+
+
+def test_attention_planning_query_runs_without_a_device(lib):
+    """s2m2_attention_supported: the launch planner (head-dim instantiation, PE bin tiles, waves per block, LDS budget) is host code."""
+    import torch
+    F16, F32 = torch.float16, torch.float32
+    assert hip.attention_supported(2, 8, 1216, 32, F16, grid=(38, 32))[0]             # S 1216x1024
+    assert hip.attention_supported(2, 8, 4864, 96, F32, grid=(76, 64))[0]             # XL 2432x2048, parity mode: the (3, 2) bin tiles
+    assert hip.attention_supported(4, 8, 63 * 64, 32, F16, grid=(64, 63))[0]          # B = 2 at 2048x2016: waves per block clamped
+    assert hip.attention_supported(512, 1, 304, 128, F16)[0]
+    ok, why = hip.attention_supported(2, 8, 5000, 32, F16, grid=(100, 50))
+    assert not ok and "96 x 96" in why
+    ok, why = hip.attention_supported(2, 8, 9216, 96, F32, grid=(96, 96))
+    assert not ok and "LDS" in why
+    from s2m2_amd.engine import check_limits
+    check_limits(2048, 2432, 384, 1, F32)
+    with pytest.raises(ValueError, match="token grid"):
+        check_limits(1600, 3200, 128, 1, F16)

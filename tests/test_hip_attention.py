@@ -54,11 +54,20 @@ def _tables(h, w, device):
     return pe_tables(h, w, device)
 
 
+# (gh, gw, D, nb): the 1/32 token grids of BASELINE's configs -- S 640x480 (15x20, d 32), S / L 1216x1024 (32x38, d 32 / 64), XL 2432x2048
+# (64x76, d 96: the (3, 2) bin tiles) -- plus ragged grids, a grid taller than 32 rows with >= 32 (batch, head) pairs (no key split, the
+# waves-per-block clamp of the PE variant) and the largest instantiated grid (96 x 96 cells, (3, 3) tiles)
+PE_CASES = [(5, 8, 32, 2), (15, 20, 32, 2), (3, 11, 32, 2), (32, 38, 32, 2), (32, 38, 64, 2), (32, 38, 96, 1), (64, 76, 96, 1), (64, 76, 64, 1),
+            (63, 64, 32, 4), (40, 33, 48, 2), (96, 96, 32, 1)]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
-@pytest.mark.parametrize("grid", [(5, 8), (15, 20), (3, 11)])
-def test_attention_with_positional_encoding(hip, dtype, grid):
-    gh, gw = grid
-    N, heads, D, nb = gh * gw, 8, 32, 2
+@pytest.mark.parametrize("case", PE_CASES)
+def test_attention_with_positional_encoding(hip, dtype, case):
+    gh, gw, D, nb = case
+    N, heads = gh * gw, 8
+    ok, why = hip.attention_supported(nb, heads, N, D, dtype, grid=(gw, gh))
+    assert ok, why
     g = torch.Generator(device="cuda").manual_seed(gh)
     C = heads * D
     qkv = (torch.randn(nb, N, 3 * C, device="cuda", generator=g) * 1.3).to(dtype)
@@ -68,8 +77,23 @@ def test_attention_with_positional_encoding(hip, dtype, grid):
     ref, a = _ref(q, k, v, heads, False)
     ys, xs = torch.meshgrid(torch.arange(gh, device="cuda"), torch.arange(gw, device="cuda"), indexing="ij")
     xs, ys = xs.reshape(-1), ys.reshape(-1)
-    pe = 0.5 * torch.cat([px[xs[:, None] - xs[None, :] + gw - 1], py[ys[:, None] - ys[None, :] + gh - 1]], 2)   # (N,N,32)
-    pref = torch.einsum("bhij,ijc->bhic", a, pe).transpose(1, 2).reshape(nb, N, heads * 32)
+    pref = torch.empty(nb, heads, N, 32, device="cuda")
+    for i0 in range(0, N, 512):                                  # the reference's einsum 'nij,ijc->nic' (attentions.py:47), in query blocks
+        sl = slice(i0, min(i0 + 512, N))
+        pe = 0.5 * torch.cat([px[xs[sl, None] - xs[None, :] + gw - 1], py[ys[sl, None] - ys[None, :] + gh - 1]], 2)   # (nq,N,32)
+        pref[:, :, sl] = torch.einsum("bhij,ijc->bhic", a[:, :, sl], pe)
+    pref = pref.transpose(1, 2).reshape(nb, N, heads * 32)
     tol = 3e-5 if dtype == torch.float32 else 4e-3
     assert float((out.float() - ref).abs().max()) < tol * max(1.0, float(v.float().abs().max()))
     assert float((pe_sum.float() - pref).abs().max()) < (3e-5 if dtype == torch.float32 else 2e-3)
+
+
+def test_attention_supported_matches_the_launch(hip):
+    """s2m2_attention_supported plans with the launch's own code: what it rejects the launch rejects with the same message."""
+    ok, why = hip.attention_supported(2, 8, 100 * 50, 32, torch.float16, grid=(100, 50))
+    assert not ok and "96 x 96" in why
+    q = torch.zeros(2, 100 * 50, 3 * 256, device="cuda", dtype=torch.float16)
+    from s2m2_amd.engine import pe_tables
+    px, py = pe_tables(50, 100, "cuda")
+    with pytest.raises(RuntimeError, match="96 x 96"):
+        hip.attention(q[..., :256], q[..., 256:512], q[..., 512:], 8, pe=(px, py, 100, 50))

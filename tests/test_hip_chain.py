@@ -113,3 +113,27 @@ def test_chain_rejects_bad_arguments(hip):
         hip.mlp_chain(x, [(w, None, 0, None), (w, None, 0, None)], carry=True)
     with pytest.raises(RuntimeError, match="act"):
         hip.mlp_chain(x, [(w, None, 3, None)])
+
+
+@pytest.mark.parametrize("C,dtype,shp,nst", [(128, torch.float16, (2, 50, 61), 3), (256, torch.float16, (2, 32, 38), 3), (512, torch.float16, (1, 5, 7), 2),
+                                              (128, torch.float32, (2, 20, 31), 3), (256, torch.float32, (1, 6, 11), 2), (128, torch.float16, (1, 1, 1), 1)])
+def test_chain_layernorm_second_output(hip, C, dtype, shp, nst):
+    """ln_out: LayerNorm(out rows) * gamma + beta as a second output of the last stage (DispInit's layer_norm, submodules.py:165,216,
+    folded into the launch that writes feature_tr_4x) == F.layer_norm of the STORED rows, fp32 statistics, rounded to the I/O dtype;
+    the first output is bit-identical to the launch without it."""
+    assert hip.mlp_chain_ln_out_supported(C, dtype)
+    g = torch.Generator(device="cuda").manual_seed(C + nst)
+    x = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 0.3).to(dtype)
+    res = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 1).to(dtype)
+    acts = (0, 1, 0)[:nst] if nst == 3 else ((2, 0) if nst == 2 else (1,))
+    raw, packed = _make(C, nst, dtype, 1 if nst == 3 else -1, acts, 3 * C + nst)
+    gam = 1 + 0.1 * torch.randn(C, device="cuda", generator=g)
+    bet = 0.05 * torch.randn(C, device="cuda", generator=g)
+    plain = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=nst == 3)
+    y, yn = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=nst == 3, ln_out=(gam, bet, 1e-5))
+    assert torch.equal(y, plain)
+    ref = F.layer_norm(y.float(), (C,), gam, bet, 1e-5)
+    err = float((yn.float() - ref).abs().max())
+    # fp32: summation order of the statistics only;  fp16: one rounding of an O(1..4) value
+    assert err < (2e-5 if dtype == torch.float32 else 4e-3), err
+    assert not hip.mlp_chain_ln_out_supported(384, torch.float16)

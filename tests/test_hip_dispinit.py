@@ -209,3 +209,183 @@ def test_sinkhorn_is_run_to_run_deterministic(hip, shape, dtype, pos):
     for _ in range(40):
         out = hip.sinkhorn_regress(cv, pos, 3, want_argmax=True)
         assert all(torch.equal(a, b) for a, b in zip(ref, out))
+
+
+# ---- K2 beyond w = 384: the 32- and 64-lane row groups (sinkhorn.hip dispatch: GL = 16 / 32 / 64 for w <= 384 / 768 / above) ----------
+def _wide_case(w, h, pos, dtype, seed, spread=3.0, peak=12.0):
+    g = torch.Generator().manual_seed(seed)
+    cv = torch.randn(1, h, w, w, generator=g) * spread + 110
+    idx = torch.randint(0, w, (h, w), generator=g)
+    if pos:
+        idx = torch.minimum(idx, torch.arange(w)[None, :].expand(h, w))              # the match of left pixel i lies at j <= i
+    cv[0, torch.arange(h)[:, None], torch.arange(w)[None, :], idx] += peak            # one strong match per left pixel
+    if dtype == torch.float16:
+        cv = cv.half().float()
+    return cv
+
+
+@pytest.mark.parametrize("w,h", [(400, 3), (608, 4), (768, 2), (776, 2), (800, 2), (1200, 2), (392, 5)])
+@pytest.mark.parametrize("pos", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_sinkhorn_wide_rows_vs_oracle(hip, w, h, pos, dtype):
+    """submodules.py:147-152,169-241 at the widths of BASELINE configs[4] (XL 2432x2048: w = 608) and on both sides of every
+    dispatch boundary of K2 (384 | 392..768 | 776..1200)."""
+    from oracle import s2m2_oracle as O
+    cv = _wide_case(w, h, pos, dtype, seed=w + 17 * pos)
+    P = O.sinkhorn_prob(cv, pos)
+    rd, rc, ro, rind = O.regress(P)
+    disp, conf, occ, am = (t.cpu() for t in hip.sinkhorn_regress(cv.to("cuda", dtype), pos, 3, want_argmax=True))
+    top = P.topk(2, 3).values
+    sure = (top[..., 0] - top[..., 1]) > 1e-4 * top[..., 0]
+    same = am == rind.int()
+    assert float(sure.float().mean()) > 0.9
+    assert bool(same[sure].all()), f"{int((~same[sure]).sum())} argmax mismatches on well separated pixels"
+    assert float((conf - rc).abs()[:, 0][same].max()) < 5e-5
+    assert float((occ - ro).abs().max()) < 5e-5
+    # disp = i - corr: |corr| reaches w, fp32 ulp at 1200 is 1.2e-4
+    assert float((disp - rd).abs()[:, 0][same].max()) < 2e-4 + 2e-7 * w
+    assert float(occ.max()) <= 1 + 1e-5 and float(occ.min()) >= 0
+
+
+@pytest.mark.parametrize("w", [304, 608, 1200])
+def test_sinkhorn_first_maximum_wins_on_exact_ties(hip, w):
+    """argmax semantics of submodules.py:226 (first maximal index): duplicated columns have identical potentials, so P ties EXACTLY in
+    the oracle and must in K2 (without the positivity mask; with it the two columns see different masks and cannot tie)."""
+    from oracle import s2m2_oracle as O
+    cv, rows, cols = _tie_case(w)
+    P = O.sinkhorn_prob(cv, False)
+    rind = O.regress(P)[3]
+    top = P.topk(2, 3).values
+    tied = top[..., 0] == top[..., 1]
+    assert bool(tied[:, :, rows].all()) and bool((rind[0, :, rows] == cols).all()), "the construction must tie exactly in the oracle"
+    am = hip.sinkhorn_regress(cv.cuda(), False, 3, want_argmax=True)[3].cpu()
+    assert bool((am[0, :, rows] == cols.int()).all())
+    assert bool((am == rind.int())[tied | ((top[..., 0] - top[..., 1]) > 1e-4 * top[..., 0])].all())
+
+
+def _tie_case(w, h=2, seed=3):
+    """8 column pairs (j, j+5) that are identical in EVERY row of the volume (so their potentials are identical and P ties exactly
+    wherever the row maximum sits on the pair); each pair is the strong match of one left pixel."""
+    g = torch.Generator().manual_seed(seed + w)
+    cv = torch.randn(1, h, w, w, generator=g) * 3 + 110
+    cols = torch.arange(8) * (w // 9) + 11
+    rows = (cols * 7 + 3) % w
+    cv[:, :, rows, cols] = 135.0
+    cv[..., cols + 5] = cv[..., cols]
+    return cv, rows, cols
+
+
+@pytest.mark.parametrize("shape,dtype,pos", [((1, 6, 608, 608), torch.float16, False), ((1, 3, 800, 800), torch.float32, True)])
+def test_sinkhorn_wide_rows_run_to_run_deterministic(hip, shape, dtype, pos):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    cv = (torch.randn(*shape, device="cuda", generator=g) * 8).to(dtype)
+    ref = [t.clone() for t in hip.sinkhorn_regress(cv, pos, 3, want_argmax=True)]
+    assert all(bool(torch.isfinite(t.float()).all()) for t in ref)
+    for _ in range(40):
+        out = hip.sinkhorn_regress(cv, pos, 3, want_argmax=True)
+        assert all(torch.equal(a, b) for a, b in zip(ref, out))
+
+
+def test_sinkhorn_fp16_wide_input_matches_fp32_on_same_values(hip):
+    g = torch.Generator().manual_seed(6)
+    cv = (torch.randn(1, 4, 608, 608, generator=g) * 4 + 100).half()
+    a = hip.sinkhorn_regress(cv.cuda(), False, 3, want_argmax=True)
+    b = hip.sinkhorn_regress(cv.float().cuda(), False, 3, want_argmax=True)
+    same = a[3] == b[3]
+    assert float(same.float().mean()) > 0.999
+    assert float((a[0] - b[0]).abs()[:, 0][same].max()) < 3e-4
+    assert float((a[1] - b[1]).abs()[:, 0][same].max()) < 1e-5 and float((a[2] - b[2]).abs().max()) < 1e-5
+
+
+# ---- K1 without the LayerNorm (s2m2_corr: tokens normalised by the launch that produced them) and row-padded cost volumes ----------------
+@pytest.mark.parametrize("C,h,w,B", [(128, 3, 304, 1), (128, 2, 160, 2), (256, 2, 304, 1), (64, 2, 40, 1), (128, 2, 8, 1), (384, 1, 608, 1), (192, 2, 72, 1)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_corr_on_normalised_tokens_equals_ln_corr(hip, C, h, w, B, dtype):
+    """s2m2_corr(LayerNorm(x)) against s2m2_ln_corr(x): the same kernel body minus statistics and affine.  The tokens are normalised
+    here with the oracle's arithmetic order in fp32 and rounded like K1 rounds its MFMA operands; in fp16 the two volumes agree to the
+    rounding of the last bit of a token (a different but equally valid fp32 summation order inside the LayerNorm)."""
+    from oracle import s2m2_oracle as O
+    g = torch.Generator().manual_seed(C + w)
+    feat = torch.randn(2 * B, C, h, w, generator=g) * 1.5 + 0.2
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.05 * torch.randn(C, generator=g)
+    if dtype == torch.float16:
+        feat = feat.half().float()
+    ref = O.ln_corr(feat, gamma, beta)
+    tok = torch.nn.functional.layer_norm(feat.permute(0, 2, 3, 1), (C,), gamma, beta, 1e-5).to(dtype).cuda().contiguous()
+    cv = hip.corr(tok)
+    assert cv.shape == (B, h, w, w) and cv.stride(2) % (64 if dtype == torch.float16 else 32) == 0 and cv.stride(2) >= w
+    scale = float(ref.abs().max())
+    err = float((cv.float().cpu() - ref).abs().max())
+    assert err < (1e-5 * scale + 1e-4 if dtype == torch.float32 else 4e-3 * scale + 0.05), (err, scale)
+    # dense output buffer and banded variant: same values
+    dense = torch.empty((B, h, w, w), device="cuda", dtype=dtype)
+    hip.corr(tok, out=dense)
+    assert torch.equal(dense, cv)
+    banded = torch.full_like(dense, -777.0)
+    hip.corr(tok, out=banded, band=11)
+    i = torch.arange(w, device="cuda")[:, None]
+    j = torch.arange(w, device="cuda")[None, :]
+    inside = (j <= i + 11).expand(B, h, w, w)
+    assert torch.equal(banded[inside], cv[inside])
+    # the padding columns of the row-padded allocation are never written
+    if cv.stride(2) > w:
+        base = torch.full((B, h, w, cv.stride(2)), 5.0, device="cuda", dtype=dtype)
+        hip.corr(tok, out=base[..., :w])
+        assert bool((base[..., w:] == 5.0).all()) and torch.equal(base[..., :w], cv)
+
+
+@pytest.mark.parametrize("w,dtype,pos", [(304, torch.float16, True), (160, torch.float32, False), (608, torch.float16, False), (72, torch.float32, True)])
+def test_sinkhorn_and_lookup_read_row_padded_volumes(hip, w, dtype, pos):
+    """K2 / K3 on the row-padded view (pitch = w rounded up to 128 bytes, garbage in the padding) == on the dense volume, bit for bit."""
+    g = torch.Generator(device="cuda").manual_seed(w)
+    h = 5
+    dense = (torch.randn(1, h, w, w, device="cuda", generator=g) * 4 + 100).to(dtype)
+    padded = hip.cv_alloc(1, h, w, dtype, "cuda")
+    assert padded.stride(2) > w or w % (64 if dtype == torch.float16 else 32) == 0
+    padded._base.fill_(float("nan")) if padded._base is not None else None
+    padded.copy_(dense)
+    a = hip.sinkhorn_regress(dense, pos, 3, want_argmax=True)
+    b = hip.sinkhorn_regress(padded, pos, 3, want_argmax=True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    disp = torch.rand(1, 1, h, w, device="cuda", generator=g) * 60 - 5
+    c = hip.cv_lookup(dense, disp, 4)
+    d = hip.cv_lookup(padded, disp, 4)
+    assert torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])
+    buf1 = torch.zeros(1, h, w, 32, device="cuda", dtype=dtype)
+    buf2 = torch.zeros_like(buf1)
+    hip.cv_lookup_into(dense, disp, buf1, 0, 16, 4)
+    hip.cv_lookup_into(padded, disp, buf2, 0, 16, 4)
+    assert torch.equal(buf1, buf2)
+
+
+def test_forward_with_folded_layernorm_matches_k1_with_its_own(monkeypatch):
+    """S2M2_FUSE_K1LN / S2M2_CV_ALIGNED (defaults on): DispInit's LayerNorm as the second output of the last K9 chain + the correlation
+    alone on a row-padded volume, against K1 normalising the tokens itself on a dense volume.  fp32: the cost volumes agree to
+    summation order, everything downstream to the parity tolerance; fp16: both are valid fp16 forwards."""
+    from s2m2_amd.model import S2M2
+    from s2m2_amd.weights import seeded_state_dict, synthetic_pair
+    sd = seeded_state_dict(128, 1, 1, 0)
+    l, r = synthetic_pair(128, 640, 1, 24, 3)
+    l, r = l.cuda(), r.cuda()
+    caps = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("S2M2_FUSE_K1LN", fold)
+        monkeypatch.setenv("S2M2_CV_ALIGNED", fold)
+        m = S2M2(128, 1, 1, use_positivity=True, refine_iter=2)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        cap = {}
+        out = m(l, r, capture=cap)
+        eng = m.engine(torch.float32)
+        assert (eng._tokens_normed is not None) == (fold == "1")
+        assert (cap["cv"].stride(2) > cap["cv"].shape[3]) == (fold == "1")
+        caps.append((cap, out, [t.clone() for t in m(l, r)], [t.clone() for t in m(l, r)]))          # eager, eager (first plain call), graph replay
+    (ca, oa, ea, ga), (cb, ob, eb, gb) = caps
+    assert float((ca["cv"] - cb["cv"]).abs().max()) < 2e-4 * float(cb["cv"].abs().max())
+    agree = float((ca["argmax"] == cb["argmax"]).float().mean())
+    assert agree > 0.999
+    if agree == 1.0:
+        assert float((oa[0] - ob[0]).abs().max()) < 2e-2
+    for x, y in zip(ea, ga):                                  # graph replay == eager on the folded path
+        assert torch.equal(x, y)
