@@ -166,14 +166,17 @@ struct LinearPix {
     __device__ __forceinline__ bool operator()(int r, long long& m) const { m = m0 + r; return m < M; }
 };
 // ... and the halo kernel (row r = patch row * 32 + column)
-struct PatchPix {
+template <int PW = 32>
+struct PatchPixT {
     int n, y0, x0, H, W;
     __device__ __forceinline__ bool operator()(int r, long long& m) const {
-        const int yy = y0 + (r >> 5), xx = x0 + (r & 31);
+        const int py = r / PW;                                     // (constant divisor: a shift for the 32-wide patches)
+        const int yy = y0 + py, xx = x0 + (r - py * PW);
         m = ((long long)n * H + yy) * W + xx;
         return yy < H && xx < W;
     }
 };
+using PatchPix = PatchPixT<32>;
 
 // the pre-LN layers of the model are the QKV projections (no activation) and the first FFN layer (GELU)
 template <typename CFG, typename T>
@@ -1089,15 +1092,19 @@ __device__ unsigned long long g_frag_trace[4096 * 4 * 8];
 #define FRAG_T(slot)
 #endif
 
-template <typename T, int BN_, int CH_, int PH_ = 4>
+template <typename T, int BN_, int CH_, int PH_ = 4, int PW_ = 32>
 struct ConvCfgF {
     static_assert(sizeof(T) == 2, "the fragment-stream kernel is fp16 only");
     // PH: patch rows (4: 128 pixels per block; 2: 64 pixels -- twice the blocks on the coarse pyramid levels, whose grids do not fill the chip)
-    static constexpr int BM = 32 * PH_, BN = BN_, PH = PH_, PW = 32, WGM = 1, WGN = BN_ / 32;
+    // PW: patch columns.  32: an MFMA pixel tile is a patch row.  40 (PH = 4: 160 pixels, 5 MFMA tiles that run across patch rows): picked
+    // by the launcher where it removes a partial round of blocks -- 256x304 is 640 patches of 4x32 on 512 resident block slots (2 per CU),
+    // i.e. two rounds the second of which runs at 25 % occupancy, but 512 patches of 4x40: one round
+    static constexpr int BM = PW_ * PH_, BN = BN_, PH = PH_, PW = PW_, WGM = 1, WGN = BN_ / 32;
     static constexpr int NWAVES = WGN, NT = 64 * NWAVES;
     static constexpr int VEC = 8, CH = CH_, KS = CH_ / 16;       // channels per chunk, k16 steps per tap
     static constexpr int RS = CH + VEC;                  // LDS row stride (elements): 16 bytes of padding per halo pixel
-    static constexpr int WM = BM, WN = 32, MT = PH_, NTL = 1;
+    static constexpr int WM = BM, WN = 32, MT = BM / 32, NTL = 1;
+    static_assert(BM % 32 == 0, "a patch is a whole number of 32-pixel MFMA tiles");
     static constexpr int MAXHALO = (PH + 2) * (PW + 2);
     static constexpr int PPX = CH / VEC;                 // 16-byte pieces per halo pixel
     static constexpr int RPI = NT / PPX;                 // halo pixels covered by one pass of the loader threads
@@ -1196,7 +1203,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     // order; a tracked load the compiler moved below the ring's first requests would only make those waits conservative), and
     // their latency runs beside the halo tile's.  (Requested after the K loop, 8 pieces per thread sat in front of the stores:
     // +3.5 us per block, profiles/r02/frag_timeline.txt.)
-    const PatchPix pix{n, y0, x0, p.H, p.W};
+    const PatchPixT<PW> pix{n, y0, x0, p.H, p.W};
     using AX = AuxRegs<CFG, T, AUX != 0 ? 8 : 4>;
     AX aux;
     if constexpr (AUX != 0) aux.template prefetch<AUX == 1>(p, tid, n0, pix);
@@ -1214,16 +1221,23 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     __syncthreads();
     FRAG_T(1);
     int g = 0;                                                    // global k16 step = index of the fragment consumed next
+    // halo-tile offset (elements) of this lane's pixel in MFMA tile i: pixel q = 32 i + lane % 32 of the patch in raster order
+    int poff[CFG::MT];
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i) {
+        if constexpr (PW == 32) poff[i] = (i * HW_ + l31) * RS;
+        else { const int q = 32 * i + l31, qy = q / PW; poff[i] = (qy * HW_ + (q - qy * PW)) * RS; }
+    }
     auto tap_steps = [&](int ky, int kx) __attribute__((always_inline)) {          // the KS k16 steps of one tap
-        const T* a = Ah + (size_t)(ky * HW_ + l31 + kx) * RS + hi * 8;
+        const T* a = Ah + (size_t)(ky * HW_ + kx) * RS + hi * 8;
         Frag<T> xf[2][CFG::MT];                                   // pixel fragments, double buffered across k16 steps
 #pragma unroll
-        for (int i = 0; i < CFG::MT; ++i) load_frag(xf[0][i], a + (size_t)i * HW_ * RS);
+        for (int i = 0; i < CFG::MT; ++i) load_frag(xf[0][i], a + poff[i]);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             if (kk + 1 < KS) {
 #pragma unroll
-                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[(kk + 1) & 1][i], a + (size_t)i * HW_ * RS + (kk + 1) * 16);
+                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[(kk + 1) & 1][i], a + poff[i] + (kk + 1) * 16);
             }
             // fragment g (slot kk) was requested KS - 1 steps ago; the KS - 2 requests made since then may still be in flight
             wait_vmcnt<KS - 2>();
@@ -1458,12 +1472,12 @@ static int launch_conv_halo(const ConvArgs& a, hipStream_t st) {
     return check_launch("conv2d");
 }
 
-template <typename T, int BN, int CH, int PH = 4>
+template <typename T, int BN, int CH, int PH = 4, int PW = 32>
 static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) != 2) {
         return set_error("conv2d: K order 2 (fragment stream) is an fp16 layout");
     } else {
-        using CFG = ConvCfgF<T, BN, CH, PH>;
+        using CFG = ConvCfgF<T, BN, CH, PH, PW>;
         const bool two = a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX;
         const int naux = a.epi == S2M2_EPI_NONE ? 0 : two ? 2 : 1;   // epilogue operands parked in registers
         // (two operands of 8 pieces each do not fit the 128-pixel block's register budget: rejected below, the instantiation is a dummy)
@@ -1475,6 +1489,7 @@ static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
             return set_error("conv2d: K order 2 needs a stride-1 3x3 / 3x1 / 1x3 layer with Cout a multiple of %d (Cout=%d)", BN, a.Cout);
         if (a.epi == S2M2_EPI_DUALMIX || (PH == 4 && (a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX)))
             return set_error("conv2d: K order 2 with 128-pixel blocks takes one-operand epilogues only (epi=%d has two)", a.epi);
+        if (PW != 32 && a.epi != S2M2_EPI_NONE) return set_error("conv2d: K order 2 with 160-pixel blocks takes no epilogue operand (epi=%d)", a.epi);
         const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
         dim3 grid((unsigned)(a.N * tx * ty), (unsigned)(a.Cout / BN));
         hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty);
@@ -1514,7 +1529,17 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         // CU -- measured -190 us per pair against the v3 tiles, where the 128-pixel variant was +90 us)
         const int ph = tile == 2 || tile == 4 ? tile : (force_ph == 2 || force_ph == 4) ? force_ph
                        : (a.epi != S2M2_EPI_NONE || blocks4 <= 256) ? 2 : 4;
+        // 4x40 patches (160 pixels, 5 MFMA tiles) instead of 4x32 where that saves a partial round of blocks: cost = rounds of the 512
+        // co-resident block slots (2 per CU) times MFMA tiles per block (tile 40 forces it, S2M2_FRAG_PW=32 switches it off)
+        static const int force_pw = getenv("S2M2_FRAG_PW") ? atoi(getenv("S2M2_FRAG_PW")) : 0;         // A/B switch
+        bool wide = false;
+        if (ph == 4 && a.epi == S2M2_EPI_NONE) {
+            const long long blocks5 = (long long)a.N * ((a.W + 39) / 40) * ((a.H + 3) / 4) * (a.Cout / 128);
+            const long long cost4 = ((blocks4 + 511) / 512) * 4, cost5 = ((blocks5 + 511) / 512) * 5;
+            wide = tile == 40 || force_pw == 40 || (tile == 0 && force_pw != 32 && cost5 < cost4);
+        }
         if constexpr (sizeof(T) == 2) {
+            if (wide) return launch_conv_frag<T, 128, 128, 4, 40>(a, st);
             return ph == 2 ? launch_conv_frag<T, 128, 128, 2>(a, st) : launch_conv_frag<T, 128, 128, 4>(a, st);
         } else {
             return launch_conv_frag<T, 128, 128, 4>(a, st);      // (reports the dtype error)

@@ -123,7 +123,7 @@ class Engine:
     def std(self, name: str, splits: Optional[Sequence[Tuple[int, int]]] = None, transposed: bool = False, frag: bool = True) -> Spec:
         """One nn.Conv2d / nn.Linear (or stride-1 nn.ConvTranspose2d when ``transposed``) as a K5 weight.  frag=False: the layer is
         launched with a stride (or S2M2_FRAG_AUX=0 keeps the epilogue-operand layers on the v3 tiles), keep K order 0."""
-        key = (name, tuple(splits) if splits else None, transposed)
+        key = (name, tuple(splits) if splits else None, transposed, bool(frag))     # frag selects the packing (K order 0 / 2)
         s = self._packed.get(key)
         if s is None:
             w = self.p[name + ".weight"]
@@ -198,6 +198,8 @@ class Engine:
         k = (key, tuple(shape), dtype or self.dtype, ns)
         b = self._bufs.get(k)
         if b is None:
+            if self._ns is None and len(self._bufs) >= 64:        # eager scratch is per stream: callers that cycle streams must not leak a
+                self._bufs.pop(next(iter(self._bufs)))            # set per stream -- oldest entry out (a GraphRunner owns its own dictionary)
             b = torch.zeros(shape, device=self.device, dtype=dtype or self.dtype)
             self._bufs[k] = b
         return b

@@ -116,14 +116,18 @@ FRAG_CASES = [
 ]
 
 
-@pytest.mark.parametrize("ph", [4, 2])            # patch height: 128- / 64-pixel blocks (the dispatcher picks by grid size)
-@pytest.mark.parametrize("case", FRAG_CASES)
+# tile: 4 / 2 = patch height of the 32-wide patches (128- / 64-pixel blocks), 40 = 4x40 patches (160-pixel blocks, 5 MFMA tiles that run
+# across patch rows); the dispatcher picks by grid size and wave quantisation
+@pytest.mark.parametrize("ph", [4, 2, 40])
+@pytest.mark.parametrize("case", FRAG_CASES + [(1, 256, 304, [128], 128, 3, 3, 1, 0), (1, 45, 83, [256], 128, 3, 1, 0, 0)])
 def test_conv_frag_stream(hip, case, ph):
     N, H, W, cs, Cout, KH, KW, act, epi = case
     if epi == 3 and ph == 4:
         pytest.skip("two-operand epilogues run on 64-pixel blocks only")
+    if epi != 0 and ph == 40:
+        pytest.skip("160-pixel blocks take no epilogue operand")
     dtype = torch.float16
-    g = torch.Generator(device="cuda").manual_seed(100 + FRAG_CASES.index(case))
+    g = torch.Generator(device="cuda").manual_seed(100 + H + W)
     srcs = [torch.randn(N, H, W, c, device="cuda", generator=g).to(dtype) for c in cs]
     cin = sum(cs)
     w = (torch.randn(Cout, cin, KH, KW, device="cuda", generator=g) / math.sqrt(cin * KH * KW)).to(dtype)

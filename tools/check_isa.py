@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Build-time guard of the scheduling assumptions behind K5 v5 (conv_frag_kernel, s2m2_amd/csrc/conv.hip).
+
+The kernel prefetches its weight fragments with loads the compiler does NOT track (common.h: global_load16_async) and waits for them with
+hand-counted ``s_waitcnt vmcnt(N)``.  That is only correct while, inside the K loop,
+
+  1. the compiler inserts no ``s_waitcnt vmcnt(0)`` of its own (it would drain the ring on every tap: slow, and a sign that a tracked
+     load got mixed in), and
+  2. no instruction other than an MFMA reads a ring register (a ``v_mov`` / ``v_accvgpr_write`` copy of a register whose load may still be
+     in flight reads stale data: DESIGN.md section 4 records two bugs and one memory fault of exactly this kind).
+
+This script compiles conv.hip to gfx950 assembly (device only), finds the K-loop basic blocks of every conv_frag_kernel instantiation
+(blocks that hold both MFMAs and 16-byte global loads) and fails when either property is violated.  ``__graft_entry__.build()`` runs it
+when the library is (re)built;  python tools/check_isa.py [--keep-asm PATH]  runs it alone (about a minute: one device-only compile).
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "s2m2_amd", "csrc", "conv.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-fast-math", "--cuda-device-only", "-S"]
+
+
+def regs_of(tok: str):
+    """'v[12:15]' -> {12..15}, 'v7' -> {7}; anything else -> empty"""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check_function(name: str, lines):
+    """-> list of problems found in the K-loop blocks of one kernel"""
+    blocks, cur = [], []
+    for ln in lines:
+        if re.match(r"^\.LBB\S*:", ln):
+            blocks.append(cur)
+            cur = []
+        else:
+            cur.append(ln.strip())
+    blocks.append(cur)
+    problems, nloops = [], 0
+    for blk in blocks:
+        ins = [l.split(";")[0].strip() for l in blk if l and not l.startswith((".", ";"))]
+        mfma = [l for l in ins if l.startswith("v_mfma")]
+        loads = [l for l in ins if l.startswith("global_load_dwordx4")]
+        if len(mfma) < 16 or not loads:
+            continue
+        nloops += 1
+        ring = set()
+        for l in loads:
+            ring |= regs_of(l.split()[1].rstrip(","))
+        for l in ins:
+            if re.search(r"s_waitcnt\b.*vmcnt\(0\)", l):
+                problems.append(f"{name}: 's_waitcnt vmcnt(0)' inside a K-loop block ({len(mfma)} MFMAs): {l}")
+            if l.startswith(("v_mfma", "global_load_dwordx4", "s_", "ds_", "buffer_")):
+                continue
+            ops = [t.strip().rstrip(",") for t in l.split()[1:]]
+            srcs = ops[1:] if ops else []
+            for t in srcs:
+                if regs_of(t) & ring:
+                    problems.append(f"{name}: non-MFMA instruction reads a ring register inside the K loop: {l}")
+    if nloops == 0:
+        problems.append(f"{name}: no K-loop block found (the check no longer matches the generated code)")
+    return problems, nloops
+
+
+def main() -> int:
+    keep = sys.argv[sys.argv.index("--keep-asm") + 1] if "--keep-asm" in sys.argv else None
+    with tempfile.TemporaryDirectory() as td:
+        asm = keep or os.path.join(td, "conv.s")
+        defines = os.environ.get("S2M2_BUILD_DEFINES", "").split()
+        r = subprocess.run([HIPCC, *FLAGS, *defines, SRC, "-o", asm], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-4000:])
+            return 2
+        text = open(asm).read().splitlines()
+    funcs, cur, name = {}, None, None
+    for ln in text:
+        m = re.match(r"^(_ZN4s2m216conv_frag_kernel\S*):", ln)
+        if m:
+            name, cur = m.group(1), []
+            funcs[name] = cur
+            continue
+        if cur is not None:
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                cur.append(ln)
+    if not funcs:
+        print("check_isa: no conv_frag_kernel instantiation found in the assembly")
+        return 1
+    bad = []
+    for name, lines in funcs.items():
+        problems, nloops = check_function(name, lines)
+        short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0][:110]
+        print(f"check_isa: {short}: {nloops} K-loop block(s), {len(problems)} problem(s)")
+        bad += problems
+    for p in bad[:20]:
+        print("  " + p)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
