@@ -502,23 +502,26 @@ def upsample_mask_1x(sd: SD, p: str, disp: Tensor, rgb: Tensor, f2x: Tensor) -> 
 # --------------------------------------------------------------------------------------------------
 @torch.no_grad()
 def forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool = False, refine_iter: int = 3,
-            output_upsample: bool = False, capture: Optional[Dict[str, Tensor]] = None, precision: str = "fp32"):
+            output_upsample: bool = False, capture: Optional[Dict[str, Tensor]] = None, precision: str = "fp32",
+            inject: Optional[Dict[str, Tensor]] = None):
     """Returns (disp_up, occ_up, conf_up), each (B,1,H,W) fp32.  ``capture`` (optional dict) receives the
     stage boundaries the parity tests compare: feature_tr_4x, cv, argmax, disp0/conf0/occ0, disp_g,
     per-iteration disp/conf/occ/corr, masks.  ``precision``: "fp32" (parity configuration) or "fp16" (emulation of the
-    reference's autocast deployment mode, see the precision note at the top of this file)."""
+    reference's autocast deployment mode, see the precision note at the top of this file).  ``inject`` (parity tests only):
+    {"feature_tr_4x": (2B,C,h,w)} replaces the transformer output before DispInit, like the product's Engine ``inject`` hook -- used to
+    run both sides from synthetic features with sharp, unambiguous matches."""
     if precision not in ("fp32", "fp16"):
         raise ValueError(precision)
     old = _Prec.half
     _Prec.half = precision == "fp16"
     try:
-        return _forward(sd, img0, img1, use_positivity, refine_iter, output_upsample, capture)
+        return _forward(sd, img0, img1, use_positivity, refine_iter, output_upsample, capture, inject)
     finally:
         _Prec.half = old
 
 
 def _forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool, refine_iter: int, output_upsample: bool,
-             capture: Optional[Dict[str, Tensor]]):
+             capture: Optional[Dict[str, Tensor]], inject: Optional[Dict[str, Tensor]] = None):
     cap = capture if capture is not None else {}
     sd = {k: v.float() for k, v in sd.items()}
     a = (img0.float() / 255.0 - 0.5) * 2
@@ -533,6 +536,8 @@ def _forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool, refine_it
     for i in range(_count(sd, "transformer.uformer_list")):
         z = mrt(sd, f"transformer.uformer_list.{i}", *z)
     tr = z[0].contiguous()
+    if inject and "feature_tr_4x" in inject:
+        tr = _q(inject["feature_tr_4x"].float()).contiguous()
     cap["feature_tr_4x"] = tr
     disp, conf, occ, cv, ind, P = disp_init(sd, tr, use_positivity)
     cap.update(cv=cv, argmax=ind, disp0=disp, conf0=conf, occ0=occ, prob=P)

@@ -30,6 +30,8 @@
 
 namespace s2m2 {
 
+constexpr size_t kLdsBytes = 160 * 1024;
+
 struct AttnArgs {
     const void* q; const void* k; const void* v; void* out;
     long long sq, sk, sv, so;           // row strides (elements)
@@ -452,8 +454,6 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     }
 }
 
-constexpr size_t kLdsBytes = 160 * 1024;
-
 template <typename T, int DP, bool PE, int MINW, bool KSPLIT, int NXT, int NYT>
 static int launch_attn_t(const AttnArgs& a, int nw, hipStream_t st) {
     using CFG = AttnCfg<T, DP, PE, MINW, KSPLIT, NXT, NYT>;
@@ -492,6 +492,14 @@ static int launch_attn_w(const AttnArgs& a, int nw, hipStream_t st) {
     }
 }
 
+// LDS the PE variant needs with nw waves per block (tables + marginal bins behind the K / V stages), for the bin tiles launch_attn_w picks
+template <typename T, int DP, int MINW, bool KSPLIT>
+static size_t pe_lds_need(const AttnArgs& a, int nw) {
+    const int sm = (a.gw <= 64 && a.gh <= 32) ? AttnCfg<T, DP, true, MINW, KSPLIT, 2, 1>::SM
+                   : (a.gh <= 64 ? AttnCfg<T, DP, true, MINW, KSPLIT, 3, 2>::SM : AttnCfg<T, DP, true, MINW, KSPLIT, 3, 3>::SM);
+    return AttnCfg<T, DP, true, MINW, KSPLIT, 2, 1>::PE_OFF + ((size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 + (size_t)nw * 32 * sm) * sizeof(float);
+}
+
 template <typename T, int DP, bool PE>
 static int launch_attn(const AttnArgs& a, hipStream_t st) {
     constexpr int MAXW = AttnCfg<T, DP, PE>::MAXW;
@@ -505,7 +513,14 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
         // few, long rows (the 2-D global blocks at 1/32: 8-16 (batch, head) pairs x 1216 tokens): a wave per query tile would leave
         // three quarters of the chip idle and walk all keys serially -> four waves per query tile, each taking every fourth 32-key
         // sub-tile, partial softmax states merged through LDS
-        if ((long long)ntq * bh < 2048 && a.Nk >= 256) return launch_attn_w<T, DP, PE, 4, true>(a, 4, st);
+        if ((long long)ntq * bh < 2048 && a.Nk >= 256) {
+            if constexpr (PE) {
+                // tall fp32 token grids (d = 64 on 76 x 64: 169 KB): tables + bins of the four key-split waves do not fit next to the
+                // 128-key stages -> two-wave blocks without the key split
+                if (pe_lds_need<T, DP, 4, true>(a, 4) > kLdsBytes) return launch_attn_w<T, DP, PE, 2>(a, 2, st);
+            }
+            return launch_attn_w<T, DP, PE, 4, true>(a, 4, st);
+        }
         // few (batch, head) pairs (the 2-D global blocks at 1/32): smaller blocks until the grid covers the chip; every block
         // re-stages K/V from L2, which is cheap next to an idle GPU
         while (nw > 2 && (long long)((ntq + nw - 1) / nw) * bh < 512) nw = (nw + 1) / 2;

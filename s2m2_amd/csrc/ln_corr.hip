@@ -227,7 +227,67 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     K1_T(1);
     Vec16<T> rawB[CFG::RIF][CFG::PPL];
     Frag<T> afrag[CFG::KSTEPS];
-    {
+    // a group of TPW left tokens is complete in this wave's scratch rows: the lanes whose token (lane & 31) belongs to the group pick
+    // their fragments up before the next group overwrites the rows
+    auto pickup = [&](int grp) __attribute__((always_inline)) {
+        __builtin_amdgcn_wave_barrier();
+        if (grp == 4 / CFG::ROUNDS - 1) K1_T(3);
+        const T* ap = Wb + (size_t)((lane & 31) % CFG::TPW) * CFG::RS + (lane >> 5) * 8;
+        if (grp == 0) {                                           // every lane reads (the lanes of later groups pick up placeholders)
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
+        } else {
+            if ((lane & 31) / CFG::TPW == grp) {
+#pragma unroll
+                for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag_keep(afrag[kk], ap + kk * 16);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    // PRENORM: tokens go global -> registers -> LDS unchanged.  With nothing to compute on them the optimiser treats the staging
+    // registers as a plain copy and sinks every load next to its LDS store -- one load in flight at a time (measured: 29 us against 22 us
+    // WITH the LayerNorm).  So this path requests its tokens with untracked loads (common.h: global_load16_async) and counted waits.
+    raw16_t pre_a[CFG::PRENORM ? CFG::RIF : 1][CFG::PPL], pre_b[CFG::PRENORM ? CFG::RIF : 1][CFG::PPL];
+    auto pre_issue = [&](raw16_t (&dst)[CFG::PRENORM ? CFG::RIF : 1][CFG::PPL], const T* src, int tok0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < CFG::RIF; ++r) {
+            int tok = tok0 + r * 8 + trow;
+            tok = tok < w ? tok : w - 1;                           // ragged tail: duplicates, never stored
+            const T* q0 = src + (size_t)tok * CFG::C + sub * CFG::VEC;
+#pragma unroll
+            for (int q = 0; q < CFG::PPL; ++q) global_load16_async(dst[r][q], q0 + CFG::LPT * q * CFG::VEC);
+        }
+    };
+    auto pre_stash = [&](raw16_t (&v)[CFG::PRENORM ? CFG::RIF : 1][CFG::PPL], int round0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < CFG::RIF; ++r)
+#pragma unroll
+            for (int q = 0; q < CFG::PPL; ++q) {
+                settle(v[r][q]);
+                *reinterpret_cast<raw16_t*>(Wb + (size_t)(((round0 + r) * 8 + trow) % CFG::TPW) * CFG::RS + (sub + CFG::LPT * q) * CFG::VEC) = v[r][q];
+            }
+    };
+    if constexpr (CFG::PRENORM) {
+        static_assert(!CFG::PIPE, "the pipelined variant has no normalised-input form");
+        pre_issue(pre_a, left, i0);
+        if (CFG::EARLY_B) pre_issue(pre_b, right, wv * CFG::TPW);
+        K1_T(2);
+#pragma unroll
+        for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
+            if (r0 > 0) pre_issue(pre_a, left, i0 + r0 * 8);
+            if (r0 == 0 && CFG::EARLY_B) wait_vmcnt<CFG::RIF * CFG::PPL>();      // the right tokens (requested later) may still be in flight
+            else wait_vmcnt<0>();
+            pre_stash(pre_a, r0);
+            if ((r0 + CFG::RIF) % CFG::ROUNDS == 0) pickup((r0 + CFG::RIF) / CFG::ROUNDS - 1);
+        }
+        // the right tokens of chunk 0 (requested at entry) go to LDS HERE, not under a condition inside the chunk loop: an untracked
+        // load whose destination is live across a control-flow merge may get a register copy there that reads it while in flight
+        if (CFG::EARLY_B) {
+            wait_vmcnt<0>();
+            pre_stash(pre_b, 0);
+        }
+    } else {
         Vec16<T> rawA[CFG::RIF][CFG::PPL];
         // unconditional (token indices are clamped): a branch here lets the compiler hoist the first LayerNorm under it and push
         // the right-token requests behind the arrival of the left tokens
@@ -245,36 +305,17 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         // left operand: normalise -> (this wave's slice of Bs as scratch) -> k16 fragments in registers.  Unconditional (clamped
         // duplicates for a wave past the row end): any branch between the requests and their first use lets the optimiser sink
         // the loads into it, behind the other requests and behind the scheduling barrier above.
-        {
-            // TPW-row scratch: the 32 tokens pass through it in 32 / TPW groups; the lanes whose token (lane & 31) belongs to the
-            // group pick their fragments up before the next group overwrites the rows
+        // TPW-row scratch: the 32 tokens pass through it in 32 / TPW groups
 #pragma unroll
-            for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
-                if (r0 > 0) {
+        for (int r0 = 0; r0 < 4; r0 += CFG::RIF) {
+            if (r0 > 0) {
 #pragma unroll
-                    for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawA[r], left, i0 + (r0 + r) * 8 + trow, w, sub);
-                }
-#pragma unroll
-                for (int r = 0; r < CFG::RIF; ++r)
-                    normalize_store<CFG, T>(rawA[r], Wb + (size_t)(((r0 + r) * 8 + trow) % CFG::TPW) * CFG::RS, gb, sub, dbg);
-                if ((r0 + CFG::RIF) % CFG::ROUNDS == 0) {         // a group of TPW tokens is complete
-                    const int grp = (r0 + CFG::RIF) / CFG::ROUNDS - 1;
-                    __builtin_amdgcn_wave_barrier();
-                    if (grp == 4 / CFG::ROUNDS - 1) K1_T(3);
-                    const T* ap = Wb + (size_t)((lane & 31) % CFG::TPW) * CFG::RS + (lane >> 5) * 8;
-                    if (grp == 0) {                               // every lane reads (the lanes of later groups pick up placeholders)
-#pragma unroll
-                        for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag(afrag[kk], ap + kk * 16);
-                    } else {
-                        if ((lane & 31) / CFG::TPW == grp) {
-#pragma unroll
-                            for (int kk = 0; kk < CFG::KSTEPS; ++kk) load_frag_keep(afrag[kk], ap + kk * 16);
-                        }
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
+                for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawA[r], left, i0 + (r0 + r) * 8 + trow, w, sub);
             }
+#pragma unroll
+            for (int r = 0; r < CFG::RIF; ++r)
+                normalize_store<CFG, T>(rawA[r], Wb + (size_t)(((r0 + r) * 8 + trow) % CFG::TPW) * CFG::RS, gb, sub, dbg);
+            if ((r0 + CFG::RIF) % CFG::ROUNDS == 0) pickup((r0 + CFG::RIF) / CFG::ROUNDS - 1);
         }
     }
 
@@ -350,6 +391,18 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     for (int c = 0; c < nchunks; ++c) {
         // right tokens of this chunk: each wave normalises its 32 into its slice, then prefetches its share of the next chunk
         const int t0 = c * TJ + wv * CFG::TPW;
+        if constexpr (CFG::PRENORM) {
+            // (no prefetch across the multiply / store phase here: a counted wait would also wait for this wave's stores -- they tick
+            // the same counter -- so a chunk's tokens are requested at its top; rows that fit one chunk, C <= 128, are unaffected)
+            if (!CFG::EARLY_B || c > 0) {                         // (chunk 0 of the EARLY_B configurations is in LDS already)
+#pragma unroll
+                for (int r0 = 0; r0 < CFG::ROUNDS; r0 += CFG::RIF) {
+                    pre_issue(pre_b, right, t0 + r0 * 8);
+                    wait_vmcnt<0>();
+                    pre_stash(pre_b, r0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int r0 = 0; r0 < CFG::ROUNDS; r0 += CFG::RIF) {
             if (!(CFG::ALLRES && (c > 0 || CFG::EARLY_B))) {
@@ -363,6 +416,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         if (CFG::ALLRES && c + 1 < nchunks) {
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r) load_token<CFG, T>(rawB[r], right, t0 + TJ + r * 8 + trow, w, sub);
+        }
         }
         K1_T(4);
         __syncthreads();

@@ -135,3 +135,59 @@ def test_fp16_640x480_pinned_to_autocast_emulation():
     assert s3["disp"]["median"] <= 1e-2 and s3["disp"]["p99"] <= 0.3, s3["disp"]
     assert s3[f"disp_it{ri - 1}"]["p99"] <= 0.05, s3
     assert s3["conf"]["p999"] <= 5e-3 and s3["occ"]["p999"] <= 5e-3, s3
+
+
+def _sharp_tokens(C, h, w, shifts, seed, noise=0.05):
+    """Synthetic transformer output (2,C,h,w) with ONE unambiguous match per left pixel: left tokens iid N(0,1) per
+    channel, right token j = left token (j + d) mod w + noise, d = shifts[row band] -- after LayerNorm the matched score is ~C (128)
+    against N(0, sqrt C) for every other column, so neither fp16 rounding of the volume (ulp 0.125 at 128) nor summation order can
+    move an argmax.  Circular shift: every pixel has its match (run without the positivity mask, wrapped matches are negative
+    disparities)."""
+    g = torch.Generator().manual_seed(seed)
+    left = torch.randn(1, C, h, w, generator=g)
+    right = torch.empty_like(left)
+    band = (h + len(shifts) - 1) // len(shifts)
+    for k, d in enumerate(shifts):
+        rows = slice(k * band, min(h, (k + 1) * band))
+        right[:, :, rows] = torch.roll(left[:, :, rows], shifts=-d, dims=3)
+    right = right + noise * torch.randn(1, C, h, w, generator=g)
+    return torch.cat([left, right], 0)
+
+
+def test_fp16_640x480_sharp_matches_free_running():
+    """The fp16 deployment mode held to a TIGHT bound end to end: with sharp, unambiguous matches injected as feature_tr_4x on both
+    sides there are no near-tie argmax flips -- the only thing that separates two valid fp16 forwards of this randomly initialised
+    model -- so the free-running HIP fp16 forward must reproduce the autocast emulation's integer argmax exactly, disp0 to the
+    reference's own fp16 quantisation, and the final maps to fp16 rounding noise through the refiners (no teacher forcing after the
+    injection point)."""
+    ri = 3
+    sd = seeded_state_dict(128, 1, 1, 0)
+    left, right = synthetic_pair(480, 640, 1, 32, 0)
+    tok = _sharp_tokens(128, 120, 160, (12, 5, 23), 4)
+    inj = {"feature_tr_4x": tok}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    c16, c32 = {}, {}
+    o16 = O.forward(sd, left, right, False, ri, False, c16, precision="fp16", inject=inj)
+    o32 = O.forward(sd, left, right, False, ri, False, c32, precision="fp32", inject=inj)
+    top = c32["prob"].topk(2, 3).values
+    assert float(((top[..., 0] - top[..., 1]) / top[..., 0]).min()) > 0.5            # the construction: every argmax is unambiguous
+    assert bool((c16["argmax"] == c32["argmax"]).all())
+    hout, hcap = PU.hip_forward(sd, 128, 1, ri, left, right, True, inject=inj, use_positivity=False)
+    assert all(torch.isfinite(t).all() for t in hout)
+    assert bool((hcap["argmax"].long() == c16["argmax"].long()).all()), "integer argmax must be bit exact when no near tie exists"
+    rows, am = PU.compare(hcap, hout, c16, o16, ri)
+    ref_rows, _ = PU.compare(c16, o16, c32, o32, ri)
+    st = PU.select(rows, ["cv", "disp0", "conf0", "occ0", "disp_g", f"disp_it{ri - 1}", "disp", "occ", "conf"])
+    ref = PU.select(ref_rows, ["disp", "occ", "conf", f"disp_it{ri - 1}"])
+    print({k: (v["median"], v["p99"], v["max"]) for k, v in st.items()})
+    print("emulation vs fp32:", {k: (v["median"], v["p99"], v["max"]) for k, v in ref.items()})
+    assert st["cv"]["max"] <= 0.125                                                   # one fp16 ulp of |cv| <= 128 ... 256
+    # K2 keeps fp32 where the reference's autocast rounds probabilities and the 5-tap sums to fp16: |j| <= 160 -> ulp 0.125
+    assert st["disp0"]["max"] <= 0.16 and st["conf0"]["max"] <= 2e-3 and st["occ0"]["max"] <= 2e-3, st
+    # free running from there: no discrete decision is left, what remains is fp16 rounding noise amplified by the randomly initialised
+    # refiners (the emulation itself sits median 0.065 / p99 0.64 px from the fp32 forward of the same features: measured with the
+    # oracle in both modes) -- the HIP forward must be no further from the emulation than the emulation is from fp32, at the median
+    # and at p99, for every final map (with argmax flips out of the picture this yardstick is 20x tighter than
+    # tests/test_fp16_reference_autocast.py's: p99 0.64 px instead of 13.5 px)
+    for name in ("disp", "occ", "conf", f"disp_it{ri - 1}"):
+        assert st[name]["median"] <= 1.0 * ref[name]["median"] + 1e-4 and st[name]["p99"] <= 1.0 * ref[name]["p99"] + 1e-3, (name, st[name], ref[name])

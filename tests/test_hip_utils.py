@@ -69,3 +69,56 @@ def test_stem_mlp_matches_the_two_conv_layers(dtype):
     assert y.shape == (2, 37, 53, 16) and y.dtype == dtype
     assert float((y.float() - ref).abs().max()) < tol
     assert float((y.float() - y2.float()).abs().max()) < tol
+
+
+# ---- pinned to the reference's REAL functions (tests/golden/make_golden_utils.py imports image_pad / image_crop from the reference with a
+# stubbed cv2 and runs the body of run_stereo_matching on a window of the reference's own sample pair) ---------------------------------
+def _gold(name):
+    import os
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name))
+
+
+def test_image_pad_matches_the_reference_function():
+    from s2m2_amd import utils
+    g = _gold("utils_pad_crop.npz")
+    for k in range(int(g["npad"])):
+        img = torch.from_numpy(g[f"pad{k}_in"])
+        sub = int(g[f"pad{k}_sub"])
+        out = utils.image_pad(img.cuda(), 32).cpu()[..., ::sub, ::sub]
+        ref = torch.from_numpy(g[f"pad{k}_out"])
+        assert tuple(out.shape) == tuple(ref.shape), k
+        # the interior is a copy (exact); the blurred border is adaptive_avg_pool2d + bilinear on values up to 255: fp32 summation order
+        assert float((out - ref).abs().max()) < 2e-3, (k, float((out - ref).abs().max()))
+
+
+def test_run_stereo_matching_body_on_the_references_sample_pair():
+    """image_pad -> forward -> image_crop -> average confidence (model_utils.py:69-94) in fp32 on a 350 x 470 window of
+    data/samples/Web/0025_{L,R}.png (uint8, not a multiple of 32) against the reference's own functions + module on the same data."""
+    from s2m2_amd import utils
+    from s2m2_amd.model import S2M2
+    from s2m2_amd.weights import seeded_state_dict
+    g = _gold("e2e_S_web0025_crop_fp32_r1.npz")
+    C, ntr, H, W, B, pos, ri, _, seed = [int(v) for v in g["cfg"]]
+    left = torch.from_numpy(g["left"]).permute(2, 0, 1)[None].cuda()          # uint8, as the demos hand it over
+    right = torch.from_numpy(g["right"]).permute(2, 0, 1)[None].cuda()
+    m = S2M2(C, 1, ntr, use_positivity=bool(pos), refine_iter=ri)
+    m.load_state_dict(seeded_state_dict(C, 1, ntr, seed), strict=True)
+    m = m.cuda().eval()
+    lp, rp = utils.image_pad(left, 32), utils.image_pad(right, 32)
+    assert float((lp.cpu()[..., ::4, ::4] - torch.from_numpy(g["left_pad_sub4"])).abs().max()) < 2e-3
+    with torch.inference_mode():
+        d, o, c = m(lp, rp)
+    d, o, c = (utils.image_crop(t, (H, W)).squeeze().float().cpu() for t in (d, o, c))
+    assert tuple(d.shape) == (H, W)
+    for name, t, lim in (("disp", d, None), ("occ", o, 5e-4), ("conf", c, 5e-4)):
+        ref = torch.from_numpy(g[name])
+        e = (t[::2, ::2] - ref).abs()
+        frac = float((e > 1e-3 + 1e-4 * ref.abs()).float().mean())
+        # free running on real image content: a near-tie argmax of DispInit may fall the other way and move its neighbourhood
+        assert frac <= 5e-3 and float(e.median()) < (2e-4 if name == "disp" else 2e-5), (name, frac, float(e.median()), float(e.max()))
+    score = float(c[100:-100, 100:-100].mean())
+    assert abs(score - float(g["avg_conf"])) < 2e-4, (score, float(g["avg_conf"]))
+    # the deployed entry point (autocast fp16, timers) on the same pair: same shapes, a score close to the fp32 one
+    out = utils.run_stereo_matching(m, left, right, torch.device("cuda"), N_repeat=1)
+    assert tuple(out[0].shape) == (H, W) and abs(out[3] - float(g["avg_conf"])) < 0.05

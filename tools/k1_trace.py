@@ -19,16 +19,29 @@ CASES = {"c2": (128, 120, 160), "c3": (128, 256, 304), "c4": (256, 256, 304), "c
 
 
 def main():
-    case = sys.argv[1] if len(sys.argv) > 1 else "c3"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    case = args[0] if args else "c3"
+    prenorm = "--prenorm" in sys.argv           # s2m2_corr: tokens already normalised (no LayerNorm phases)
+    aligned = "--aligned" in sys.argv           # cost-volume rows on 128-byte lines (hip.cv_alloc)
     C, h, w = CASES[case]
     lib = hip.load()
     lib.s2m2_debug_k1_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     torch.manual_seed(0)
     feat = (torch.randn(2, h, w, C, device="cuda") * 1.5).half()
     g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
-    out = torch.empty((1, h, w, w), device="cuda", dtype=torch.float16)
+    out = hip.cv_alloc(1, h, w, torch.float16, "cuda", aligned=True) if aligned else torch.empty((1, h, w, w), device="cuda", dtype=torch.float16)
+    if prenorm:
+        feat = torch.nn.functional.layer_norm(feat.float(), (C,)).half()
+
+    def launch():
+        if prenorm:
+            hip.corr(feat, out=out)
+        elif aligned:
+            raise SystemExit("--aligned needs --prenorm (s2m2_ln_corr writes dense volumes)")
+        else:
+            hip.ln_corr(feat, g, b, out=out)
     for _ in range(5):
-        hip.ln_corr(feat, g, b, out=out)
+        launch()
     torch.cuda.synchronize()
     buf = np.zeros(1024 * 16 * 16, dtype=np.uint64)
     assert lib.s2m2_debug_k1_trace(buf.ctypes.data, buf.nbytes) == 0
@@ -43,9 +56,10 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(20):
-        hip.ln_corr(feat, g, b, out=out)
+        launch()
     ev1.record()
     torch.cuda.synchronize()
+    print(f"variant: {'s2m2_corr (normalised tokens)' if prenorm else 's2m2_ln_corr'}, cv pitch {out.stride(2)}")
     print(f"K1 timeline {case}: {h} blocks x {nw} waves; raw span {span:.0f} ticks, read as {hz / 1e6:.0f} MHz; eager back-to-back "
           f"{ev0.elapsed_time(ev1) * 1e3 / 20:.1f} us per launch (instrumented build); microseconds since the first wave's entry")
     # (the shader clock is not synchronised across XCDs: only differences inside one wave are meaningful)
