@@ -163,6 +163,30 @@ def secondary_640x480(model, eng, dev, use_fp16, refine_iter, model_type, steps=
                          "note": "h = 120 image rows = 120 workgroups on 256 CUs: this size cannot fill the chip with one pair"}}
 
 
+def secondary_batched(model, dev, use_fp16, a, pairs=2, steps=10, warmup=3):
+    """Information only (not `value`, whose workload is ONE pair per GPU per step as BASELINE's configs[2] shards them): the same model and
+    size with `pairs` pairs per launch sequence on rank 0's GPU -- what batching buys when a caller has more than one pair per GPU
+    (every grid doubles: fewer partially filled rounds of blocks, twice the rows per launch on the coarse pyramid levels)."""
+    import torch
+    from s2m2_amd.weights import noise_pair
+    left, right = (t.to(dev) for t in noise_pair(a.height, a.width, pairs, seed=11))
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+            return model(left, right)
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": f"{a.model}-model {a.width}x{a.height} refine_iter={a.refine_iter}, {pairs} pairs per step, n_gpus=1 (rank 0)",
+            "value": steps * pairs / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / (steps * pairs), "steps": steps, "warmup": warmup}
+
+
 def pmc_traffic(model_type, H, W, use_fp16, B):
     """HBM bytes per K1 launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of
     tools/k1_only.py, corrected as MI355X_MICROARCH.md prescribes -> profiles/rNN/k1_<case>_<dtype>_pmc.json).  PMC collection
@@ -393,6 +417,8 @@ def main():
         line["per_rank_ms_per_step"] = [round(x, 4) for x in per_rank_ms]
         if not a.no_secondary and (a.height, a.width) != (480, 640):
             line["secondary"] = secondary_640x480(model, eng, dev, use_fp16, a.refine_iter, a.model)
+            if B == 1:
+                line["secondary_batched"] = secondary_batched(model, dev, use_fp16, a, pairs=2)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.model, a.height, a.width, a.refine_iter)
         print(json.dumps(line), flush=True)

@@ -80,6 +80,10 @@ int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, 
  */
 int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
               void* stream, void* start_event, void* stop_event);
+/* measurement aid (not part of the path; tools/k1_store_path.py): K1's store pattern alone -- mode 0: one block per volume row, 32 rows per
+ * wave in 128-byte segments exactly like the kernel's store loop, no loads / MFMA; 1: the same with non-temporal stores; 2 / 3: the same
+ * bytes as one linear stream (3: non-temporal).  fp16 volume of `rows` rows of w x cv_pitch; events as s2m2_ln_corr_timed. */
+int s2m2_debug_store_pattern(void* cv, int rows, int w, int cv_pitch, int mode, void* stream, void* start_event, void* stop_event);
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);
@@ -213,6 +217,10 @@ typedef struct s2m2_chain_desc {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_out_eps;
+    /* placement hint, 0 = none: the rows are `rows / (8 * xcd_group_rows)` images of 8 groups of xcd_group_rows consecutive rows each;
+       group g of every image is processed on XCD g (blocks are dealt to XCDs round robin by the hardware), so that a consumer which
+       places its work the same way -- s2m2_corr: image row y on XCD y / (h / 8) -- reads these rows from the L2 that holds them. */
+    long long xcd_group_rows;
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);
 int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);

@@ -42,6 +42,10 @@ struct ChainArgs {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_out_eps;
+    // > 0: row tiles are handed to blocks so that the XCD a block runs on (hardware: block b on XCD b % 8) owns the tiles of ONE eighth of
+    // every image -- xcd_tiles consecutive tiles per image and XCD.  The consumer K1 places image row y on XCD y / (h / 8): it then finds the
+    // normalised tokens in the L2 of the XCD that wrote them.
+    int xcd_tiles;
 };
 
 template <typename T, int C_, int BM_, int NST_, int NW_, int WP_ = 4>
@@ -277,7 +281,13 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     T* W0 = reinterpret_cast<T*>(smem + 2 * CFG::A_BYTES);
     T* W1 = reinterpret_cast<T*>(smem + 2 * CFG::A_BYTES + CFG::W_BYTES);
     const int tid = threadIdx.x;
-    const long long m0 = (long long)blockIdx.x * CFG::BM;
+    int tile = blockIdx.x;
+    if (p.xcd_tiles > 0) {                                        // (the host checked that the grid is images x 8 x xcd_tiles)
+        const int x = tile & 7, k = tile >> 3;
+        const int img = k / p.xcd_tiles, r = k - img * p.xcd_tiles;
+        tile = (img * 8 + x) * p.xcd_tiles + r;
+    }
+    const long long m0 = (long long)tile * CFG::BM;
 
     ChainStream<CFG, T> ws;
     ws.init(p, tid);
@@ -370,6 +380,11 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     }
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "mlp_chain: cannot allocate the zero page");
+    a.xcd_tiles = 0;
+    static const bool xcd_off = getenv("S2M2_K9_XCD") != nullptr && atoi(getenv("S2M2_K9_XCD")) == 0;    // A/B switch
+    const int bm = (d->dtype == S2M2_F32 || d->rows <= 8192 || d->C >= 384) ? 32 : 64;   // (the tile heights picked below)
+    if (d->xcd_group_rows > 0 && !xcd_off && d->xcd_group_rows % bm == 0 && d->rows % (8LL * d->xcd_group_rows) == 0 && !(getenv("S2M2_CHAIN_CFG")))
+        a.xcd_tiles = (int)(d->xcd_group_rows / bm);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const char* force = getenv("S2M2_CHAIN_CFG");          // tuning only: "s" (32-row tiles) / "m" (64-row tiles)
     char cfg = d->rows <= 8192 ? 's' : 'm';                       // at most one 32-row tile per CU: short tiles, more CUs busy (measured: tools/chainbench.py)

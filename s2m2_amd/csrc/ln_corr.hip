@@ -188,10 +188,20 @@ template <> __device__ __forceinline__ void store_quad<float>(float* dst, float 
     *reinterpret_cast<float4_t*>(dst) = v;
 }
 
+// 16-byte store of a cost-volume piece; nt: non-temporal (streaming) -- the volume is written once and is larger than the L2 of the XCD that
+// writes it, so allocating its lines there only evicts them again (A/B switch S2M2_K1_NT, measured in profiles/r03/k1_store_path.txt)
+template <typename TO>
+__device__ __forceinline__ void store_cv(TO* dst, const Vec16<TO>& v, int nt) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 r = __builtin_bit_cast(f4, v);
+    if (nt) __builtin_nontemporal_store(r, reinterpret_cast<f4*>(dst));
+    else *reinterpret_cast<f4*>(dst) = r;
+}
+
 template <typename CFG, typename T, typename TO>
 __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, TO* __restrict__ cv,
-                                                                 int B, int h, int w, int nstrip, int band, int pitch) {
+                                                                 int B, int h, int w, int nstrip, int band, int pitch, int flags) {
     constexpr int dbg = S2M2_LNCORR_DBG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                         const int i = i0 + rr;
                         const int j = j0 + pc * CFG::VECO;
                         const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                        if (i < w && j < w && j < jlim && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * pitch + j) = v;
+                        if (i < w && j < w && j < jlim && !(dbg & 1)) store_cv(cvrow + (size_t)i * pitch + j, v, flags & 1);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                     const int i = i0 + rr;
                     const int j = j0 + pc * CFG::VECO;
                     const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                    if (i < w && j < w && !(dbg & 1)) *reinterpret_cast<Vec16<TO>*>(cvrow + (size_t)i * pitch + j) = v;
+                    if (i < w && j < w && !(dbg & 1)) store_cv(cvrow + (size_t)i * pitch + j, v, flags & 1);
                 }
                 __builtin_amdgcn_wave_barrier();
                 K1_T(6 + (pp < 8 ? pp : 8));
@@ -531,6 +541,7 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;
     const int pitch = g_pitch > 0 ? g_pitch : w;
+    static const int k1_flags = getenv("S2M2_K1_NT") ? (atoi(getenv("S2M2_K1_NT")) != 0 ? 1 : 0) : 0;      // A/B switch: non-temporal stores
     if constexpr (!CFG::PIPE && !std::is_void<typename PipeOf<CFG>::type>::value) {
         // measured (tools/k1_ab.py, c3 fp16): 24.2 us pipelined vs 21.3 us plain -- the extra barriers and the smaller store bursts cost
         // more than the overlap returns, so the pipelined variant stays an opt-in experiment
@@ -540,10 +551,10 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     }
     if (g_ev_start || g_ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
-                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch);
+                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
-                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch);
+                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
     return check_launch("ln_corr");
 }
 
@@ -630,6 +641,51 @@ extern "C" int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int 
     g_band = -1;
     g_pitch = 0;
     return rc;
+}
+
+// measurement aid (profiles/r03/k1_store_path.txt): what does the memory system give K1's STORE pattern alone?  mode 0 / 1: one block per
+// volume row of ceil(w / 32) waves, a wave owns 32 rows and writes them as 64-column (128-byte for fp16) segments, 8 rows per store
+// instruction, pair by pair -- exactly the store loop of ln_corr_kernel, from registers, no loads, no MFMA (1: non-temporal);
+// mode 2 / 3: the same bytes as one linear stream of 16-byte stores from 2048 blocks (3: non-temporal).
+namespace s2m2 {
+__global__ __launch_bounds__(1024) void store_pattern_kernel(half_t* cv, int w, int pitch, int mode, long long total16) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    Vec16<half_t> v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.v[e] = (half_t)(float)(lane + e);
+    if (mode >= 2) {
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total16; q += (long long)gridDim.x * blockDim.x)
+            store_cv(cv + q * 8, v, mode & 1);
+        return;
+    }
+    half_t* cvrow = cv + (size_t)blockIdx.x * w * pitch;
+    const int i0 = wv * 32;
+    const int npair = (w + 63) / 64;
+    for (int pp = 0; pp < npair; ++pp) {
+        int pr = pp + wv;
+        pr = pr % npair;
+        const int j0 = pr * 64;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int q = it * 64 + lane;
+            const int rr = q >> 3, pc = q & 7;
+            const int i = i0 + rr, j = j0 + pc * 8;
+            if (i < w && j < w) store_cv(cvrow + (size_t)i * pitch + j, v, mode & 1);
+        }
+    }
+}
+}  // namespace s2m2
+
+extern "C" int s2m2_debug_store_pattern(void* cv, int rows, int w, int cv_pitch, int mode, void* stream, void* start_event, void* stop_event) {
+    using namespace s2m2;
+    S2M2_REQUIRE(cv && rows > 0 && w > 0 && w % 8 == 0 && w <= 512 && mode >= 0 && mode <= 3, "debug_store_pattern: bad arguments");
+    if (cv_pitch == 0) cv_pitch = w;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long total16 = (long long)rows * w * cv_pitch / 8;
+    const dim3 grid(mode >= 2 ? 2048 : rows), block(mode >= 2 ? 256 : ((w + 31) / 32) * 64);
+    hipExtLaunchKernelGGL(store_pattern_kernel, grid, block, 0, st, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event), 0,
+                          static_cast<half_t*>(cv), w, cv_pitch, mode, total16);
+    return check_launch("debug_store_pattern");
 }
 
 extern "C" int s2m2_event_create(void** event) {

@@ -67,7 +67,16 @@ template <int GL> __device__ __forceinline__ int group_min_i(int x) {
     return x;
 }
 
-template <typename TI, int NWV, int GL, int NCH>
+// 16-byte pieces in front of row i of the LDS-resident triangle (row r holds its columns 0 .. r, rounded up to whole pieces)
+__device__ __forceinline__ int tri_pieces(int i, int ppe) {        // ppe: elements per piece
+    const int q = i / ppe, rem = i - q * ppe;
+    return i + ppe * ((q * (q - 1)) >> 1) + q * rem;               // sum_{r < i} (floor(r / ppe) + 1)
+}
+
+// TRI: the block keeps the row's lower cost-volume triangle (use_positivity: j <= i) in LDS -- pass 0 copies the pieces it reads from
+// global memory, the ot_iter later sweeps read LDS: the volume is read from HBM / MALL ONCE (the algorithmic minimum) and the latency
+// of a row fetch drops from a memory round trip to an LDS read.  Needs (w / 8 + 1) * w / 2 * 16 bytes: w <= ~380 for fp16.
+template <typename TI, int NWV, int GL, int NCH, bool TRI = false>
 __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __restrict__ cv, float* __restrict__ disp,
                                                                     float* __restrict__ conf, float* __restrict__ occ,
                                                                     int32_t* __restrict__ amax, int w, int ot_iter, int use_pos, int pitch) {
@@ -84,6 +93,8 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     float* v = u + ns;                                     // [ns]
     float* pm = v + ns;                                    // [NWV][ns]  per-wave column partial stabiliser
     float* pz = pm + NWV * ns;                             // [NWV][ns]  per-wave column partial sum
+    // [TRI] packed lower triangle behind the vectors and the three flag words, 16-byte aligned
+    raw16_t* tri = reinterpret_cast<raw16_t*>(smem + (((size_t)(2 + 2 * NWV) * ns * sizeof(float) + 16 + 15) & ~(size_t)15));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,17 +108,27 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     float* oo = occ + (size_t)blockIdx.x * w;
 
     // row i (i == w: the dustbin row, S = 0, never masked): raw 16-byte pieces of the lane's columns j = c*CW + pl*8 + 0..7
-    auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
+    // SRC 0: global memory; 1: global memory + copy into the LDS triangle (pass 0 of a TRI block); 2: the LDS triangle
+    auto fetch_row_from = [&](int i, raw16_t (&raw)[NCH][PPC], int src) __attribute__((always_inline)) {
         const TI* Si = S + (size_t)(i < w ? i : 0) * pitch;
         const int jend = i < w ? (use_pos ? i + 1 : w) : 0;
+        raw16_t* trow = tri;
+        if constexpr (TRI) trow = tri + tri_pieces(i < w ? i : 0, VEC);
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int q = 0; q < PPC; ++q) {
                 const int j0 = c * CW + pl * 8 + q * VEC;
-                if (j0 < jend) raw[c][q] = global_load16(Si + j0);          // w % 8 == 0: a piece starting inside [0, w) is whole
+                if (j0 < jend) {                                            // w % 8 == 0: a piece starting inside [0, w) is whole
+                    if (TRI && src == 2) raw[c][q] = trow[j0 / VEC];
+                    else {
+                        raw[c][q] = global_load16(Si + j0);
+                        if (TRI && src == 1) trow[j0 / VEC] = raw[c][q];
+                    }
+                }
             }
     };
+    auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) { fetch_row_from(i, raw, TRI ? 2 : 0); };
     auto decode_row = [&](int i, const raw16_t (&raw)[NCH][PPC], float (&x)[NE]) __attribute__((always_inline)) {
         const int jend = i < w ? (use_pos ? i + 1 : w) : (i == w ? w : 0);
 #pragma unroll
@@ -141,7 +162,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 
     // ---- exact column sweep: v_j = log nu_j - LSE_i(S_ij + u_i) with lazy-maximum accumulators (pass 0, where u = 0, and the
     // fallback of the fast sweep below)
-    auto exact_cols = [&](bool use_u) __attribute__((always_inline)) {
+    auto exact_cols = [&](bool use_u) __attribute__((always_inline)) {        // (use_u false = pass 0: the one sweep that reads global memory in a TRI block)
         LSE col[NE], bin;
 #pragma unroll
         for (int c = 0; c < NE; ++c) col[c].init();
@@ -155,7 +176,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             for (int c = 0; c < NCH; ++c)
 #pragma unroll
                 for (int q = 0; q < PPC; ++q) raw[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f};
-            if (active) fetch_row(i, raw);
+            if (active) fetch_row_from(i, raw, use_u ? (TRI ? 2 : 0) : (TRI ? 1 : 0));
             float x[NE];
             decode_row(active ? i : w + 1, raw, x);
             const float ua = active ? (use_u ? u[i] : 0.f) : -INFINITY;
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                 bj = group_min_i<GL>(best == bmax ? bj : 0x7fffffff);
                 const float mass = srow * gsc;
                 // 5 taps around the argmax, evaluated by lanes 0..4 of the group (zero outside [0,w) and in the masked triangle)
-                const TI* Si = S + (size_t)i * pitch;
+                const TI* Si = TRI ? reinterpret_cast<const TI*>(tri + tri_pieces(i, VEC)) : S + (size_t)i * pitch;
                 const int jj = bj + pl - 2;
                 float pk = 0.f;
                 if (pl < 5 && jj >= 0 && jj < jend) pk = __expf(to_f32(Si[jj]) + ci + v[jj]);
@@ -337,13 +358,22 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     }
 }
 
-template <typename TI, int GL, int NCH>
+template <typename TI, int GL, int NCH, bool TRI = false>
 static int launch_sinkhorn(const void* cv, float* disp, float* conf, float* occ, int32_t* amax, int rows, int w, int ot_iter,
                            int use_pos, int pitch, hipStream_t st) {
     // 16 waves per row block where a lane's state (8 * NCH columns: values + two accumulator words each) fits 128 registers, else 8
     constexpr int NWV = NCH == 1 ? 16 : 8;
-    auto kern = sinkhorn_regress_kernel<TI, NWV, GL, NCH>;
-    const size_t lds = (size_t)(2 + 2 * NWV) * ((w + 4) & ~3) * sizeof(float) + 16;
+    auto kern = sinkhorn_regress_kernel<TI, NWV, GL, NCH, TRI>;
+    size_t lds = (size_t)(2 + 2 * NWV) * ((w + 4) & ~3) * sizeof(float) + 16;
+    if (TRI) {
+        constexpr int VEC = 16 / sizeof(TI);
+        const size_t pieces = (size_t)w + (size_t)VEC * ((size_t)(w / VEC) * (w / VEC - 1) / 2);       // tri_pieces(w): w % VEC == 0
+        const size_t tri_bytes = ((lds + 15) & ~(size_t)15) + pieces * 16;
+        static const bool off = getenv("S2M2_K2_TRI") != nullptr && atoi(getenv("S2M2_K2_TRI")) == 0;   // A/B switch
+        if (!use_pos || off || tri_bytes > 160 * 1024)
+            return launch_sinkhorn<TI, GL, NCH, false>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);
+        lds = tri_bytes;
+    }
     if (lds > 160 * 1024) return set_error("sinkhorn: w=%d needs %zu bytes of LDS (at most about w = 1200)", w, lds);
     static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
     if (reserve_lds(reinterpret_cast<const void*>(kern), lds, lds_granted, "sinkhorn")) return 1;
@@ -358,9 +388,9 @@ static int dispatch_ppl(const void* cv, float* disp, float* conf, float* occ, in
 #define S2M2_K2(GL)                                                                                                          \
     {                                                                                                                        \
         const int nch = (w + 8 * GL - 1) / (8 * GL);                                                                         \
-        if (nch <= 1) return launch_sinkhorn<TI, GL, 1>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
-        if (nch <= 2) return launch_sinkhorn<TI, GL, 2>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
-        if (nch <= 3) return launch_sinkhorn<TI, GL, 3>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
+        if (nch <= 1) return launch_sinkhorn<TI, GL, 1, GL == 16>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
+        if (nch <= 2) return launch_sinkhorn<TI, GL, 2, GL == 16>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
+        if (nch <= 3) return launch_sinkhorn<TI, GL, 3, GL == 16>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);          \
     }
     // (measured at w = 304: 32 lanes per row x 16 waves, 91.7 us, is no faster than 16 lanes x 8 waves, 90.4 us -- the row chain, not
     // the number of resident waves, sets the pace)

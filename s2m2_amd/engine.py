@@ -340,7 +340,10 @@ class Engine:
         if self.use_chain and self.chain_ok(c):
             stages = [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)), (f2[0], f2[1], hip.ACT_NONE, None)]
             if ln_out is not None and hip.mlp_chain_ln_out_supported(c, self.dtype):
-                out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out)
+                # K1 places image row y on XCD y / (h / 8): hand the token rows of that eighth of every image to the same XCD
+                n, h, w, _ = z.shape
+                grp = (h // 8) * w if h % 8 == 0 else 0
+                out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp)
                 return out
             return hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True)
         z = self.cconv(proj, [o], epi=hip.EPI_ADD, aux0=z)

@@ -40,7 +40,8 @@ class ChainDesc(ctypes.Structure):
     _fields_ = [("x", _vp), ("res", _vp), ("out", _vp), ("x_stride", _ll), ("res_stride", _ll), ("out_stride", _ll), ("rows", _ll),
                 ("C", _i), ("nstage", _i), ("weight", _vp * 3), ("bias", _vp * 3), ("ln_wsum", _vp * 3), ("act", _i * 3),
                 ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
-                ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float)]
+                ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float),
+                ("xcd_group_rows", _ll)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -51,6 +52,7 @@ SIGNATURES = {
     "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "s2m2_ln_corr_timed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_ln_corr_banded": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_debug_store_pattern": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_event_create": (_i, [ctypes.POINTER(_vp)]),
     "s2m2_event_destroy": (_i, [_vp]),
     "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
@@ -351,11 +353,12 @@ def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
 
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
-              ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None):
+              ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
     res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
-    ln_out = (gamma fp32 (C), beta fp32 (C), eps): also return LayerNorm(out) * gamma + beta  -> (out, normalised)."""
+    ln_out = (gamma fp32 (C), beta fp32 (C), eps): also return LayerNorm(out) * gamma + beta  -> (out, normalised).
+    xcd_group_rows: placement hint (s2m2_chain_desc): x is images of 8 groups of that many rows, group g runs on XCD g."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_chain")
     d = ChainDesc()
@@ -376,6 +379,7 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
     if not all(t.is_cuda for t in keep if t is not None):
         raise ValueError("mlp_chain: tensors must live on the GPU")
     d.res_stage, d.carry, d.ln_eps = res_stage, int(carry), ln_eps
+    d.xcd_group_rows = int(xcd_group_rows)
     if res_stage >= 0:
         if res is None or res.dtype != x.dtype or tuple(res.shape) != tuple(x.shape):
             raise ValueError("mlp_chain: res must match x")

@@ -87,7 +87,7 @@ def make():
     def mlp_chain_ln_out_supported(C, dtype):
         return C in (128, 256)
 
-    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None):
+    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0):
         t, ys = x.float(), []
         for s, (w, b, act, wsum) in enumerate(stages):
             a = F.layer_norm(t, (t.shape[-1],), eps=ln_eps) if wsum is not None else t

@@ -137,3 +137,18 @@ def test_chain_layernorm_second_output(hip, C, dtype, shp, nst):
     # fp32: summation order of the statistics only;  fp16: one rounding of an O(1..4) value
     assert err < (2e-5 if dtype == torch.float32 else 4e-3), err
     assert not hip.mlp_chain_ln_out_supported(384, torch.float16)
+
+
+def test_chain_xcd_placement_hint_changes_nothing_but_the_block_order(hip):
+    """xcd_group_rows only permutes which block computes which row tile: outputs are bit-identical."""
+    C, dtype = 128, torch.float16
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(2, 64, 152, C, device="cuda", generator=g).to(dtype)             # 2 images x 8 groups x (8 rows x 152) = 1216 rows = 19 tiles of 64
+    res = torch.randn(2, 64, 152, C, device="cuda", generator=g).to(dtype)
+    raw, packed = _make(C, 3, dtype, 1, (0, 1, 0), 11)
+    gam, bet = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    a = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5))
+    b = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), xcd_group_rows=8 * 152)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    c = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, xcd_group_rows=100)      # not a multiple of the tile height: hint ignored
+    assert torch.equal(a[0], c)

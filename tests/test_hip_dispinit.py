@@ -366,7 +366,7 @@ def test_forward_with_folded_layernorm_matches_k1_with_its_own(monkeypatch):
     from s2m2_amd.model import S2M2
     from s2m2_amd.weights import seeded_state_dict, synthetic_pair
     sd = seeded_state_dict(128, 1, 1, 0)
-    l, r = synthetic_pair(128, 640, 1, 24, 3)
+    l, r = synthetic_pair(128, 608, 1, 24, 3)                 # w = 152: 608-byte fp32 rows, padded to 640 bytes (pitch 160)
     l, r = l.cuda(), r.cuda()
     caps = []
     for fold in ("1", "0"):

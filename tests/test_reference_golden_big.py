@@ -1,7 +1,7 @@
 """BASELINE configs[3] (L, CH=256 NTR=3, 1216x1024, refine_iter 3) and configs[4] (XL, CH=384 NTR=3, 2432x2048, allow_negative) against
 the REFERENCE itself: tests/golden/e2e_L_1216x1024_fp32_r3_sub.npz / e2e_XL_2432x2048_fp32_r1_neg_sub.npz hold outputs of the
 unmodified reference module (tests/golden/make_golden_big.py: sub-sampled transformer features, complete cost-volume rows, complete
-DispInit outputs with integer argmax and top-2 gap, global-refiner disparity, sub-sampled final maps), in fp32.
+DispInit outputs with integer argmax and top-2 relative gap, global-refiner disparity, sub-sampled final maps), in fp32.
 
 GPU (the HIP fp32 forward at these geometries: K1 wide-C strips, K2 with 32 lanes per row at w = 608, K4 at d = 64 / 96 / 256 / 384 and
 N = 1216 / 4864 incl. the PE variant with (3, 2) bin tiles, K5 at Cin = 256 ... 768, K9 / K10 or their K5 fallbacks at C = 256 ... 768):
@@ -34,9 +34,12 @@ def _load(name):
                    sub=int(g["sub"]), fsub=int(g["fsub"]), cvsub=int(g["cvsub"]), gsub=int(g["gsub"]))
 
 
-def _sure(g, c):
-    h, w = c["H"] // 4, c["W"] // 4
-    return torch.as_tensor(np.unpackbits(g["sure0"])[:c["B"] * h * w].reshape(c["B"], h, w).astype(bool))
+def _sure(g, c, cv_err=0.0):
+    """Pixels whose integer argmax must be reproduced bit for bit: the reference's own top-2 relative gap of the masked transport
+    probabilities exceeds what fp32 summation order of the correlation sums can move.  P ~ exp(S + ...): an error e in two scores moves
+    the relative gap by up to 2e, so the threshold is max(1e-4, 4 x the largest cost-volume error measured in this test) -- 1e-4 at
+    C = 128 (|cv| ~ 128, errors ~1e-4), ~2e-3 at C = 384 (|cv| ~ 380: one fp32 ulp is 3e-5, sums of 384 terms differ by ~5e-4)."""
+    return torch.as_tensor(g["gap0"].astype(np.float32))[:, 0] > max(1e-4, 4.0 * cv_err)
 
 
 def _t(a):
@@ -57,7 +60,7 @@ def test_golden_rows_are_reproduced_by_the_oracles_dispinit(name):
     rows = slice(None, None, c["cvsub"])
     P = O.sinkhorn_prob(cv, c["pos"])
     d, cf, oc, ind = O.regress(P)
-    sure = _sure(g, c)[:, rows]
+    sure = _sure(g, c, 1e-4)[:, rows]                       # (the oracle runs on the reference's own cv rows: only the OT sums differ)
     am_ref = torch.as_tensor(g["argmax"].astype(np.int32))[:, rows]
     assert bool((ind.int() == am_ref)[sure].all()) and float(sure.float().mean()) > 0.99
     same = ind.int() == am_ref
@@ -83,7 +86,7 @@ def test_hip_fp32_against_the_reference(name):
     assert report["cv"][0] <= 1e-3, report
     am_ref = torch.as_tensor(g["argmax"].astype(np.int32))
     same = hcap["argmax"].int() == am_ref
-    sure = _sure(g, c)
+    sure = _sure(g, c, report["cv"][1])
     report["argmax"] = (float(same.float().mean()), float(sure.float().mean()), int((~same[sure]).sum()))
     assert report["argmax"][2] == 0 and report["argmax"][0] >= 0.995, report
     flipped = 1.0 - report["argmax"][0]

@@ -31,10 +31,13 @@ class Tracer:
             if not self.on:
                 return f(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if self.real.METER is None:
+                self.real.METER = {}
+            fl0 = sum(v[0] for v in self.real.METER.values())
             e0.record()
             r = f(*a, **k)
             e1.record()
-            self.log.append((name, self.sig(name, a, k), e0, e1))
+            self.log.append((name, self.sig(name, a, k), e0, e1, sum(v[0] for v in self.real.METER.values()) - fl0))
             return r
         return wrapped
 
@@ -78,7 +81,7 @@ def ab(a):
     aggs = []
     for lg in logs:
         agg = collections.OrderedDict()
-        for name, sig, e0, e1 in lg:
+        for name, sig, e0, e1, _fl in lg:
             d = agg.setdefault((name, sig.replace(" frag", "")), [0, 0.0])
             d[0] += 1; d[1] += e0.elapsed_time(e1) * 1e3
         aggs.append(agg)
@@ -116,19 +119,23 @@ def main():
         eng.run(left, right)
     torch.cuda.synchronize()
     agg = collections.OrderedDict()
-    for name, sig, e0, e1 in tr.log:
-        d = agg.setdefault((name, sig), [0, 0.0])
-        d[0] += 1; d[1] += e0.elapsed_time(e1) * 1e3
+    for name, sig, e0, e1, fl in tr.log:
+        d = agg.setdefault((name, sig), [0, 0.0, 0.0])
+        d[0] += 1; d[1] += e0.elapsed_time(e1) * 1e3; d[2] += fl
     tot = sum(v[1] for v in agg.values()) / a.iters
     print("total traced GPU time per pass: %.2f ms (eager, event-bracketed; includes ~2-4 us event overhead per call)" % (tot / 1e3))
     by = collections.defaultdict(float)
-    for (name, sig), (n, t) in agg.items():
+    for (name, sig), (n, t, fl) in agg.items():
         by[name] += t / a.iters
     for name, t in sorted(by.items(), key=lambda x: -x[1]):
         print("  %-18s %8.1f us  %5.1f%%" % (name, t, 100 * t / tot))
     print()
-    for (name, sig), (n, t) in sorted(agg.items(), key=lambda x: -x[1][1]):
-        print("%-16s %-58s calls/pass %3d  avg %7.1f us  total %8.1f us  %4.1f%%" % (name, sig, n // a.iters, t / n, t / a.iters, 100 * t / a.iters / tot))
+    # last column: time this row would save per pass if it ran at 700 TFLOP/s (what the large 3x3 layers reach) -- where the MFMA time is lost
+    for (name, sig), (n, t, fl) in sorted(agg.items(), key=lambda x: -x[1][1]):
+        tf = fl / (t * 1e-6) / 1e12 if fl > 0 else 0.0
+        lost = (t - fl / 700e12 * 1e6) / a.iters if fl > 0 else 0.0
+        print("%-16s %-58s calls/pass %3d  avg %7.1f us  total %8.1f us  %4.1f%%  %6.1f TF/s  over-700: %7.1f us" %
+              (name, sig, n // a.iters, t / n, t / a.iters, 100 * t / a.iters / tot, tf, lost))
 
 
 if __name__ == "__main__":
