@@ -84,6 +84,17 @@ int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_p
  * wave in 128-byte segments exactly like the kernel's store loop, no loads / MFMA; 1: the same with non-temporal stores; 2 / 3: the same
  * bytes as one linear stream (3: non-temporal).  fp16 volume of `rows` rows of w x cv_pitch; events as s2m2_ln_corr_timed. */
 int s2m2_debug_store_pattern(void* cv, int rows, int w, int cv_pitch, int mode, void* stream, void* start_event, void* stop_event);
+/*
+ * [A4] K1 in its streaming form: the correlation on fp16 tokens that are normalised AND stored in MFMA-fragment order by the launch that
+ *   produced them (s2m2_chain_desc.ln_out_tile_w).  No LDS staging of tokens, no block barrier: a wave owns 32 left tokens in registers
+ *   and streams the right row tile by tile with coalesced 1 KB fragment loads, so the loads of one wave run under the stores of another
+ *   (the LDS form of s2m2_corr / s2m2_ln_corr loads, meets at a barrier, then stores: with one image row per CU the two phases add up).
+ *   tokens_tiled: s2m2_corr_tiled_bytes(B, h, w, C) bytes; cv, cv_pitch, band, events: as s2m2_corr.  C = 64 / 128 / 256 (fp16 volume),
+ *   128 (fp32 volume).
+ */
+size_t s2m2_corr_tiled_bytes(int B, int h, int w, int C);
+int s2m2_corr_tiled(const void* tokens_tiled, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype, int band,
+                    void* stream, void* start_event, void* stop_event);
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);
@@ -217,6 +228,10 @@ typedef struct s2m2_chain_desc {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_out_eps;
+    /* > 0 (fp16 only): ln_out is written in the MFMA-fragment order s2m2_corr_tiled reads -- the rows are image rows of ln_out_tile_w
+       tokens, cut into 32-token tiles; the 16-byte piece (token x of image row r, channels 8p .. 8p+7) goes to 16-byte slot
+       ((r * ceil(w/32) + x/32) * (C/16) + p/2) * 64 + (p%2) * 32 + x%32 of a buffer of s2m2_corr_tiled_bytes(); ln_out_stride is ignored. */
+    int ln_out_tile_w;
     /* placement hint, 0 = none: the rows are `rows / (8 * xcd_group_rows)` images of 8 groups of xcd_group_rows consecutive rows each;
        group g of every image is processed on XCD g (blocks are dealt to XCDs round robin by the hardware), so that a consumer which
        places its work the same way -- s2m2_corr: image row y on XCD y / (h / 8) -- reads these rows from the L2 that holds them. */

@@ -42,6 +42,7 @@ struct ChainArgs {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_out_eps;
+    int ln_tile_w;                      // > 0: ln_out in the MFMA-fragment order of s2m2_corr_tiled, the rows being image rows of ln_tile_w tokens
     // > 0: row tiles are handed to blocks so that the XCD a block runs on (hardware: block b on XCD b % 8) owns the tiles of ONE eighth of
     // every image -- xcd_tiles consecutive tiles per image and XCD.  The consumer K1 places image row y on XCD y / (h / 8): it then finds the
     // normalised tokens in the L2 of the XCD that wrote them.
@@ -265,7 +266,18 @@ struct ChainStage {
                     Vec16<T> o;
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
-                    if (m < p.rows) *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
+                    if (m < p.rows) {
+                        if (sizeof(T) == 2 && p.ln_tile_w > 0) {
+                            // fragment order: 32-token tile t of image row rid, k16 step kk = pcx / 2, half hh = pcx % 2 -> 16-byte slot
+                            // ((rid * NT + t) * KS + kk) * 64 + hh * 32 + token % 32   (what a lane of K1 loads for its MFMA operand)
+                            const long long rid = m / p.ln_tile_w;
+                            const int x = (int)(m - rid * p.ln_tile_w);
+                            const long long slot = ((rid * ((p.ln_tile_w + 31) >> 5) + (x >> 5)) * (C / 16) + (pcx >> 1)) * 64 + (pcx & 1) * 32 + (x & 31);
+                            reinterpret_cast<Vec16<T>*>(p.ln_out)[slot] = o;
+                        } else {
+                            *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
+                        }
+                    }
                 }
             }
         }
@@ -372,11 +384,14 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     S2M2_REQUIRE(!any_ln || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
     a.res_stage = d->res_stage; a.carry = d->carry; a.ln_eps = d->ln_eps;
     a.ln_out = d->ln_out; a.ln_out_stride = d->ln_out_stride; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out_eps = d->ln_out_eps;
+    a.ln_tile_w = d->ln_out_tile_w;
     if (d->ln_out) {
         const int ppr = d->C * (d->dtype == S2M2_F16 ? 2 : 4) / 16;      // 16-byte pieces per row = lanes that share a row in the store pass
         S2M2_REQUIRE(ppr == 16 || ppr == 32 || ppr == 64, "mlp_chain: ln_out needs a row of 16, 32 or 64 pieces (C=%d has %d)", d->C, ppr);
         S2M2_REQUIRE(d->ln_gamma && d->ln_beta && d->ln_out_eps > 0.f && d->ln_out_stride >= d->C && d->ln_out_stride % 8 == 0,
                      "mlp_chain: ln_out needs gamma, beta, a positive eps and a row stride that is a multiple of 8");
+        S2M2_REQUIRE(d->ln_out_tile_w >= 0 && (d->ln_out_tile_w == 0 || (d->dtype == S2M2_F16 && d->rows % d->ln_out_tile_w == 0)),
+                     "mlp_chain: ln_out_tile_w=%d needs fp16 rows that are whole image rows of that many tokens", d->ln_out_tile_w);
     }
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "mlp_chain: cannot allocate the zero page");

@@ -504,6 +504,93 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 }
 
 // ------------------------------------------------------------------------------------------------
+// K1, streaming form (s2m2_corr_tiled; fp16 tokens, normalised by their producer and stored IN MFMA FRAGMENT ORDER):
+//
+// The LDS form above is phase-serial: every wave of a row loads (5 us at c3), the block meets at a barrier, then every wave stores
+// (11 us) -- and with one image row per CU (B = 1: 256 rows, 256 CUs) nothing else runs on the CU while either phase waits on the memory
+// system.  The store loop ALONE takes 8.5 us, loads alone ~5 (profiles/r03/k1_store_path.txt): the kernel's 18.4 us is their sum plus
+// launch, not their maximum.  Here a wave shares NOTHING with its neighbours: it owns 32 left tokens (8 fragment registers for C = 128)
+// and walks the right row pair by pair of 32-token tiles, reading each tile's fragments with perfectly coalesced 1 KB loads
+// (fragment f of tile t at ((row * NT + t) * KS + f) * 1 KB + lane * 16 B -- the layout the producing s2m2_mlp_chain launch writes:
+// s2m2_chain_desc.ln_out_tile_w), multiplying, staging, storing.  No LDS for tokens, no block barrier; the ten waves of a row are at
+// different points of that loop, so one wave's tile loads run under another wave's stores.  The right row is read ten times per row
+// from L1 / L2 (78 KB x 10 per CU at 64 B/clk = 6 us, under the stores) instead of once into LDS.
+// ------------------------------------------------------------------------------------------------
+template <int C, typename TO>
+__global__ __launch_bounds__(1024) void corr_stream_kernel(const raw16_t* __restrict__ frag, TO* __restrict__ cv, int B, int h, int w,
+                                                            int NT, int nsplit, int band, int pitch, int flags) {
+    constexpr int KS = C / 16;
+    constexpr int VECO = 16 / sizeof(TO), CRS = 64 + VECO;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int NWB = blockDim.x >> 6;
+    TO* Wc = reinterpret_cast<TO*>(smem) + (size_t)wv * 32 * CRS;            // this wave's 32 x 64 staging tile
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int row = bid / nsplit;                        // (b, y)
+    const int part = bid - row * nsplit;
+    const int b = row / h, y = row - b * h;
+    const int lt = part * NWB + wv;                      // left tile of this wave
+    if (lt >= NT) return;
+    const int i0 = lt * 32;
+    const raw16_t* L = frag + ((size_t)((size_t)(b * h + y) * NT + lt) * KS) * 64 + lane;
+    const raw16_t* R = frag + ((size_t)((size_t)((B + b) * h + y) * NT) * KS) * 64 + lane;
+    TO* cvrow = cv + (size_t)row * w * pitch;
+    Frag<half_t> af[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) af[kk].v = __builtin_bit_cast(half8_t, L[kk * 64]);
+    int npair = (NT + 1) >> 1;
+    if (band >= 0) {                                     // banded volume: this wave's rows need columns up to i0 + 31 + band only
+        const int need = (i0 + 31 + band) / 64 + 1;
+        npair = npair < need ? npair : need;
+    }
+    const int stagger = (flags & 2) ? lt : 0;            // A/B: every wave starts at its own pair (spreads the stores, costs L1 reuse)
+    for (int pp = 0; pp < npair; ++pp) {
+        int pr = pp + stagger;
+        pr = pr >= npair ? pr % npair : pr;
+        const int ct0 = 2 * pr;
+        const bool two = ct0 + 1 < NT;
+        const raw16_t* r0 = R + (size_t)ct0 * KS * 64;
+        const raw16_t* r1 = two ? r0 + KS * 64 : r0;
+        raw16_t q0[KS], q1[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) { q0[kk] = global_load16(r0 + kk * 64); q1[kk] = global_load16(r1 + kk * 64); }
+        float16_t acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            Frag<half_t> b0, b1;
+            b0.v = __builtin_bit_cast(half8_t, q0[kk]);
+            b1.v = __builtin_bit_cast(half8_t, q1[kk]);
+            mma32(acc0, b0, af[kk]);                      // D[j][i]: lane = left pixel i, registers = right pixels j
+            mma32(acc1, b1, af[kk]);
+        }
+        TO* wrow = Wc + (size_t)(lane & 31) * CRS + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            store_quad<TO>(wrow + 8 * g, acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
+            store_quad<TO>(wrow + 32 + 8 * g, acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        constexpr int PPR = 64 / VECO;                    // 16-B pieces per staged row (64 columns)
+        constexpr int ITERS = 32 * PPR / 64;
+        const int j0 = ct0 * 32;
+        const int jlim = two ? j0 + 64 : j0 + 32;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int q = it * 64 + lane;
+            const int rr = q / PPR, pc = q - rr * PPR;
+            const int i = i0 + rr;
+            const int j = j0 + pc * VECO;
+            const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CRS + pc * VECO);
+            if (i < w && j < w && j < jlim) store_cv(cvrow + (size_t)i * pitch + j, v, flags & 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 // s2m2_ln_corr_timed: events attached to the next launch of the calling thread (hipExtLaunchKernel records them at the start and
@@ -618,6 +705,51 @@ extern "C" int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const fl
     const int rc = s2m2_ln_corr_timed(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream, start_event, stop_event);
     s2m2::g_band = -1;
     return rc;
+}
+
+template <int C, typename TO>
+static int launch_corr_stream(const void* frag, void* cv, int B, int h, int w, int pitch, int band, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    using namespace s2m2;
+    auto kern = corr_stream_kernel<C, TO>;
+    const int NT = (w + 31) / 32;
+    // waves per block: a whole row when it fits 12 resident waves per CU (<= 170 registers), else the row in equal parts
+    int nsplit = (NT + 11) / 12;
+    static const int force_split = getenv("S2M2_K1_SPLIT") ? atoi(getenv("S2M2_K1_SPLIT")) : 0;       // tuning knob: blocks per image row
+    if (force_split > 0 && force_split <= NT) nsplit = force_split;
+    const int nwb = (NT + nsplit - 1) / nsplit;
+    const size_t lds = (size_t)nwb * 32 * (64 + 16 / sizeof(TO)) * sizeof(TO);
+    static size_t lds_granted[kMaxDevices] = {};
+    if (reserve_lds(reinterpret_cast<const void*>(kern), lds, lds_granted, "corr_tiled")) return 1;
+    static const int k1_flags = (getenv("S2M2_K1_NT") && atoi(getenv("S2M2_K1_NT")) != 0 ? 1 : 0) |
+                                (getenv("S2M2_K1_STAGGER") && atoi(getenv("S2M2_K1_STAGGER")) != 0 ? 2 : 0);      // A/B switches
+    hipExtLaunchKernelGGL(kern, dim3(B * h * nsplit), dim3(nwb * 64), lds, st, e0, e1, 0, static_cast<const raw16_t*>(frag),
+                          static_cast<TO*>(cv), B, h, w, NT, nsplit, band, pitch, k1_flags);
+    return check_launch("corr_tiled");
+}
+
+extern "C" size_t s2m2_corr_tiled_bytes(int B, int h, int w, int C) {
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return 0;
+    return (size_t)2 * B * h * ((w + 31) / 32) * 32 * C * 2;          // fp16, rows padded to whole 32-token tiles
+}
+
+extern "C" int s2m2_corr_tiled(const void* tokens_tiled, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype, int band,
+                               void* stream, void* start_event, void* stop_event) {
+    using namespace s2m2;
+    S2M2_REQUIRE(tokens_tiled && cv, "corr_tiled: null pointer");
+    S2M2_REQUIRE(B > 0 && h > 0 && w > 0 && w % 8 == 0, "corr_tiled: bad shape B=%d h=%d w=%d (w a multiple of 8)", B, h, w);
+    if (cv_pitch == 0) cv_pitch = w;
+    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "corr_tiled: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t e0 = static_cast<hipEvent_t>(start_event), e1 = static_cast<hipEvent_t>(stop_event);
+    const int bnd = band >= 0 ? band : -1;
+    if (cv_dtype == S2M2_F16) {
+        if (C == 64) return launch_corr_stream<64, half_t>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
+        if (C == 128) return launch_corr_stream<128, half_t>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
+        if (C == 256) return launch_corr_stream<256, half_t>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
+    } else if (cv_dtype == S2M2_F32) {
+        if (C == 128) return launch_corr_stream<128, float>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
+    }
+    return set_error("corr_tiled: unsupported C=%d / cv dtype %d (fp16 tokens; C = 64, 128, 256 with an fp16 volume, C = 128 with fp32)", C, cv_dtype);
 }
 
 extern "C" int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,

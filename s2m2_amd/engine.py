@@ -110,7 +110,10 @@ class Engine:
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
         self.cv_aligned = os.environ.get("S2M2_CV_ALIGNED", "1") != "0"  # A/B switch: 0 = dense cost-volume rows (pitch = w)
-        self._tokens_normed: Optional[Tensor] = None
+        # A/B switch: 0 = K1 in its LDS form on row-major normalised tokens (hip.corr) instead of the streaming form on fragment-ordered
+        # tokens (hip.corr_tiled; fp16 only -- the fp32 parity mode always runs the LDS form)
+        self.k1_stream = os.environ.get("S2M2_K1_STREAM", "1") != "0"
+        self._tokens_normed = None                               # Tensor (row-major) or hip.TiledTokens (fragment order)
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
@@ -343,7 +346,9 @@ class Engine:
                 # K1 places image row y on XCD y / (h / 8): hand the token rows of that eighth of every image to the same XCD
                 n, h, w, _ = z.shape
                 grp = (h // 8) * w if h % 8 == 0 else 0
-                out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp)
+                tiled = self.k1_stream and hip.corr_tiled_supported(c, self.dtype)     # fragment order for the streaming form of K1
+                out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp,
+                                                         ln_out_tiled=tiled)
                 return out
             return hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True)
         z = self.cconv(proj, [o], epi=hip.EPI_ADD, aux0=z)
@@ -519,6 +524,8 @@ class Engine:
         if normed is not None:
             if out is None:
                 out = self.cv_buffer(tr)
+            if isinstance(normed, hip.TiledTokens):
+                return hip.corr_tiled(normed, out=out, timer=timer, band=band)
             return hip.corr(normed, out=out, timer=timer, band=band)
         return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer, band=band)
 

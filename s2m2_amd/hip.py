@@ -41,7 +41,7 @@ class ChainDesc(ctypes.Structure):
                 ("C", _i), ("nstage", _i), ("weight", _vp * 3), ("bias", _vp * 3), ("ln_wsum", _vp * 3), ("act", _i * 3),
                 ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
                 ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float),
-                ("xcd_group_rows", _ll)]
+                ("ln_out_tile_w", _i), ("xcd_group_rows", _ll)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -58,6 +58,8 @@ SIGNATURES = {
     "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "s2m2_sinkhorn_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "s2m2_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_corr_tiled_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
+    "s2m2_corr_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
@@ -197,6 +199,52 @@ def cv_alloc(B: int, h: int, w: int, dtype: torch.dtype, device, aligned: bool =
     per = 128 // (2 if dtype == torch.float16 else 4)
     pitch = (w + per - 1) // per * per if aligned else w
     return torch.empty((B, h, w, pitch), device=device, dtype=dtype)[..., :w]
+
+
+class TiledTokens:
+    """Normalised fp16 tokens of a stereo pair batch (2B,h,w,C) in the MFMA-fragment order of s2m2_corr_tiled (written by
+    mlp_chain(..., ln_out_tiled=True)): image rows cut into 32-token tiles, a tile = C/16 fragments of 1 KB (lane-major)."""
+
+    def __init__(self, B: int, h: int, w: int, C: int, device):
+        self.B, self.h, self.w, self.C = B, h, w, C
+        n = int(load().s2m2_corr_tiled_bytes(B, h, w, C))
+        self.buf = torch.empty(n // 2, device=device, dtype=torch.float16)
+
+    @staticmethod
+    def from_rows(tokens: torch.Tensor) -> "TiledTokens":
+        """(2B,h,w,C) fp16 rows -> fragment order (test / tool helper; the engine's tokens arrive tiled from K9)"""
+        twoB, h, w, C = tokens.shape
+        t = TiledTokens(twoB // 2, h, w, C, tokens.device)
+        nt = (w + 31) // 32
+        x = torch.zeros((twoB, h, nt * 32, C), device=tokens.device, dtype=torch.float16)
+        x[:, :, :w] = tokens
+        # (n, y, tile, r, kk, hh, e) -> (n, y, tile, kk, hh, r, e)
+        x = x.reshape(twoB, h, nt, 32, C // 16, 2, 8).permute(0, 1, 2, 4, 5, 3, 6).contiguous()
+        t.buf.copy_(x.reshape(-1))
+        return t
+
+    def to_rows(self) -> torch.Tensor:
+        nt = (self.w + 31) // 32
+        x = self.buf.reshape(2 * self.B, self.h, nt, self.C // 16, 2, 32, 8).permute(0, 1, 2, 5, 3, 4, 6)
+        return x.reshape(2 * self.B, self.h, nt * 32, self.C)[:, :, :self.w].contiguous()
+
+
+def corr_tiled(tokens: TiledTokens, cv_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None,
+               timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
+    """K1, streaming form (s2m2_corr_tiled) -> cv (B,h,w,w), a row-padded view (cv_alloc) unless ``out`` is given."""
+    B, h, w, C = tokens.B, tokens.h, tokens.w, tokens.C
+    cv = out if out is not None else cv_alloc(B, h, w, cv_dtype, tokens.buf.device)
+    if tuple(cv.shape) != (B, h, w, w):
+        raise ValueError("corr_tiled: out must be a (B,h,w,w) tensor")
+    pitch = _cv_pitch(cv, "corr_tiled")
+    _check(load().s2m2_corr_tiled(tokens.buf.data_ptr(), cv.data_ptr(), B, h, w, C, pitch, _DT[cv.dtype], band, _stream(),
+                                  timer.start if timer is not None else None, timer.stop if timer is not None else None), "s2m2_corr_tiled")
+    _meter("ln_corr", 2.0 * B * h * w * w * C)
+    return cv
+
+
+def corr_tiled_supported(C: int, dtype: torch.dtype) -> bool:
+    return dtype == torch.float16 and C in (64, 128, 256)
 
 
 def corr(tokens: torch.Tensor, cv_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
@@ -353,12 +401,14 @@ def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
 
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
-              ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0):
+              ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0,
+              ln_out_tiled: bool = False):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
     res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
     ln_out = (gamma fp32 (C), beta fp32 (C), eps): also return LayerNorm(out) * gamma + beta  -> (out, normalised).
-    xcd_group_rows: placement hint (s2m2_chain_desc): x is images of 8 groups of that many rows, group g runs on XCD g."""
+    xcd_group_rows: placement hint (s2m2_chain_desc): x is images of 8 groups of that many rows, group g runs on XCD g.
+    ln_out_tiled (x (N,h,w,C) fp16): the normalised rows come back as a TiledTokens buffer in the fragment order corr_tiled reads."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_chain")
     d = ChainDesc()
@@ -392,8 +442,16 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
         _dev(gam, bet)
         if gam.dtype != torch.float32 or bet.dtype != torch.float32 or gam.numel() != C or bet.numel() != C:
             raise ValueError(f"mlp_chain: ln_out gamma / beta must be fp32 ({C})")
-        normed = torch.empty(x.shape, device=x.device, dtype=x.dtype)
-        d.ln_out, d.ln_out_stride, d.ln_gamma, d.ln_beta, d.ln_out_eps = normed.data_ptr(), C, gam.data_ptr(), bet.data_ptr(), float(eps)
+        if ln_out_tiled:
+            if x.dim() != 4 or x.dtype != torch.float16 or x.shape[0] % 2:
+                raise ValueError("mlp_chain: ln_out_tiled needs (2B,h,w,C) fp16 rows")
+            normed = TiledTokens(x.shape[0] // 2, x.shape[1], x.shape[2], C, x.device)
+            d.ln_out_tile_w = x.shape[2]
+            ln_ptr = normed.buf.data_ptr()
+        else:
+            normed = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+            ln_ptr = normed.data_ptr()
+        d.ln_out, d.ln_out_stride, d.ln_gamma, d.ln_beta, d.ln_out_eps = ln_ptr, C, gam.data_ptr(), bet.data_ptr(), float(eps)
     _check(load().s2m2_mlp_chain(ctypes.byref(d), _stream()), "s2m2_mlp_chain")
     _meter("mlp_chain", 2.0 * rows * C * C * len(stages))
     return out if normed is None else (out, normed)

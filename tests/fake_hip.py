@@ -87,7 +87,13 @@ def make():
     def mlp_chain_ln_out_supported(C, dtype):
         return C in (128, 256)
 
-    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0):
+    def corr_tiled_supported(C, dtype):
+        return False                                     # (the CPU stand-in keeps row-major tokens: the fp32 wiring test never tiles)
+
+    class TiledTokens:                                   # only the isinstance() check of Engine.cost_volume needs it
+        pass
+
+    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0, ln_out_tiled=False):
         t, ys = x.float(), []
         for s, (w, b, act, wsum) in enumerate(stages):
             a = F.layer_norm(t, (t.shape[-1],), eps=ln_eps) if wsum is not None else t
@@ -205,6 +211,7 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, corr_tiled_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
+    ns.TiledTokens = TiledTokens
     return ns

@@ -152,3 +152,18 @@ def test_chain_xcd_placement_hint_changes_nothing_but_the_block_order(hip):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     c = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, xcd_group_rows=100)      # not a multiple of the tile height: hint ignored
     assert torch.equal(a[0], c)
+
+
+def test_chain_layernorm_output_in_fragment_order(hip):
+    """ln_out_tiled: the same normalised rows, stored in the MFMA-fragment order s2m2_corr_tiled reads (ragged last 32-token tile)."""
+    C, dtype = 128, torch.float16
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = (torch.randn(2, 5, 72, C, device="cuda", generator=g) * 2).to(dtype)         # w = 72: tiles of 32, 32, 8 tokens
+    res = torch.randn(2, 5, 72, C, device="cuda", generator=g).to(dtype)
+    raw, packed = _make(C, 3, dtype, 1, (0, 1, 0), 21)
+    gam = 1 + 0.1 * torch.randn(C, device="cuda", generator=g)
+    bet = 0.05 * torch.randn(C, device="cuda", generator=g)
+    y0, n0 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5))
+    y1, t1 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), ln_out_tiled=True)
+    assert torch.equal(y0, y1) and isinstance(t1, hip.TiledTokens)
+    assert torch.equal(t1.to_rows(), n0)

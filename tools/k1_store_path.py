@@ -2,7 +2,7 @@
 """What does the memory system give K1's store phase?  ("commit a store-only microbench of the same 47.3 MB pattern
 from 256 single-row blocks".)  Every number is the kernel's own execution time (start / stop HIP events attached to the dispatch):
 
-  * K1 as shipped for the case (LayerNorm inside / normalised tokens, dense / 128-byte-aligned rows),
+  * K1 in its three forms (LayerNorm inside / normalised tokens through LDS / streaming on fragment-ordered tokens; dense / 128-byte-aligned rows),
   * its store loop ALONE (s2m2_debug_store_pattern mode 0: same blocks, same waves, same 128-byte segments, no loads, no MFMA),
   * the same bytes as one linear stream of 16-byte stores from 2048 blocks (mode 2) -- the plain write ceiling of the box,
   * non-temporal variants of both (modes 1 / 3; K1 itself: run with S2M2_K1_NT=1).
@@ -49,11 +49,15 @@ def main():
 
     def row(name, fn, nbytes):
         med, mn = timed(fn)
-        print(f"  {name:<62}{med:7.2f} us ({mn:6.2f})  {nbytes / med / 1e6:6.2f} TB/s of its bytes")
+        print(f"  {name:<80}{med:7.2f} us ({mn:6.2f})  {nbytes / med / 1e6:6.2f} TB/s of its bytes")
 
     row("K1 with its LayerNorm, dense rows (s2m2_ln_corr)", lambda t: hip.ln_corr(feat, g, b, out=dense, timer=t), allbytes)
     row("K1 on normalised tokens, dense rows (s2m2_corr)", lambda t: hip.corr(normed, out=dense, timer=t), allbytes)
     row(f"K1 on normalised tokens, rows on 128-byte lines (pitch {padded.stride(2)})", lambda t: hip.corr(normed, out=padded, timer=t), allbytes)
+
+    tiled = hip.TiledTokens.from_rows(normed)
+    row("K1 streaming form on fragment-ordered tokens, dense rows (s2m2_corr_tiled)", lambda t: hip.corr_tiled(tiled, out=dense, timer=t), allbytes)
+    row(f"K1 streaming form, rows on 128-byte lines (pitch {padded.stride(2)})", lambda t: hip.corr_tiled(tiled, out=padded, timer=t), allbytes)
 
     def pat(buf, mode):
         def f(t):
@@ -73,7 +77,7 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
-    print(f"  {'256 MiB fill (torch zero_, events around 10 launches)':<62}{us:7.2f} us           {big.numel() / us / 1e6:6.2f} TB/s")
+    print(f"  {'256 MiB fill (torch zero_, events around 10 launches)':<80}{us:7.2f} us           {big.numel() / us / 1e6:6.2f} TB/s")
 
 
 if __name__ == "__main__":
