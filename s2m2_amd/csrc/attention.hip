@@ -53,7 +53,13 @@ struct AttnCfg {
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int KSTEPS = DP / 16;
     static constexpr int ND = (DP + 31) / 32;            // 32-wide output d tiles
-    static constexpr int KT = DP <= 64 ? 4 : (DP <= 128 ? 2 : 1);   // 32-key sub-tiles staged per block barrier (latency amortisation)
+    // 32-key sub-tiles staged per block barrier (latency amortisation).  Key-split blocks (few, long rows: the 2-D attention at 1/32, 1216
+    // keys x 16 (batch, head) pairs) are latency chains of stage barriers with 4 MFMAs per wave between them: fp16 stages of 256 keys
+    // (two sub-tiles per wave and stage) halve the number of barriers
+#ifndef S2M2_ATTN_KSPLIT_KT
+#define S2M2_ATTN_KSPLIT_KT 8            // (experiment builds: 4 = the round-2 stages of 128 keys)
+#endif
+    static constexpr int KT = (KSPLIT_ && sizeof(T) == 2 && DP_ <= 64) ? S2M2_ATTN_KSPLIT_KT : (DP <= 64 ? 4 : (DP <= 128 ? 2 : 1));
     static constexpr int KVT = 32 * KT;                  // keys per stage
     static constexpr int KRS = DP + VEC;                 // K tile row stride (elements)
     static constexpr int VRS = KVT + 4;                  // Vt row stride (elements): keys of one stage + pad
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
         if (t + 1 < nstage) fetch((t + 1) * KVT);                 // in flight under this stage's MFMAs
         if (wave_active) {
 #pragma unroll 1
-            for (int sub = CFG::KSPLIT ? wv : 0; sub < (CFG::KSPLIT ? wv + 1 : CFG::KT); ++sub) {
+            for (int sub = CFG::KSPLIT ? wv : 0; sub < CFG::KT; sub += CFG::KSPLIT ? 4 : 1) {
                 const int kv0 = t * KVT + sub * 32;
                 if (kv0 >= a.Nk) break;
                 // ---- S^T = K . Q^T
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
 
     if constexpr (CFG::KSPLIT) {
         // ---- the four waves hold partial (max, sum, O, pe) over disjoint key subsets of the SAME 32 queries: merge through LDS
-        static_assert(CFG::KT == 4, "key split uses one 32-key sub-tile per wave and stage");
+        static_assert(CFG::KT % 4 == 0, "key split: every wave takes every fourth 32-key sub-tile of a stage");
         __syncthreads();                                          // K/V staging is dead: reuse the space (the PE area lies behind it)
         float* mm = reinterpret_cast<float*>(smem);               // [4][32] running max
         float* ml = mm + 128;                                     // [4][32] running sum

@@ -1537,7 +1537,7 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         // co-resident block slots (2 per CU) times MFMA tiles per block (tile 40 forces it, S2M2_FRAG_PW=32 switches it off)
         static const int force_pw = getenv("S2M2_FRAG_PW") ? atoi(getenv("S2M2_FRAG_PW")) : 0;         // A/B switch
         bool wide = false;
-        static const int aux_pw = getenv("S2M2_FRAG_AUX_PW") ? atoi(getenv("S2M2_FRAG_AUX_PW")) : 0;     // A/B switch: 40 = one-operand layers on 160-pixel blocks too
+        static const int aux_pw = getenv("S2M2_FRAG_AUX_PW") ? atoi(getenv("S2M2_FRAG_AUX_PW")) : 40;    // A/B switch: 32 = one-operand layers on 64-pixel blocks only
         const bool one_op = a.epi == S2M2_EPI_ADD || a.epi == S2M2_EPI_MUL;
         if (one_op && (tile == 40 || (tile == 0 && aux_pw == 40 && force_ph == 0))) {
             const long long b4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.Cout / 128);

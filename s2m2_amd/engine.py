@@ -110,9 +110,11 @@ class Engine:
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
         self.cv_aligned = os.environ.get("S2M2_CV_ALIGNED", "1") != "0"  # A/B switch: 0 = dense cost-volume rows (pitch = w)
-        # A/B switch: 0 = K1 in its LDS form on row-major normalised tokens (hip.corr) instead of the streaming form on fragment-ordered
-        # tokens (hip.corr_tiled; fp16 only -- the fp32 parity mode always runs the LDS form)
-        self.k1_stream = os.environ.get("S2M2_K1_STREAM", "1") != "0"
+        # opt-in experiment (S2M2_K1_STREAM=1, fp16): K9 writes the normalised tokens in MFMA-fragment order and K1 runs its streaming
+        # form (hip.corr_tiled: no LDS for tokens, no block barrier).  Measured (profiles/r03/k1_store_path.txt, bench A/B): 18.3 us
+        # stand-alone like the LDS form, but 22.4 vs 19.4 us inside the forward (the right row is re-read once per wave from L2 / MALL
+        # instead of once into LDS) -- off by default
+        self.k1_stream = os.environ.get("S2M2_K1_STREAM", "0") == "1"
         self._tokens_normed = None                               # Tensor (row-major) or hip.TiledTokens (fragment order)
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()

@@ -424,7 +424,7 @@ def test_corr_tiled_equals_corr_bit_for_bit(hip, C, h, w, B, cvdt):
 
 
 def test_fp16_forward_is_bit_identical_with_either_form_of_k1(monkeypatch):
-    """S2M2_K1_STREAM (default on, fp16): K9 writes the normalised tokens in fragment order and K1 runs its streaming form; off: row-major
+    """S2M2_K1_STREAM=1 (opt-in, fp16): K9 writes the normalised tokens in fragment order and K1 runs its streaming form; off: row-major
     tokens and the LDS form.  Same operands, same MFMA chains -> the same cost volume and therefore the same forward, bit for bit
     (eager and hipGraph replay)."""
     from s2m2_amd import hip as H

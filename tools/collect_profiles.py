@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Copy the summaries of a tools/gpu_profile_r02.sh pass from gpurun_out/<tag>/ into profiles/<tag>/ (tracked) and derive the K1 PMC
-traffic JSON + the rocprofv3-vs-bench agreement line.     python tools/collect_profiles.py r02"""
+"""Copy the summaries of a tools/gpu_profile_rNN.sh pass from gpurun_out/<tag>/ into profiles/<dst>/ (tracked) and derive the K1 PMC
+traffic JSON + the rocprofv3-vs-bench agreement line.     python tools/collect_profiles.py r03p [r03]"""
 import csv
 import json
 import os
@@ -10,10 +10,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles", tag)
+dtag = sys.argv[2] if len(sys.argv) > 2 else tag
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles", dtag)
 os.makedirs(dst, exist_ok=True)
 for f in ("bench_N1.json", "bench_N1_banded.json", "kbench.txt", "convbench_3x3_cold.txt", "attnbench.txt", "k1_timeline.txt",
-          "frag_timeline.txt", "fusionbench.txt", "layer_ab_frag.txt", "layer_trace_eager.txt", "parity_c1_c3_c2.txt", "configs_all_models.txt"):
+          "frag_timeline.txt", "fusionbench.txt", "layer_ab_frag.txt", "layer_trace_eager.txt", "parity_c1_c3_c2.txt", "configs_all_models.txt",
+          "pytest_gpu.txt", "attnbench_kt4.txt", "convbench_3x3_hot.txt", "k1_store_path.txt", "clock_probe.txt", "layer_ab_frag_pw.txt",
+          "layer_ab_frag_aux_pw.txt", "parity_tables.txt", "parity_c4_c5_vs_reference.txt", "ab_k1_own_ln_dense.json", "ab_frag_pw32.json",
+          "ab_frag_aux_pw32.json", "ab_k2_notri.json", "ab_default.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 copies = {"prof_bench/bench_kernel_stats.csv": "bench_c3_S_fp16_kernel_stats.csv", "prof_k1_c3/k1_kernel_stats.csv": "k1_only_c3_kernel_stats.csv",

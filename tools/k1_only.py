@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--calib-mib", type=int, default=512)
+    ap.add_argument("--form", default="corr", choices=["corr", "ln"],
+                    help="corr: the shipped fp16 path (tokens normalised by K9, s2m2_corr, volume rows on 128-byte lines); ln: s2m2_ln_corr, dense rows")
     a = ap.parse_args()
     C, h, w = CASES[a.case]
     dt = torch.float16 if a.dtype == "fp16" else torch.float32
@@ -29,8 +31,11 @@ def main():
     feat = torch.randn(2, h, w, C, device="cuda").to(dt)
     g = torch.ones(C, device="cuda")
     b = torch.zeros(C, device="cuda")
+    if a.form == "corr":
+        tok = torch.nn.functional.layer_norm(feat.float(), (C,)).to(dt)
+        cv = hip.cv_alloc(1, h, w, dt, "cuda")
     for _ in range(a.iters):
-        cv = hip.ln_corr(feat, g, b)
+        cv = hip.corr(tok, out=cv) if a.form == "corr" else hip.ln_corr(feat, g, b)
     torch.cuda.synchronize()
     # calibration: a streaming copy of a known byte count, larger than the 256 MiB Infinity Cache
     n = a.calib_mib * 1024 * 1024 // 2
@@ -39,7 +44,7 @@ def main():
     for _ in range(3):
         dst.copy_(src)
     torch.cuda.synchronize()
-    print(f"k1_only: case={a.case} dtype={a.dtype} iters={a.iters} cv={tuple(cv.shape)} calib_bytes={src.numel() * 2}")
+    print(f"k1_only: form={a.form} pitch={cv.stride(2)} case={a.case} dtype={a.dtype} iters={a.iters} cv={tuple(cv.shape)} calib_bytes={src.numel() * 2}")
 
 
 if __name__ == "__main__":

@@ -66,11 +66,11 @@ def main():
     # per-block view: duration of each phase for the median wave
     def d(a, b_, q=50):
         return np.percentile((t[:, :, b_] - t[:, :, a]) * scale, q)
-    print(f"{'per-wave duration (us @ 2.4 GHz)':<36}{'p10':>8}{'median':>8}{'p90':>8}")
+    print(f"{'per-wave duration (us @ 2.4 GHz)':<36}{'p10':>8}{'median':>8}{'p90':>8}{'max':>8}")
     for name, a, b_ in (("prologue (affine -> LDS, barrier)", 0, 1), ("issue of all token loads", 1, 2), ("wait + LayerNorm left tokens", 2, 3),
                         ("LayerNorm right tokens", 3, 4), ("block barrier wait", 4, 5), ("MFMA + staging + store issue", 5, 15),
                         ("entry -> last store issued", 0, 15)):
-        print(f"{name:<36}{d(a, b_, 10):8.2f}{d(a, b_):8.2f}{d(a, b_, 90):8.2f}")
+        print(f"{name:<36}{d(a, b_, 10):8.2f}{d(a, b_):8.2f}{d(a, b_, 90):8.2f}{d(a, b_, 100):8.2f}")
     nbytes = 2 * h * w * C * 2 + h * w * w * 2
     print(f"bytes per launch {nbytes / 1e6:.1f} MB: loads {2 * h * w * C * 2 / 1e6:.1f} MB in issue+wait = {d(1, 3):.2f} us -> "
           f"{2 * h * w * C * 2 / d(1, 3) / 1e6:.1f} TB/s;  stores {h * w * w * 2 / 1e6:.1f} MB issued in {d(5, 15):.2f} us -> "
