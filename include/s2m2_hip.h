@@ -232,6 +232,16 @@ typedef struct s2m2_chain_desc {
        tokens, cut into 32-token tiles; the 16-byte piece (token x of image row r, channels 8p .. 8p+7) goes to 16-byte slot
        ((r * ceil(w/32) + x/32) * (C/16) + p/2) * 64 + (p%2) * 32 + x%32 of a buffer of s2m2_corr_tiled_bytes(); ln_out_stride is ignored. */
     int ln_out_tile_w;
+    /* fan-out stages, nfan = 0: none.  nfan further C -> C layers that ALL read the chain's `out` rows (while they are still in LDS) and
+       write fan_out[:, f*C:(f+1)*C] = W_f . (fan_ln_wsum ? LayerNorm(out rows) : out rows) + b_f  -- the Q | K | V projection of the attention
+       block that follows (reference attentions.py:24-28,71-74 behind the pre-norm of :117,148), fused into the launch that produces its
+       input: fan_weight packed (nfan*C, C), fan_bias fp32 (nfan*C) or NULL, fan_ln_wsum fp32 (nfan*C) row sums (eps ln_eps) or NULL. */
+    const void* fan_weight;
+    const float* fan_bias;
+    const float* fan_ln_wsum;
+    void* fan_out;
+    long long fan_out_stride;
+    int nfan;
     /* placement hint, 0 = none: the rows are `rows / (8 * xcd_group_rows)` images of 8 groups of xcd_group_rows consecutive rows each;
        group g of every image is processed on XCD g (blocks are dealt to XCDs round robin by the hardware), so that a consumer which
        places its work the same way -- s2m2_corr: image row y on XCD y / (h / 8) -- reads these rows from the L2 that holds them. */

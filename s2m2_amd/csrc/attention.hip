@@ -55,11 +55,12 @@ struct AttnCfg {
     static constexpr int ND = (DP + 31) / 32;            // 32-wide output d tiles
     // 32-key sub-tiles staged per block barrier (latency amortisation).  Key-split blocks (few, long rows: the 2-D attention at 1/32, 1216
     // keys x 16 (batch, head) pairs) are latency chains of stage barriers with 4 MFMAs per wave between them: fp16 stages of 256 keys
-    // (two sub-tiles per wave and stage) halve the number of barriers
+    // (two sub-tiles per wave and stage) halve the number of barriers -- measured (profiles/r03/attnbench*.txt) 21.6 -> 20.2 us for
+    // (2,8,1216,32), 17.7 -> 15.0 for (1,8,1216,32); NOT for the PE variant (52 -> 65 us: its tables + bins leave less LDS per block)
 #ifndef S2M2_ATTN_KSPLIT_KT
 #define S2M2_ATTN_KSPLIT_KT 8            // (experiment builds: 4 = the round-2 stages of 128 keys)
 #endif
-    static constexpr int KT = (KSPLIT_ && sizeof(T) == 2 && DP_ <= 64) ? S2M2_ATTN_KSPLIT_KT : (DP <= 64 ? 4 : (DP <= 128 ? 2 : 1));
+    static constexpr int KT = (KSPLIT_ && !PE_ && sizeof(T) == 2 && DP_ <= 64) ? S2M2_ATTN_KSPLIT_KT : (DP <= 64 ? 4 : (DP <= 128 ? 2 : 1));
     static constexpr int KVT = 32 * KT;                  // keys per stage
     static constexpr int KRS = DP + VEC;                 // K tile row stride (elements)
     static constexpr int VRS = KVT + 4;                  // Vt row stride (elements): keys of one stage + pad

@@ -42,6 +42,14 @@ struct ChainArgs {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_out_eps;
+    // fan-out stages behind the chain: nfan further C -> C layers that ALL read the chain's final rows (still in LDS), layer f writing
+    // columns [f*C, (f+1)*C) of fan_out -- the fused Q | K | V projection of the attention that follows (pre-LayerNorm folded in)
+    const void* fan_w;                  // packed (nfan*C, C)
+    const float* fan_b;                 // (nfan*C) or null
+    const float* fan_wsum;              // (nfan*C) row sums of fan_w: LayerNorm (no affine, eps ln_eps) of the final rows folded in; null: none
+    void* fan_out;
+    long long fan_out_stride;
+    int nfan;
     int ln_tile_w;                      // > 0: ln_out in the MFMA-fragment order of s2m2_corr_tiled, the rows being image rows of ln_tile_w tokens
     // > 0: row tiles are handed to blocks so that the XCD a block runs on (hardware: block b on XCD b % 8) owns the tiles of ONE eighth of
     // every image -- xcd_tiles consecutive tiles per image and XCD.  The consumer K1 places image row y on XCD y / (h / 8): it then finds the
@@ -80,11 +88,12 @@ struct ChainCfg {
 template <typename CFG, typename T>
 struct ChainStream {
     raw16_t r[CFG::D][CFG::B_IT];
-    const T *w0, *w1, *w2;
+    const T *w0, *w1, *w2, *wf;
     int off, lrow, pc;
 
     __device__ __forceinline__ void init(const ChainArgs& p, int tid) {
         w0 = static_cast<const T*>(p.w[0]); w1 = static_cast<const T*>(p.w[1]); w2 = static_cast<const T*>(p.w[2]);
+        wf = static_cast<const T*>(p.fan_w);
         lrow = tid / CFG::WP; pc = tid % CFG::WP;
         off = lrow * CFG::C + pc * CFG::VEC;
     }
@@ -93,6 +102,7 @@ struct ChainStream {
         // masked telescoping sum instead of a select chain (the compiler folds chains into a scratch lookup table)
         const long long d1 = (const char*)w1 - (const char*)w0, d2 = (const char*)w2 - (const char*)w1;
         const T* wp = reinterpret_cast<const T*>((const char*)w0 + ((st >= 1 ? d1 : 0) + (st >= 2 ? d2 : 0)));
+        if (st >= CFG::NST) wp = wf + (size_t)(st - CFG::NST) * CFG::C * CFG::C;      // fan-out stages (block-uniform)
         const T* q = wp + off + ch * CFG::BK;
 #pragma unroll
         for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + (size_t)it * CFG::WROWS * CFG::C);
@@ -119,7 +129,7 @@ struct ChainStage {
     // one stage: K loop over the CPS chunks of stage S (stream positions S*CPS ...), then the epilogue
     static __device__ __forceinline__ void run(const ChainArgs& p, ChainStream<CFG, T>& ws, T* A0, T* A1, T* W0, T* W1, int tid, long long m0) {
         constexpr int C = CFG::C, BK = CFG::BK, RS = CFG::RS, ARS = CFG::ARS, D = CFG::D, CPS = CFG::CPS, VEC = CFG::VEC;
-        constexpr int TOTAL = CFG::NST * CPS;
+        const int TOTAL = (CFG::NST + p.nfan) * CPS;               // chunks of the whole weight stream, fan-out stages included
         constexpr bool LAST = S == CFG::NST - 1;
         T* Ain = (S & 1) ? A1 : A0;
         T* Aother = (S & 1) ? A0 : A1;
@@ -249,6 +259,7 @@ struct ChainStage {
                     for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
                 }
                 if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + pcx * VEC) = v;
+                if (p.nfan > 0) *reinterpret_cast<Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC) = v;   // the stored rows: A operand of the fan-out stages
                 if (ln2) {                                         // block-uniform
                     // statistics of the STORED (rounded) row, two passes in fp32 like K1 / nn.LayerNorm: biased variance, eps inside
                     float x[VEC], sum = 0.f;
@@ -284,6 +295,94 @@ struct ChainStage {
     }
 };
 
+// Fan-out stages: nfan C -> C layers that all read the chain's final rows (Afin: the last stage's tile with carry / residual added and
+// rounded, written back by its store pass), each staged through Aoth and stored to its own column block of fan_out.  The weight stream
+// simply continues (stream positions (NST + f) * CPS ...).  Pre-LayerNorm fold as in the regular stages; the row statistics are taken from
+// the A fragments during the first fan-out stage and reused.
+template <typename CFG, typename T>
+__device__ __forceinline__ void chain_fan(const ChainArgs& p, ChainStream<CFG, T>& ws, T* Afin, T* Aoth, T* W0, T* W1, int tid, long long m0) {
+    constexpr int C = CFG::C, BK = CFG::BK, RS = CFG::RS, ARS = CFG::ARS, D = CFG::D, CPS = CFG::CPS, VEC = CFG::VEC;
+    const int TOTAL = (CFG::NST + p.nfan) * CPS;
+    const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const bool ln_on = p.fan_wsum != nullptr;
+    LnRow ln[CFG::MT];
+    const T* arow = Afin + (size_t)l31 * ARS + hi * 8;
+    const int brow = (wn * CFG::WN + l31) * RS + hi * 8;
+    __syncthreads();                                               // the final rows are in Afin (written by every thread of the last store pass)
+#pragma unroll 1
+    for (int F = 0; F < p.nfan; ++F) {
+        CoutRegs<CFG> bias, wsum;
+        bias.load(p.fan_b ? p.fan_b + F * C : nullptr, p.zero, C, 0, wn, lane);
+        if (ln_on) wsum.load(p.fan_wsum + F * C, p.zero, C, 0, wn, lane);
+        float16_t acc[CFG::MT][CFG::NTL];
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+            for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        float ln_s[CFG::MT], ln_q[CFG::MT], ln_shift[CFG::MT];
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i) {
+            ln_s[i] = ln_q[i] = 0.f;
+            ln_shift[i] = (sizeof(T) == 4 && ln_on) ? to_f32(Afin[(size_t)(i * 32 + l31) * ARS]) : 0.f;
+        }
+        const bool stats = ln_on && F == 0;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CPS; c0 += D) {
+#pragma unroll
+            for (int f = 0; f < D; ++f) {
+                const int j = (CFG::NST + F) * CPS + c0 + f;       // stream position of this chunk
+                T* wb = (f & 1) ? W1 : W0;
+                T* wnext = (f & 1) ? W0 : W1;
+                if (j + D < TOTAL) ws.fetch(j + D, f);
+                const T* a = arow + (c0 + f) * BK;
+                const T* b = wb + brow;
+#pragma unroll
+                for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                    Frag<T> xf[CFG::MT], wf[CFG::NTL];
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], a + (size_t)i * 32 * ARS + kk * 16);
+#pragma unroll
+                    for (int jn = 0; jn < CFG::NTL; ++jn) load_frag(wf[jn], b + (size_t)jn * 32 * RS + kk * 16);
+                    if (stats) {
+#pragma unroll
+                        for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < CFG::NTL; ++jn) mma32(acc[i][jn], wf[jn], xf[i]);
+                }
+                if (j + 1 < TOTAL) ws.stash(wnext, (f + 1) % D);
+                __syncthreads();
+            }
+        }
+        if (stats) {
+            const float inv = 1.0f / (float)C;
+#pragma unroll
+            for (int i = 0; i < CFG::MT; ++i) {
+                const float sm = ln_s[i] + __shfl_xor(ln_s[i], 32), q = ln_q[i] + __shfl_xor(ln_q[i], 32);
+                const float mean = sm * inv;
+                ln[i].mean = mean + ln_shift[i];
+                ln[i].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
+            }
+        }
+        if (ln_on) chain_stage_tile<CFG, T, true>(S2M2_ACT_NONE, acc, Aoth, bias, wn, lane, ln, &wsum);
+        else chain_stage_tile<CFG, T, false>(S2M2_ACT_NONE, acc, Aoth, bias, wn, lane, nullptr, nullptr);
+        __syncthreads();
+        T* outp = static_cast<T*>(p.fan_out) + (size_t)F * C;
+#pragma unroll
+        for (int it = 0; it < CFG::X_IT; ++it) {
+            const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+            const long long m = m0 + row;
+            const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Aoth + (size_t)row * ARS + pcx * VEC);
+            if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.fan_out_stride + pcx * VEC) = v;
+        }
+        __syncthreads();                                           // Aoth is staged again by the next fan-out stage
+    }
+}
+
 template <typename CFG, typename T>
 __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     constexpr int VEC = CFG::VEC, ARS = CFG::ARS, D = CFG::D;
@@ -315,7 +414,7 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     }
 #pragma unroll
     for (int f = 1; f < D; ++f)
-        if (f < CFG::NST * CFG::CPS) ws.fetch(f, f);
+        if (f < (CFG::NST + p.nfan) * CFG::CPS) ws.fetch(f, f);
     ws.stash(W0, 0);
 #pragma unroll
     for (int it = 0; it < CFG::X_IT; ++it) {
@@ -327,6 +426,10 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     ChainStage<CFG, T, 0>::run(p, ws, A0, A1, W0, W1, tid, m0);
     if constexpr (CFG::NST > 1) ChainStage<CFG, T, 1>::run(p, ws, A0, A1, W0, W1, tid, m0);
     if constexpr (CFG::NST > 2) ChainStage<CFG, T, 2>::run(p, ws, A0, A1, W0, W1, tid, m0);
+    if (p.nfan > 0) {                                              // block-uniform
+        T* Afin = ((CFG::NST - 1) & 1) ? A1 : A0;                  // the last stage stages in place: its tile is its input buffer
+        chain_fan<CFG, T>(p, ws, Afin, Afin == A0 ? A1 : A0, W0, W1, tid, m0);
+    }
 }
 
 template <typename T, int C, int BM, int NST, int NW, int WP = 4>
@@ -385,6 +488,14 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     a.res_stage = d->res_stage; a.carry = d->carry; a.ln_eps = d->ln_eps;
     a.ln_out = d->ln_out; a.ln_out_stride = d->ln_out_stride; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out_eps = d->ln_out_eps;
     a.ln_tile_w = d->ln_out_tile_w;
+    a.fan_w = d->fan_weight; a.fan_b = d->fan_bias; a.fan_wsum = d->fan_ln_wsum; a.fan_out = d->fan_out; a.fan_out_stride = d->fan_out_stride;
+    a.nfan = d->nfan;
+    S2M2_REQUIRE(d->nfan >= 0 && d->nfan <= 4, "mlp_chain: nfan=%d (0..4)", d->nfan);
+    if (d->nfan > 0) {
+        S2M2_REQUIRE(d->fan_weight && d->fan_out && d->fan_out_stride >= (long long)d->nfan * d->C && d->fan_out_stride % 8 == 0,
+                     "mlp_chain: fan-out stages need fan_weight, fan_out and a row stride of at least nfan * C (multiple of 8)");
+        S2M2_REQUIRE(!d->fan_ln_wsum || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
+    }
     if (d->ln_out) {
         const int ppr = d->C * (d->dtype == S2M2_F16 ? 2 : 4) / 16;      // 16-byte pieces per row = lanes that share a row in the store pass
         S2M2_REQUIRE(ppr == 16 || ppr == 32 || ppr == 64, "mlp_chain: ln_out needs a row of 16, 32 or 64 pieces (C=%d has %d)", d->C, ppr);

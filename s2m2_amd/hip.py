@@ -41,7 +41,8 @@ class ChainDesc(ctypes.Structure):
                 ("C", _i), ("nstage", _i), ("weight", _vp * 3), ("bias", _vp * 3), ("ln_wsum", _vp * 3), ("act", _i * 3),
                 ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
                 ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float),
-                ("ln_out_tile_w", _i), ("xcd_group_rows", _ll)]
+                ("ln_out_tile_w", _i), ("fan_weight", _vp), ("fan_bias", _vp), ("fan_ln_wsum", _vp), ("fan_out", _vp), ("fan_out_stride", _ll),
+                ("nfan", _i), ("xcd_group_rows", _ll)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -402,13 +403,16 @@ def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
               ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0,
-              ln_out_tiled: bool = False):
+              ln_out_tiled: bool = False, fan=None):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
     res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
     ln_out = (gamma fp32 (C), beta fp32 (C), eps): also return LayerNorm(out) * gamma + beta  -> (out, normalised).
     xcd_group_rows: placement hint (s2m2_chain_desc): x is images of 8 groups of that many rows, group g runs on XCD g.
-    ln_out_tiled (x (N,h,w,C) fp16): the normalised rows come back as a TiledTokens buffer in the fragment order corr_tiled reads."""
+    ln_out_tiled (x (N,h,w,C) fp16): the normalised rows come back as a TiledTokens buffer in the fragment order corr_tiled reads.
+    fan = (packed weight (n*C, C), fp32 bias (n*C) or None, ln_wsum fp32 (n*C) or None): n further C -> C layers on the OUTPUT rows
+    (pre-LayerNorm folded in when ln_wsum is given), returned as one (..., n*C) tensor: the fused QKV projection of the next attention.
+    Return value: out, or a tuple (out[, normalised][, fan_out]) in that order."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_chain")
     d = ChainDesc()
@@ -452,9 +456,24 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
             normed = torch.empty(x.shape, device=x.device, dtype=x.dtype)
             ln_ptr = normed.data_ptr()
         d.ln_out, d.ln_out_stride, d.ln_gamma, d.ln_beta, d.ln_out_eps = ln_ptr, C, gam.data_ptr(), bet.data_ptr(), float(eps)
+    fan_out = None
+    nfan = 0
+    if fan is not None:
+        fw, fb, fws = fan
+        nfan = fw.shape[0] // C
+        if fw.dtype != x.dtype or fw.dim() != 2 or fw.shape[1] != C or fw.shape[0] != nfan * C or not fw.is_contiguous() or not fw.is_cuda:
+            raise ValueError(f"mlp_chain: fan weight must be a packed (n*{C}, {C}) {x.dtype} device matrix")
+        for name, t in (("fan bias", fb), ("fan ln_wsum", fws)):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != nfan * C or not t.is_contiguous() or not t.is_cuda):
+                raise ValueError(f"mlp_chain: {name} must be fp32 ({nfan * C}) on the device")
+        fan_out = torch.empty(tuple(x.shape[:-1]) + (nfan * C,), device=x.device, dtype=x.dtype)
+        d.fan_weight, d.fan_out, d.fan_out_stride, d.nfan = fw.data_ptr(), fan_out.data_ptr(), nfan * C, nfan
+        d.fan_bias = fb.data_ptr() if fb is not None else None
+        d.fan_ln_wsum = fws.data_ptr() if fws is not None else None
     _check(load().s2m2_mlp_chain(ctypes.byref(d), _stream()), "s2m2_mlp_chain")
-    _meter("mlp_chain", 2.0 * rows * C * C * len(stages))
-    return out if normed is None else (out, normed)
+    _meter("mlp_chain", 2.0 * rows * C * C * (len(stages) + nfan))
+    res_t = (out,) + ((normed,) if normed is not None else ()) + ((fan_out,) if fan_out is not None else ())
+    return res_t[0] if len(res_t) == 1 else res_t
 
 
 def feature_fusion_supported(C: int, dtype: torch.dtype) -> bool:
