@@ -108,6 +108,9 @@ class Engine:
         # opt-in: banded cost volume (columns j <= i + 11) for use_positivity models.  Off by default: the reference's DispInit hands
         # out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward (measured: profiles/r02/kbench.txt)
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
+        # A/B switch: 0 = the Q | K | V projection of every attention as its own K5 launch (1: as fan-out stages of the K9 launch that
+        # produces its input, where there is one)
+        self.fuse_qkv = os.environ.get("S2M2_FUSE_QKV", "1") != "0"
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
         self.cv_aligned = os.environ.get("S2M2_CV_ALIGNED", "1") != "0"  # A/B switch: 0 = dense cost-volume rows (pitch = w)
         # opt-in experiment (S2M2_K1_STREAM=1, fp16): K9 writes the normalised tokens in MFMA-fragment order and K1 runs its streaming
@@ -307,15 +310,21 @@ class Engine:
             self._pe_cache[key] = pe_tables(h, w, self.device)
         return self._pe_cache[key]
 
+    def qkv_spec(self, p: str) -> Spec:
+        """[q | k | v] of one attention module (attentions.py:24-28,71-74) stacked along Cout: one GEMM"""
+        c = self.p[p + ".q.weight"].shape[1]
+        return self.merged(p + "|qkv", [(p + ".q", 0, 1.0, False), (p + ".k", 0, 1.0, False), (p + ".v", 0, 1.0, False)], c)
+
     def qkv(self, p: str, x: Tensor) -> Tensor:
-        c = x.shape[-1]
-        spec = self.merged(p + "|qkv", [(p + ".q", 0, 1.0, False), (p + ".k", 0, 1.0, False), (p + ".v", 0, 1.0, False)], c)
+        spec = self.qkv_spec(p)
         return self.cconv(spec, [x], ln=self.fuse_ln) if self.fuse_ln else self.cconv(spec, [hip.layernorm(x)])
 
-    def attn_core(self, p: str, z: Tensor, nh: int, two_d: bool, cross: bool, use_pe: bool) -> Tensor:
-        """pre-LN -> fused QKV projection -> K4; returns the attention output BEFORE the output projection (see attn_ffn)."""
+    def attn_core(self, p: str, z: Tensor, nh: int, two_d: bool, cross: bool, use_pe: bool, qkv: Optional[Tensor] = None) -> Tensor:
+        """pre-LN -> fused QKV projection -> K4; returns the attention output BEFORE the output projection (see attn_ffn).  qkv: the
+        projection of ``z`` when the K9 launch that produced ``z`` already computed it (attn_ffn's fan-out stages)."""
         n, h, w, c = z.shape
-        qkv = self.qkv(p + ".attn", z)                       # pre-LN folded into the projection
+        if qkv is None:
+            qkv = self.qkv(p + ".attn", z)                   # pre-LN folded into the projection
         v3 = qkv.reshape(n, h * w, 3 * c) if two_d else qkv.reshape(n * h, w, 3 * c)
         q, k, v = v3[..., :c], v3[..., c:2 * c], v3[..., 2 * c:]
         if use_pe:
@@ -336,14 +345,21 @@ class Engine:
             self._wsum[wp.data_ptr()] = ws
         return ws
 
-    def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor, ln_out=None) -> Tensor:
+    def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor, ln_out=None, next_attn: Optional[str] = None):
         """z' = z + proj(o);  z' + ffn.2(GELU(ffn.0(LayerNorm(z')))) (attentions.py:311-321,347-355): one K9 launch when the width
         is supported, else three K5 launches (pre-LN folded into the first FFN layer).  ln_out = (gamma, beta, eps): the K9 launch also
-        writes LayerNorm(result) * gamma + beta (kept in ``self._tokens_normed`` for K1, see features())."""
+        writes LayerNorm(result) * gamma + beta (kept in ``self._tokens_normed`` for K1, see features()).  next_attn: prefix of the
+        attention module that reads the result next -- its pre-LN + Q | K | V projection runs as fan-out stages of the same K9 launch
+        (the rows are still in LDS): one launch and one round trip of the rows less per attention.  -> (result, qkv or None)."""
         c = z.shape[-1]
         proj, f0, f2 = self.std(pa + ".attn.proj"), self.std(pf + ".ffn.0"), self.std(pf + ".ffn.2")
         if self.use_chain and self.chain_ok(c):
             stages = [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)), (f2[0], f2[1], hip.ACT_NONE, None)]
+            if next_attn is not None and self.fuse_qkv and self.fuse_ln and ln_out is None:
+                qs = self.qkv_spec(next_attn)
+                if qs[2] == 1 and qs[3] == 1 and qs[4] == 3 * c:
+                    out, qkv = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, fan=(qs[0], qs[1], self.wsum(qs)))
+                    return out, qkv
             if ln_out is not None and hip.mlp_chain_ln_out_supported(c, self.dtype):
                 # K1 places image row y on XCD y / (h / 8): hand the token rows of that eighth of every image to the same XCD
                 n, h, w, _ = z.shape
@@ -351,14 +367,14 @@ class Engine:
                 tiled = self.k1_stream and hip.corr_tiled_supported(c, self.dtype)     # fragment order for the streaming form of K1
                 out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp,
                                                          ln_out_tiled=tiled)
-                return out
-            return hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True)
+                return out, None
+            return hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True), None
         z = self.cconv(proj, [o], epi=hip.EPI_ADD, aux0=z)
         if self.fuse_ln:
             hdn = self.cconv(f0, [z], ln=True, act=hip.ACT_GELU)
         else:
             hdn = self.cconv(f0, [hip.layernorm(z)], act=hip.ACT_GELU)
-        return self.cconv(f2, [hdn], epi=hip.EPI_ADD, aux0=z)
+        return self.cconv(f2, [hdn], epi=hip.EPI_ADD, aux0=z), None
 
     def chain_ok(self, c: int) -> bool:
         ok = self._chain_ok.get(c)
@@ -366,11 +382,21 @@ class Engine:
             ok = self._chain_ok[c] = hip.mlp_chain_supported(c, self.dtype)
         return ok
 
-    def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False, ln_out=None) -> Tensor:
-        """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321).  ln_out: see attn_ffn (last launch of the block)."""
+    def first_attn(self, p: str) -> str:
+        """prefix of the attention module a block applies first (cross attention where the block has one)"""
+        return p + (".cross_attn.attn" if (p + ".cross_attn.attn.q.weight") in self.p else ".self_attn.attn")
+
+    def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False, ln_out=None, qkv_in: Optional[Tensor] = None,
+                   next_block: Optional[str] = None):
+        """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321).  ln_out: see attn_ffn (last launch of the block).
+        qkv_in: the Q | K | V projection of ``z`` for the block's first attention, if the launch that produced ``z`` computed it;
+        next_block: prefix of the attention block applied to the result next (its first projection is computed here).
+        -> (result, that projection or None)."""
         if (p + ".cross_attn.attn.q.weight") in self.p:
-            z = self.attn_ffn(p + ".cross_attn", p + ".ffn_c", self.attn_core(p + ".cross_attn", z, nh, two_d, True, False), z)
-        return self.attn_ffn(p + ".self_attn", p + ".ffn", self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe), z, ln_out=ln_out)
+            o = self.attn_core(p + ".cross_attn", z, nh, two_d, True, False, qkv=qkv_in)
+            z, qkv_in = self.attn_ffn(p + ".cross_attn", p + ".ffn_c", o, z, next_attn=p + ".self_attn.attn")
+        o = self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe, qkv=qkv_in)
+        return self.attn_ffn(p + ".self_attn", p + ".ffn", o, z, ln_out=ln_out, next_attn=self.first_attn(next_block) if next_block else None)
 
     def _count(self, prefix: str) -> int:
         n = 0
@@ -385,27 +411,28 @@ class Engine:
         z1 = self.conv_block(p + ".enc1", self.down(p + ".down_conv0", z0))
         z2 = self.conv_block(p + ".enc2", self.down(p + ".down_conv1", z1))
         z3 = self.down(p + ".down_conv2", z2)
-        for i in range(self._count(p + ".enc3s")):
-            z3 = self.attn_block(f"{p}.enc3s.{i}", z3, 8, True, use_pe)
-        for i in range(self._count(p + ".dec3s")):
-            z3 = self.attn_block(f"{p}.dec3s.{i}", z3, 8, True, False)
+        blocks = [(f"{p}.enc3s.{i}", use_pe) for i in range(self._count(p + ".enc3s"))] + \
+                 [(f"{p}.dec3s.{i}", False) for i in range(self._count(p + ".dec3s"))]
+        q = None
+        for k, (bp, pe) in enumerate(blocks):                     # consecutive blocks on the same tensor: each computes the next one's Q | K | V
+            z3, q = self.attn_block(bp, z3, 8, True, pe, qkv_in=q, next_block=blocks[k + 1][0] if k + 1 < len(blocks) else None)
         n2 = self.conv_block(p + ".dec2", self.fusion_up(p + ".concat_conv2", z2, p + ".up_conv2", z3))
         n1 = self.conv_block(p + ".dec1", self.fusion_up(p + ".concat_conv1", z1, p + ".up_conv1", n2))
         n0 = self.conv_block(p + ".dec0", self.fusion_up(p + ".concat_conv0", z0, p + ".up_conv0", n1))
         return n0, n1, n2, z3
 
     def mrt(self, p: str, z0: Tensor, z1: Tensor, z2: Tensor, z3: Tensor, ln_out=None):
-        z0 = self.attn_block(p + ".enc_attn0", z0, 1, False)
-        z1 = self.attn_block(p + ".enc_attn1", self.fusion(p + ".down_concat1", z1, self.down(p + ".down_conv0", z0)), 2, False)
-        z2 = self.attn_block(p + ".enc_attn2", self.fusion(p + ".down_concat2", z2, self.down(p + ".down_conv1", z1)), 4, False)
+        z0 = self.attn_block(p + ".enc_attn0", z0, 1, False)[0]
+        z1 = self.attn_block(p + ".enc_attn1", self.fusion(p + ".down_concat1", z1, self.down(p + ".down_conv0", z0)), 2, False)[0]
+        z2 = self.attn_block(p + ".enc_attn2", self.fusion(p + ".down_concat2", z2, self.down(p + ".down_conv1", z1)), 4, False)[0]
         z3 = self.fusion(p + ".down_concat3", z3, self.down(p + ".down_conv2", z2))
-        for i in range(2):
-            z3 = self.attn_block(f"{p}.enc_attn3s.{i}", z3, 8, True)
-        for i in range(2):
-            z3 = self.attn_block(f"{p}.dec_attn3s.{i}", z3, 8, True)
-        z2 = self.attn_block(p + ".dec_attn2", self.fusion_up(p + ".up_concat2", z2, p + ".up_conv2", z3), 4, False)
-        z1 = self.attn_block(p + ".dec_attn1", self.fusion_up(p + ".up_concat1", z1, p + ".up_conv1", z2), 2, False)
-        z0 = self.attn_block(p + ".dec_attn0", self.fusion_up(p + ".up_concat0", z0, p + ".up_conv0", z1), 1, False, ln_out=ln_out)
+        blocks = [f"{p}.enc_attn3s.{i}" for i in range(2)] + [f"{p}.dec_attn3s.{i}" for i in range(2)]
+        q = None
+        for k, bp in enumerate(blocks):
+            z3, q = self.attn_block(bp, z3, 8, True, qkv_in=q, next_block=blocks[k + 1] if k + 1 < len(blocks) else None)
+        z2 = self.attn_block(p + ".dec_attn2", self.fusion_up(p + ".up_concat2", z2, p + ".up_conv2", z3), 4, False)[0]
+        z1 = self.attn_block(p + ".dec_attn1", self.fusion_up(p + ".up_concat1", z1, p + ".up_conv1", z2), 2, False)[0]
+        z0 = self.attn_block(p + ".dec_attn0", self.fusion_up(p + ".up_concat0", z0, p + ".up_conv0", z1), 1, False, ln_out=ln_out)[0]
         return z0, z1, z2, z3
 
     # ---- refiners ------------------------------------------------------------------------------------

@@ -93,7 +93,7 @@ def make():
     class TiledTokens:                                   # only the isinstance() check of Engine.cost_volume needs it
         pass
 
-    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0, ln_out_tiled=False):
+    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0, ln_out_tiled=False, fan=None):
         t, ys = x.float(), []
         for s, (w, b, act, wsum) in enumerate(stages):
             a = F.layer_norm(t, (t.shape[-1],), eps=ln_eps) if wsum is not None else t
@@ -106,10 +106,15 @@ def make():
                 y = y + ys[0]
             ys.append(y)
             t = y
+        outs = [t.to(x.dtype)]
         if ln_out is not None:
             g, b, eps = ln_out
-            return t.to(x.dtype), F.layer_norm(t.to(x.dtype).float(), (t.shape[-1],), g, b, eps).to(x.dtype)
-        return t.to(x.dtype)
+            outs.append(F.layer_norm(t.to(x.dtype).float(), (t.shape[-1],), g, b, eps).to(x.dtype))
+        if fan is not None:
+            fw, fb, fws = fan
+            a = F.layer_norm(outs[0].float(), (t.shape[-1],), eps=ln_eps) if fws is not None else outs[0].float()
+            outs.append(F.linear(a, fw.float(), fb).to(x.dtype))
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     def feature_fusion_supported(C, dtype):
         return C in (128, 256)

@@ -167,3 +167,41 @@ def test_chain_layernorm_output_in_fragment_order(hip):
     y1, t1 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), ln_out_tiled=True)
     assert torch.equal(y0, y1) and isinstance(t1, hip.TiledTokens)
     assert torch.equal(t1.to_rows(), n0)
+
+
+@pytest.mark.parametrize("C,dtype,shp,nst,nfan,ln", [(128, torch.float16, (2, 50, 61), 3, 3, True), (256, torch.float16, (2, 32, 38), 3, 3, True),
+                                                      (256, torch.float16, (1, 64, 76), 3, 3, True), (384, torch.float16, (1, 16, 19), 3, 3, True),
+                                                      (512, torch.float16, (1, 5, 7), 2, 2, False), (128, torch.float32, (2, 20, 31), 3, 3, True),
+                                                      (256, torch.float32, (1, 6, 11), 3, 3, True), (128, torch.float16, (1, 1, 1), 1, 1, True),
+                                                      (128, torch.float16, (2, 256, 304), 3, 3, True)])
+def test_chain_fan_out_stages(hip, C, dtype, shp, nst, nfan, ln):
+    """Fan-out stages (the fused Q | K | V projection of the next attention): nfan C -> C layers on the chain's OUTPUT rows with the
+    pre-LayerNorm folded in == the stand-alone K5 launch with the same folded LayerNorm on the stored rows (what the engine ran before),
+    and == F.linear(F.layer_norm(out)) in fp32; the chain's own output is bit-identical to the launch without fan-out stages."""
+    g = torch.Generator(device="cuda").manual_seed(C + nst + nfan)
+    x = (torch.randn(*shp, C, device="cuda", generator=g) * 1.5).to(dtype)
+    res = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 1).to(dtype)
+    acts = (0, 1, 0)[:nst] if nst == 3 else ((2, 0) if nst == 2 else (1,))
+    raw, packed = _make(C, nst, dtype, 1 if nst == 3 else -1, acts, 5 * C + nst)
+    wq = (torch.randn(nfan * C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+    bq = torch.randn(nfan * C, device="cuda", generator=g) * 0.3
+    wp = pack.pack_conv(wq, dtype)
+    bp = pack.pack_bias(bq, nfan * C)
+    wsum = wp.float().sum(1).contiguous() if ln else None
+    plain = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=nst == 3)
+    y, q = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=nst == 3, fan=(wp, bp, wsum))
+    assert torch.equal(y, plain) and q.shape == (*shp, nfan * C)
+    a = F.layer_norm(y.float(), (C,)) if ln else y.float()
+    ref = F.linear(a, wq.reshape(nfan * C, C).float(), bq)
+    err = float((q.float() - ref).abs().max())
+    scale = max(1.0, float(ref.abs().max()))
+    assert err < (3e-4 if dtype == torch.float32 else 4e-3 * scale), (err, scale)
+    sep = hip.conv2d([y.reshape(1, 1, -1, C)], wp, bp, 1, 1, nfan * C, ln_wsum=wsum).reshape(q.shape)
+    assert float((q.float() - sep.float()).abs().max()) < (3e-4 if dtype == torch.float32 else 2 ** -7 * scale)
+    # with a LayerNorm second output as well: three results, unchanged
+    if hip.mlp_chain_ln_out_supported(C, dtype):
+        gam = torch.ones(C, device="cuda")
+        bet = torch.zeros(C, device="cuda")
+        y3, n3, q3 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=nst == 3, ln_out=(gam, bet, 1e-5), fan=(wp, bp, wsum))
+        assert torch.equal(y3, y) and torch.equal(q3, q)
+        assert float((n3.float() - F.layer_norm(y.float(), (C,))).abs().max()) < (2e-5 if dtype == torch.float32 else 4e-3)
