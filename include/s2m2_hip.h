@@ -188,6 +188,10 @@ typedef struct s2m2_conv_desc {
                                stacked_MRT.py:21-26): a GEMM row is the mean of input pixels (2y, 2x) .. (2y+1, 2x+1), formed and rounded
                                to the I/O dtype exactly as s2m2_resample2x mode 0 does; output (N, H/2, W/2, Cout).  Needs KH = KW = 1,
                                stride 1, korder 0, no shuffle2 / ln_wsum / DUALMIX. */
+    int epi_cout0;          /* > 0 (korder 2, one-operand epilogues ADD / MUL, a multiple of 128): the epilogue applies to couts >= epi_cout0
+                               only, couts below it are stored after bias + activation -- two layers that read the same input stacked along
+                               Cout with different epilogues in ONE launch (ConvGRU: z = sigmoid(convz(hx)) | r*h = sigmoid(convr(hx)) * h,
+                               refinenet.py:24-29).  aux0 is indexed with the cout itself: aux0[pixel * aux0_stride + cout]. */
 } s2m2_conv_desc;
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
 

@@ -58,6 +58,7 @@ struct ConvArgs {
     int ksplit;                 // S2M2_EPI_DUALMIX: K index where the second GEMM (second accumulator, bias2) starts
     const float* bias2;
     int pool2;                  // 1x1 layer behind AvgPool2d(2): a row is the mean of 4 input pixels (stride = 2, Ho = H / 2, Wo = W / 2)
+    int epi_cout0;              // v5 only: the epilogue applies to cout blocks at or above this cout (0: all)
 };
 
 template <typename T, int BM_, int BN_, int WGM_, int PPR_ = 8, int NPF_ = 1, int NWAVES_ = 4>
@@ -102,10 +103,11 @@ struct AuxRegs {
     // pix(r, m): global output pixel of staged row r (false: outside the image / past M)
     // ONE: the caller launches with one-operand epilogues only (a1 stays a constant zero: no registers)
     template <bool ONE = false, typename PIX>
-    __device__ __forceinline__ void prefetch(const ConvArgs& p, int tid, int n0, PIX pix) {
+    __device__ __forceinline__ void prefetch(const ConvArgs& p, int tid, int n0, PIX pix, int epi_override = -1) {
         if constexpr (ON) {
-            if (p.epi == S2M2_EPI_NONE) return;
-            const bool two = !ONE && (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX || p.epi == S2M2_EPI_DUALMIX);
+            const int epi = epi_override >= 0 ? epi_override : p.epi;
+            if (epi == S2M2_EPI_NONE) return;
+            const bool two = !ONE && (epi == S2M2_EPI_GRU || epi == S2M2_EPI_GATEMIX || epi == S2M2_EPI_DUALMIX);
 #pragma unroll
             for (int it = 0; it < NP; ++it) {
                 const int q = tid + CFG::NT * it, r = q / PCR, pcc = q - r * PCR;
@@ -122,8 +124,9 @@ struct AuxRegs {
 
 // epilogue 2: the staged tile comes back as 16-byte pieces of whole pixel rows: aux combine, coalesced store
 template <typename CFG, typename T, typename AX, typename PIX>
-__device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int tid, int n0, const AX& aux, PIX pix) {
+__device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int tid, int n0, const AX& aux, PIX pix, int epi_override = -1) {
     constexpr int VEC = CFG::VEC, PCR = AX::PCR;
+    const int epi = epi_override >= 0 ? epi_override : p.epi;
     T* outp = static_cast<T*>(p.out);
 #pragma unroll
     for (int it = 0; it < AX::NP; ++it) {
@@ -132,7 +135,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int t
         long long m;
         if (q >= AX::TOTAL || !pix(r, m) || co >= p.Cout) continue;
         Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
-        if (p.epi != S2M2_EPI_NONE) {
+        if (epi != S2M2_EPI_NONE) {
             Vec16<T> a0, a1;
             if constexpr (AX::ON) {
                 a0 = __builtin_bit_cast(Vec16<T>, aux.a0[it]);
@@ -140,10 +143,10 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int t
             } else {
                 a0 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux0) + m * p.aux0_stride + co);
                 a1 = a0;
-                if (p.epi == S2M2_EPI_GRU || p.epi == S2M2_EPI_GATEMIX)
+                if (epi == S2M2_EPI_GRU || epi == S2M2_EPI_GATEMIX)
                     a1 = *reinterpret_cast<const Vec16<T>*>(static_cast<const T*>(p.aux1) + m * p.aux1_stride + co);
             }
-            aux_combine(v, p.epi, a0, a1);
+            aux_combine(v, epi, a0, a1);
         }
         long long opix = m;
         int oc = co;
@@ -1209,7 +1212,9 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     constexpr bool AUX_LATE = AUX != 0 && PW != 32;
     using AX = AuxRegs<CFG, T, AUX != 0 ? (AUX_LATE ? 10 : 8) : 4>;
     AX aux;
-    if constexpr (AUX != 0 && !AUX_LATE) aux.template prefetch<AUX == 1>(p, tid, n0, pix);
+    // stacked layers with different epilogues (epi_cout0): cout blocks below it store bias + activation only
+    const int epi_eff = (n0 < p.epi_cout0) ? (int)S2M2_EPI_NONE : p.epi;
+    if constexpr (AUX != 0 && !AUX_LATE) aux.template prefetch<AUX == 1>(p, tid, n0, pix, epi_eff);
     float16_t acc[CFG::MT][CFG::NTL];
 #pragma unroll
     for (int i = 0; i < CFG::MT; ++i)
@@ -1278,7 +1283,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     for (int s = 0; s < KS; ++s) settle(ring[s]);
 
     // ---- epilogues: staging rows r = patch pixel in raster order
-    if constexpr (AUX_LATE) aux.template prefetch<AUX == 1>(p, tid, n0, pix);
+    if constexpr (AUX_LATE) aux.template prefetch<AUX == 1>(p, tid, n0, pix, epi_eff);
     FRAG_T(2);
     __syncthreads();                                              // the staging tile aliases the halo tile
     FRAG_T(3);
@@ -1286,7 +1291,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     FRAG_T(4);
     __syncthreads();
     FRAG_T(5);
-    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix);                 // (!AUX: launched with epi == NONE only, no operand is read)
+    store_tile<CFG, T>(p, Cs, tid, n0, aux, pix, epi_eff);        // (!AUX: launched with epi == NONE only, no operand is read)
     FRAG_T(6);
 }
 
@@ -1686,6 +1691,11 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2; a.korder = d->korder;
     a.ln_wsum = d->ln_wsum; a.ln_eps = d->ln_eps;
     a.ksplit = d->ksplit; a.bias2 = d->bias2;
+    a.epi_cout0 = d->epi_cout0;
+    if (d->epi_cout0)
+        S2M2_REQUIRE(d->korder == 2 && d->epi_cout0 > 0 && d->epi_cout0 % 128 == 0 && d->epi_cout0 < d->Cout &&
+                     (d->epi == S2M2_EPI_ADD || d->epi == S2M2_EPI_MUL),
+                     "conv2d: epi_cout0=%d needs K order 2, a one-operand epilogue (ADD / MUL) and a multiple of 128 below Cout", d->epi_cout0);
     if (d->epi == S2M2_EPI_DUALMIX)
         S2M2_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && !d->shuffle2 && !d->korder && !d->ln_wsum && d->aux1 &&
                      d->ksplit > 0 && d->ksplit < a.Cin && d->ksplit % 64 == 0 && d->act == S2M2_ACT_SIGMOID && d->out_scale == 1.0f,

@@ -108,9 +108,12 @@ class Engine:
         # opt-in: banded cost volume (columns j <= i + 11) for use_positivity models.  Off by default: the reference's DispInit hands
         # out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward (measured: profiles/r02/kbench.txt)
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
-        # A/B switch: 0 = the Q | K | V projection of every attention as its own K5 launch (1: as fan-out stages of the K9 launch that
-        # produces its input, where there is one)
-        self.fuse_qkv = os.environ.get("S2M2_FUSE_QKV", "1") != "0"
+        # opt-in (S2M2_FUSE_QKV=1): the Q | K | V projection of an attention as fan-out stages of the K9 launch that produces its input,
+        # where there is one.  Measured neutral end to end (20 launches fewer per pair, 9.80-9.85 vs 9.84 ms same-box): at 1/16 and 1/32
+        # the chain's 32-row tiles occupy 76-152 CUs and three more weight streams double its length, which costs what the separate
+        # 456-block K5 launch cost -- off by default
+        self.fuse_qkv = os.environ.get("S2M2_FUSE_QKV", "0") == "1"
+        self.fuse_gru = os.environ.get("S2M2_FUSE_GRU", "1") != "0"     # A/B switch: 0 = the z and r gates of ConvGRU as two launches
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
         self.cv_aligned = os.environ.get("S2M2_CV_ALIGNED", "1") != "0"  # A/B switch: 0 = dense cost-volume rows (pitch = w)
         # opt-in experiment (S2M2_K1_STREAM=1, fp16): K9 writes the normalised tokens in MFMA-fragment order and K1 runs its streaming
@@ -445,12 +448,22 @@ class Engine:
         return hip.global_update(self.cconv(self.std(p + ".out_feat.0"), [f]), disp, conf, self.use_positivity)
 
     def gru(self, p: str, h: Tensor, x: Tensor) -> Tensor:
-        """ConvGRU (refinenet.py:7-36): two separable passes; the gate arithmetic lives in the conv epilogues."""
+        """ConvGRU (refinenet.py:7-36): two separable passes; the gate arithmetic lives in the conv epilogues.  z and r read the same
+        cat(h, x) through layers of the same shape: ONE launch with the two layers stacked along Cout, whose upper half carries the
+        r * h epilogue (s2m2_conv_desc.epi_cout0; fp16 / K order 2) -- 6 launches fewer per refinement step and cat(h, x) read once."""
+        C = h.shape[-1]
         for sfx in ("1", "2"):
-            with self.fork():
-                z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
-            rh = self.cconv(self.std(f"{p}.convr{sfx}", frag=self.frag_aux), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
-            self.join(z)
+            zr = None
+            if self.fuse_gru and self.frag_aux:
+                zr = self.merged(f"{p}|zr{sfx}", [(f"{p}.convz{sfx}", 0, 1.0, False), (f"{p}.convr{sfx}", 0, 1.0, False)], h.shape[-1] + x.shape[-1])
+            if zr is not None and getattr(zr, "korder", 0) == 2 and zr[4] == 2 * C and C % 128 == 0:
+                both = self.cconv(zr, [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h, epi_cout0=C)
+                z, rh = both[..., :C], both[..., C:]
+            else:
+                with self.fork():
+                    z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
+                rh = self.cconv(self.std(f"{p}.convr{sfx}", frag=self.frag_aux), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
+                self.join(z)
             h = self.cconv(self.std(f"{p}.convq{sfx}", frag=self.frag_aux2), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
 

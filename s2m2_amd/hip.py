@@ -32,7 +32,7 @@ class ConvDesc(ctypes.Structure):
                 ("out", _vp), ("out_stride", _i), ("N", _i), ("H", _i), ("W", _i), ("KH", _i), ("KW", _i), ("Cout", _i),
                 ("act", _i), ("epi", _i), ("aux0", _vp), ("aux1", _vp), ("aux0_stride", _i), ("aux1_stride", _i),
                 ("out_scale", ctypes.c_float), ("shuffle2", _i), ("tile", _i), ("dtype", _i), ("korder", _i), ("stride", _i),
-                ("ln_wsum", _vp), ("ln_eps", ctypes.c_float), ("ksplit", _i), ("bias2", _vp), ("pool2", _i)]
+                ("ln_wsum", _vp), ("ln_eps", ctypes.c_float), ("ksplit", _i), ("bias2", _vp), ("pool2", _i), ("epi_cout0", _i)]
 
 
 class ChainDesc(ctypes.Structure):
@@ -312,12 +312,13 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
            epi: int = EPI_NONE, aux0: Optional[torch.Tensor] = None, aux1: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, out_scale: float = 1.0, shuffle2: int = 0, tile: int = 0,
            stride: int = 1, korder: int = 0, ln_wsum: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-           ksplit: int = 0, bias2: Optional[torch.Tensor] = None, pool2: bool = False) -> torch.Tensor:
+           ksplit: int = 0, bias2: Optional[torch.Tensor] = None, pool2: bool = False, epi_cout0: int = 0) -> torch.Tensor:
     """Implicit-GEMM convolution / linear layer (s2m2_conv2d).  srcs: list of (N,H,W,Cs) tensors, concatenated along C;
     weight: packed (Cout, KH*KW*sum(Cs)) (see s2m2_amd.pack); bias fp32 (Cout) or None.  Returns (N,H,W,Cout), or
     (N,2H,2W,shuffle2) for the 2x2-stride-2 transposed-conv GEMM.  ln_wsum (fp32 (Cout) row sums of the packed weight): the 1x1 layer
     is preceded by LayerNorm(Cin, no affine, eps=ln_eps) of the raw input rows, folded into the kernel.  pool2: the 1x1 layer is preceded
-    by AvgPool2d(2), folded into its operand load -> (N, H//2, W//2, Cout)."""
+    by AvgPool2d(2), folded into its operand load -> (N, H//2, W//2, Cout).  epi_cout0 > 0: the one-operand epilogue applies to couts
+    >= epi_cout0 only and aux0 has Cout - epi_cout0 channels (two stacked layers, one launch: s2m2_conv_desc.epi_cout0)."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     d = ConvDesc()
@@ -354,10 +355,13 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
     d.act, d.epi = act, epi
     for name, a in (("aux0", aux0), ("aux1", aux1)):
         if a is not None:
-            if a.dtype != dt or tuple(a.shape) != (n, ho, wo, Cout):
-                raise ValueError(f"conv2d: {name} must be {(n, ho, wo, Cout)} {dt}, got {tuple(a.shape)} {a.dtype}")
-            setattr(d, name, a.data_ptr())
+            ac = Cout - epi_cout0 if name == "aux0" else Cout
+            if a.dtype != dt or tuple(a.shape) != (n, ho, wo, ac):
+                raise ValueError(f"conv2d: {name} must be {(n, ho, wo, ac)} {dt}, got {tuple(a.shape)} {a.dtype}")
+            # (the kernel indexes aux0 with the cout: a tensor that covers couts >= epi_cout0 starts epi_cout0 elements "before" its base)
+            setattr(d, name, a.data_ptr() - (epi_cout0 * a.element_size() if name == "aux0" else 0))
             setattr(d, name + "_stride", _nhwc(a))
+    d.epi_cout0 = epi_cout0
     d.out_scale = out_scale
     d.shuffle2 = shuffle2
     d.tile = tile

@@ -320,3 +320,30 @@ def test_conv_pool2_equals_avgpool_then_conv(hip, shape, dtype):
     assert float((fused.float() - tref).abs().max()) < (2e-2 if dtype == torch.float16 else 2e-4)
     with pytest.raises(RuntimeError, match="pool2"):
         hip.conv2d([x], pack.pack_conv(torch.zeros(cout, cin, 3, 3), dtype), None, 3, 3, cout, pool2=True)
+
+
+@pytest.mark.parametrize("shape,k", [((1, 37, 83, 128), (3, 1)), ((2, 16, 40, 128), (1, 3)), ((1, 256, 304, 128), (3, 1))])
+@pytest.mark.parametrize("tile", [0, 2, 40])
+def test_conv_frag_two_stacked_layers_with_different_epilogues(hip, shape, k, tile):
+    """epi_cout0: z = sigmoid(convz(cat(h, x))) and r*h = sigmoid(convr(cat(h, x))) * h of ConvGRU (refinenet.py:24-29) as ONE launch with
+    the two layers stacked along Cout -- bit-identical to the two separate launches (same K order, same epilogue arithmetic)."""
+    N, H, W, C = shape
+    KH, KW = k
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(H + W)
+    h = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
+    x = torch.randn(N, H, W, C, device="cuda", generator=g).to(dtype)
+    ws = [(torch.randn(C, 2 * C, KH, KW, device="cuda", generator=g) / math.sqrt(2 * C * KH * KW)).to(dtype) for _ in range(2)]
+    bs = [torch.randn(C, device="cuda", generator=g) * 0.1 for _ in range(2)]
+    sp = [(C, C), (C, C)]
+    z = hip.conv2d([h, x], pack.pack_conv_frag(ws[0], dtype, sp), pack.pack_bias(bs[0], C), KH, KW, C, act=hip.ACT_SIGMOID, korder=2)
+    rh = hip.conv2d([h, x], pack.pack_conv_frag(ws[1], dtype, sp), pack.pack_bias(bs[1], C), KH, KW, C, act=hip.ACT_SIGMOID, epi=hip.EPI_MUL,
+                    aux0=h, korder=2)
+    wz = pack.pack_conv_frag(torch.cat(ws, 0), dtype, sp)
+    both = hip.conv2d([h, x], wz, pack.pack_bias(torch.cat(bs), 2 * C), KH, KW, 2 * C, act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h,
+                      korder=2, epi_cout0=C, tile=tile)
+    assert torch.equal(both[..., :C], z) and torch.equal(both[..., C:], rh)
+    ref = torch.sigmoid(_ref_conv([h, x], ws[1], bs[1], 0)).half().float() * h.float()
+    assert float((both[..., C:].float() - ref).abs().max()) < 2e-2
+    with pytest.raises(RuntimeError, match="epi_cout0"):
+        hip.conv2d([h, x], wz, pack.pack_bias(torch.cat(bs), 2 * C), KH, KW, 2 * C, act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h, korder=2, epi_cout0=64)

@@ -106,7 +106,7 @@ def test_smallest_legal_image():
 
 
 def test_forward_with_fused_qkv_projection_matches_separate_launches(monkeypatch):
-    """S2M2_FUSE_QKV (default on): the Q | K | V projection of an attention as fan-out stages of the K9 launch that produces its input,
+    """S2M2_FUSE_QKV=1 (opt-in): the Q | K | V projection of an attention as fan-out stages of the K9 launch that produces its input,
     against the stand-alone K5 launch.  Same operands, fp32 accumulation in a different order: fp32 forwards agree to the parity
     tolerance, the fp16 forwards to fp16 rounding noise."""
     from s2m2_amd.model import S2M2
@@ -133,3 +133,23 @@ def test_forward_with_fused_qkv_projection_matches_separate_launches(monkeypatch
         assert float((a32[0] - b32[0]).abs().max()) < 2e-2
     assert all(torch.isfinite(t).all() for t in a16)
     assert float((a16[0] - b16[0]).abs().median()) < 0.05
+
+
+def test_fp16_forward_is_bit_identical_with_merged_gru_gates(monkeypatch):
+    """S2M2_FUSE_GRU (default on): the z and r gates of ConvGRU in one launch (s2m2_conv_desc.epi_cout0) -- same kernels, same K order,
+    same epilogue arithmetic as the two launches it replaces: the fp16 forward is unchanged bit for bit."""
+    from s2m2_amd.model import S2M2
+    from s2m2_amd.weights import seeded_state_dict, synthetic_pair
+    sd = seeded_state_dict(128, 1, 1, 0)
+    l, r = synthetic_pair(160, 352, 1, 24, 3)
+    l, r = l.cuda(), r.cuda()
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("S2M2_FUSE_GRU", fuse)
+        m = S2M2(128, 1, 1, use_positivity=True, refine_iter=2)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().eval()
+        with torch.autocast("cuda", dtype=torch.float16):
+            m(l, r)
+            outs.append([t.clone() for t in m(l, r)])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
