@@ -345,5 +345,6 @@ def test_conv_frag_two_stacked_layers_with_different_epilogues(hip, shape, k, ti
     assert torch.equal(both[..., :C], z) and torch.equal(both[..., C:], rh)
     ref = torch.sigmoid(_ref_conv([h, x], ws[1], bs[1], 0)).half().float() * h.float()
     assert float((both[..., C:].float() - ref).abs().max()) < 2e-2
-    with pytest.raises(RuntimeError, match="epi_cout0"):
-        hip.conv2d([h, x], wz, pack.pack_bias(torch.cat(bs), 2 * C), KH, KW, 2 * C, act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h, korder=2, epi_cout0=64)
+    with pytest.raises(RuntimeError, match="epi_cout0"):           # not a multiple of the 128-cout block
+        wide = torch.cat([h, h[..., :64]], -1).contiguous()
+        hip.conv2d([h, x], wz, pack.pack_bias(torch.cat(bs), 2 * C), KH, KW, 2 * C, act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=wide, korder=2, epi_cout0=64)
