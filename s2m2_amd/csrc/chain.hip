@@ -432,6 +432,214 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// K9, weights-stationary form (fp16, C = 128; long row counts).  The streaming kernel above re-reads the chain's weights (96 KB for three
+// stages) per 64-row tile and meets at a block barrier per 64-byte chunk of K -- 4 MFMAs per wave between barriers: at 1/4 resolution a
+// block lives ~8 us for 0.7 us of MFMA work (profiles/r03/layer_trace_eager.txt: 230-280 TF/s).  Here a PERSISTENT block copies every
+// weight of the chain into LDS once (XOR-swizzled 16-byte pieces: conflict-free ds_read_b128 without padding) and walks over row tiles:
+//   * 8 waves = 2 groups x 4; a group owns one 32-row tile per step, a wave 32 rows x 32 couts, the whole K = 128 of a stage without a
+//     barrier (A tile and weights are both resident);
+//   * ONE block barrier per stage (the output tile of a stage is the A operand of the next), two buffers per group;
+//   * the next tile's input and residual rows are requested before the first stage of the current one and land under its three stages.
+// Same arithmetic and rounding points as the streaming kernel (tests/test_hip_chain.py runs both against the same references).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NST_>
+struct ChainWsCfg {
+    static constexpr int C = 128, BM = 32, NST = NST_, NG = 2, NWG = 4, NT = 64 * NG * NWG, GT = 64 * NWG;
+    static constexpr int VEC = 8, ARS = C + VEC, CRS = ARS, KSTEPS = C / 16, PPR = C / VEC;
+    static constexpr int WM = BM, MT = 1, WN = 32, NTL = 1;
+    static constexpr int X_IT = BM * PPR / GT;                   // 16-byte pieces per thread and tile
+    static constexpr size_t W_BYTES = (size_t)NST * C * C * sizeof(half_t);
+    static constexpr size_t A_BYTES = (size_t)BM * ARS * sizeof(half_t);
+    static constexpr size_t LDS_BYTES = W_BYTES + (size_t)NG * 2 * A_BYTES;
+    static_assert(X_IT * GT == BM * PPR && LDS_BYTES <= 160 * 1024, "weights-stationary chain tile");
+};
+
+template <int NST>
+__global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(ChainArgs p, int ntiles) {
+    using CFG = ChainWsCfg<NST>;
+    using T = half_t;
+    constexpr int C = CFG::C, VEC = CFG::VEC, ARS = CFG::ARS, PPR = CFG::PPR, GT = CFG::GT, X_IT = CFG::X_IT, BM = CFG::BM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Wt = reinterpret_cast<T*>(smem);                           // [NST][C][C], piece pc of row r at slot pc ^ (r & 15)
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave / CFG::NWG, wn = wave - g * CFG::NWG;      // row-tile group, cout tile of this wave
+    const int gt = tid - g * GT;                                  // thread inside the group
+    T* A0 = reinterpret_cast<T*>(smem + CFG::W_BYTES + (size_t)(2 * g) * CFG::A_BYTES);
+    T* A1 = A0 + BM * ARS;
+
+    // ---- every weight of the chain -> LDS, once per block
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const T* wsrc = static_cast<const T*>(p.w[st]);
+        for (int q = tid; q < C * PPR; q += CFG::NT) {
+            const int r = q / PPR, pc = q - r * PPR;
+            *reinterpret_cast<raw16_t*>(Wt + (size_t)st * C * C + (size_t)r * C + ((pc ^ (r & 15)) * VEC)) = global_load16(wsrc + (size_t)r * C + pc * VEC);
+        }
+    }
+    const int npair = (ntiles + 1) >> 1;
+    const int niter = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // uniform for the block (>= 1: grid <= npair)
+    auto fetch_rows = [&](long long m0, const void* src, long long stride, raw16_t (&r)[X_IT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
+            const long long m = m0 + row;
+            const T* q = (src != nullptr && m < p.rows) ? static_cast<const T*>(src) + m * stride + pcx * VEC : static_cast<const T*>(p.zero);
+            r[it] = global_load16(q);
+        }
+    };
+    const bool res_any = p.res_stage >= 0;
+    raw16_t xr[X_IT], rr[X_IT], xn[X_IT], rn[X_IT];
+    long long m0 = ((long long)2 * blockIdx.x + g) * BM;
+    fetch_rows(m0, p.x, p.x_stride, xr);
+    fetch_rows(m0, res_any ? p.res : nullptr, p.res_stride, rr);
+
+    // per-cout vectors of every stage stay in registers for the life of the block
+    CoutRegs<CFG> bias[NST], wsum[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        bias[st].load(p.b[st], p.zero, C, 0, wn, lane);
+        wsum[st].load(p.wsum[st], p.zero, C, 0, wn, lane);
+    }
+    const bool ln2 = p.ln_out != nullptr;
+    float g2[VEC], b2[VEC];
+    if (ln2) {
+        const int pcx = gt % PPR;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { g2[e] = p.ln_gamma[pcx * VEC + e]; b2[e] = p.ln_beta[pcx * VEC + e]; }
+    }
+    const int sw = l31 & 15;                                      // swizzle key of this lane's weight row (wn * 32 + l31)
+
+    for (int iter = 0; iter < niter; ++iter) {
+        __syncthreads();                                          // previous tile's store pass has read A0 / A1 (first pass: weights visible)
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
+            *reinterpret_cast<raw16_t*>(A0 + (size_t)row * ARS + pcx * VEC) = xr[it];
+        }
+        const long long mnext = m0 + (long long)2 * gridDim.x * BM;
+        if (iter + 1 < niter) {                                   // in flight under this tile's stages
+            fetch_rows(mnext, p.x, p.x_stride, xn);
+            fetch_rows(mnext, res_any ? p.res : nullptr, p.res_stride, rn);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const bool last = st == NST - 1;
+            T* Ain = (st & 1) ? A1 : A0;
+            T* Aoth = (st & 1) ? A0 : A1;
+            T* Aout = last ? Ain : Aoth;
+            const bool ln_on = p.wsum[st] != nullptr;
+            float16_t acc[1][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+            float ln_s = 0.f, ln_q = 0.f;
+            const T* arow = Ain + (size_t)l31 * ARS + hi * 8;
+            const T* wrow = Wt + (size_t)st * C * C + (size_t)(wn * 32 + l31) * C;
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                Frag<T> xf, wf;
+                load_frag(xf, arow + kk * 16);
+                load_frag(wf, wrow + (((2 * kk + hi) ^ sw) * VEC));
+                if (ln_on) ln_accumulate(xf, ln_s, ln_q, 0.f);
+                mma32(acc[0][0], wf, xf);                          // D[cout][row]
+            }
+            if (last) __syncthreads();                             // staged in place: every wave is done reading Ain
+            if (ln_on) {
+                LnRow ln[1];
+                const float inv = 1.0f / (float)C;
+                const float sm = ln_s + __shfl_xor(ln_s, 32), q = ln_q + __shfl_xor(ln_q, 32);
+                const float mean = sm * inv;
+                ln[0].mean = mean;
+                ln[0].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
+                chain_stage_tile<CFG, T, true>(p.act[st], acc, Aout, bias[st], wn, lane, ln, &wsum[st]);
+            } else {
+                chain_stage_tile<CFG, T, false>(p.act[st], acc, Aout, bias[st], wn, lane, nullptr, nullptr);
+            }
+            __syncthreads();
+            if (!last) {
+                if (p.res_stage == st) {                           // Aout += res (rounded like the separate launch: tile, then the sum)
+#pragma unroll
+                    for (int it = 0; it < X_IT; ++it) {
+                        const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
+                        Vec16<T>* q = reinterpret_cast<Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC);
+                        Vec16<T> v = *q;
+                        const Vec16<T> u = __builtin_bit_cast(Vec16<T>, rr[it]);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
+                        *q = v;
+                    }
+                    __syncthreads();
+                }
+            } else {                                               // coalesced store of the staged tile (+ carry, + res, LayerNorm output)
+                T* outp = static_cast<T*>(p.out);
+#pragma unroll
+                for (int it = 0; it < X_IT; ++it) {
+                    const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
+                    const long long m = m0 + row;
+                    Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC);
+                    if (p.carry) {
+                        const Vec16<T> u = *reinterpret_cast<const Vec16<T>*>(Aoth + (size_t)row * ARS + pcx * VEC);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
+                    }
+                    if (p.res_stage == st) {
+                        const Vec16<T> u = __builtin_bit_cast(Vec16<T>, rr[it]);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
+                    }
+                    if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + pcx * VEC) = v;
+                    if (ln2) {
+                        float x[VEC], sum = 0.f;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) { x[e] = to_f32(v.v[e]); sum += x[e]; }
+#pragma unroll
+                        for (int o = 1; o < PPR; o <<= 1) sum += __shfl_xor(sum, o);
+                        const float mean = sum * (1.0f / (float)C);
+                        float sq = 0.f;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) { x[e] -= mean; sq = __builtin_fmaf(x[e], x[e], sq); }
+#pragma unroll
+                        for (int o = 1; o < PPR; o <<= 1) sq += __shfl_xor(sq, o);
+                        const float rstd = rsqrtf(sq * (1.0f / (float)C) + p.ln_out_eps);
+                        Vec16<T> o;
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
+                        if (m < p.rows) {
+                            if (p.ln_tile_w > 0) {
+                                const long long rid = m / p.ln_tile_w;
+                                const int xq = (int)(m - rid * p.ln_tile_w);
+                                const long long slot = ((rid * ((p.ln_tile_w + 31) >> 5) + (xq >> 5)) * (C / 16) + (pcx >> 1)) * 64 + (pcx & 1) * 32 + (xq & 31);
+                                reinterpret_cast<Vec16<T>*>(p.ln_out)[slot] = o;
+                            } else {
+                                *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        m0 = mnext;
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) { xr[it] = xn[it]; rr[it] = rn[it]; }
+    }
+}
+
+template <int NST>
+static int launch_chain_ws(const ChainArgs& a, hipStream_t st) {
+    using CFG = ChainWsCfg<NST>;
+    auto kern = mlp_chain_ws_kernel<NST>;
+    static size_t lds_granted[kMaxDevices] = {};
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "mlp_chain")) return 1;
+    const int ntiles = (int)((a.rows + CFG::BM - 1) / CFG::BM);
+    const int npair = (ntiles + 1) / 2;
+    const int grid = npair < 256 ? npair : 256;                   // one persistent block per CU (130 KB of LDS)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::NT), CFG::LDS_BYTES, st, a, ntiles);
+    return check_launch("mlp_chain");
+}
+
 template <typename T, int C, int BM, int NST, int NW, int WP = 4>
 static int launch_chain(const ChainArgs& a, hipStream_t st) {
     using CFG = ChainCfg<T, C, BM, NST, NW, WP>;
@@ -516,6 +724,16 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     char cfg = d->rows <= 8192 ? 's' : 'm';                       // at most one 32-row tile per CU: short tiles, more CUs busy (measured: tools/chainbench.py)
     if (force && *force) cfg = *force;
     static const bool wide = getenv("S2M2_CHAIN_CHUNK128") != nullptr;   // A/B switch: 128-byte K chunks
+    // weights-stationary persistent form: fp16, C = 128, enough rows to give every CU several tiles (S2M2_CHAIN_WS=0: off, tuning knob
+    // S2M2_CHAIN_WS_MIN: smallest row count)
+    static const bool ws_off = getenv("S2M2_CHAIN_WS") != nullptr && atoi(getenv("S2M2_CHAIN_WS")) == 0;
+    static const long long ws_min = getenv("S2M2_CHAIN_WS_MIN") ? atoll(getenv("S2M2_CHAIN_WS_MIN")) : 32768;
+    if (d->dtype == S2M2_F16 && d->C == 128 && d->nfan == 0 && !ws_off && d->rows >= ws_min && !(force && *force)) {
+        a.xcd_tiles = 0;
+        if (d->nstage == 1) return launch_chain_ws<1>(a, st);
+        if (d->nstage == 2) return launch_chain_ws<2>(a, st);
+        return launch_chain_ws<3>(a, st);
+    }
     if (d->dtype == S2M2_F16) {
         switch (d->C) {
             case 128:

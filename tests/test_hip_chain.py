@@ -65,6 +65,12 @@ CASES = [  # C, dtype, rows-shape, nstage, ln_stage, acts, res_stage, carry
     (256, torch.float32, (2, 16, 19), 3, 1, (0, 1, 0), 0, True),
     (256, torch.float32, (1, 6, 11), 2, -1, (2, 0), -1, False),
     (128, torch.float32, (1, 9, 30), 2, 0, (1, 0), 1, False),
+    # >= 32768 rows at C = 128 fp16: the weights-stationary persistent form (mlp_chain_ws_kernel), incl. ragged row counts
+    (128, torch.float16, (2, 256, 304), 3, 1, (0, 1, 0), 0, True),
+    (128, torch.float16, (1, 255, 303), 2, -1, (2, 0), -1, False),
+    (128, torch.float16, (1, 250, 301), 1, 0, (1,), 0, False),
+    (128, torch.float16, (1, 200, 300), 2, 0, (1, 0), 1, False),
+    (128, torch.float16, (3, 111, 101), 3, 1, (0, 1, 0), 0, True),
 ]
 
 
@@ -116,6 +122,7 @@ def test_chain_rejects_bad_arguments(hip):
 
 
 @pytest.mark.parametrize("C,dtype,shp,nst", [(128, torch.float16, (2, 50, 61), 3), (256, torch.float16, (2, 32, 38), 3), (512, torch.float16, (1, 5, 7), 2),
+                                              (128, torch.float16, (2, 256, 304), 3), (128, torch.float16, (1, 201, 299), 2),
                                               (128, torch.float32, (2, 20, 31), 3), (256, torch.float32, (1, 6, 11), 2), (128, torch.float16, (1, 1, 1), 1)])
 def test_chain_layernorm_second_output(hip, C, dtype, shp, nst):
     """ln_out: LayerNorm(out rows) * gamma + beta as a second output of the last stage (DispInit's layer_norm, submodules.py:165,216,
@@ -154,12 +161,13 @@ def test_chain_xcd_placement_hint_changes_nothing_but_the_block_order(hip):
     assert torch.equal(a[0], c)
 
 
-def test_chain_layernorm_output_in_fragment_order(hip):
+@pytest.mark.parametrize("hh", [5, 300])              # 300: 43 200 rows -> the weights-stationary form
+def test_chain_layernorm_output_in_fragment_order(hip, hh):
     """ln_out_tiled: the same normalised rows, stored in the MFMA-fragment order s2m2_corr_tiled reads (ragged last 32-token tile)."""
     C, dtype = 128, torch.float16
     g = torch.Generator(device="cuda").manual_seed(9)
-    x = (torch.randn(2, 5, 72, C, device="cuda", generator=g) * 2).to(dtype)         # w = 72: tiles of 32, 32, 8 tokens
-    res = torch.randn(2, 5, 72, C, device="cuda", generator=g).to(dtype)
+    x = (torch.randn(2, hh, 72, C, device="cuda", generator=g) * 2).to(dtype)        # w = 72: tiles of 32, 32, 8 tokens
+    res = torch.randn(2, hh, 72, C, device="cuda", generator=g).to(dtype)
     raw, packed = _make(C, 3, dtype, 1, (0, 1, 0), 21)
     gam = 1 + 0.1 * torch.randn(C, device="cuda", generator=g)
     bet = 0.05 * torch.randn(C, device="cuda", generator=g)
