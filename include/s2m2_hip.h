@@ -252,6 +252,9 @@ typedef struct s2m2_chain_desc {
     long long xcd_group_rows;
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);
+/* nstage = 0 with nfan > 0 ("fan-out only": the nfan layers read the x rows themselves -- a Q | K | V projection as ONE pass over the rows,
+ * the stacked weight resident in LDS): 1 where the library has that form (fp16, C = 128, nfan 1..3), else 0 */
+int s2m2_mlp_fan_supported(int C, int nfan, int dtype);
 int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
 
 /*

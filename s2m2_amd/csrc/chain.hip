@@ -452,7 +452,8 @@ struct ChainWsCfg {
     static constexpr int X_IT = BM * PPR / GT;                   // 16-byte pieces per thread and tile
     static constexpr size_t W_BYTES = (size_t)NST * C * C * sizeof(half_t);
     static constexpr size_t A_BYTES = (size_t)BM * ARS * sizeof(half_t);
-    static constexpr size_t LDS_BYTES = W_BYTES + (size_t)NG * 2 * A_BYTES;
+    static constexpr size_t CV_BYTES = (size_t)NST * 2 * C * sizeof(float);          // bias and rowsum(W) of every stage
+    static constexpr size_t LDS_BYTES = W_BYTES + (size_t)NG * 2 * A_BYTES + CV_BYTES;
     static_assert(X_IT * GT == BM * PPR && LDS_BYTES <= 160 * 1024, "weights-stationary chain tile");
 };
 
@@ -469,6 +470,14 @@ __global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(Chain
     const int gt = tid - g * GT;                                  // thread inside the group
     T* A0 = reinterpret_cast<T*>(smem + CFG::W_BYTES + (size_t)(2 * g) * CFG::A_BYTES);
     T* A1 = A0 + BM * ARS;
+    // per-cout fp32 vectors in LDS too: read per stage with ds_read -- as global loads they would be YOUNGER than the row prefetches, and
+    // waiting for them (loads return in order) would drain the prefetch at the first epilogue of every tile
+    float* Cv = reinterpret_cast<float*>(smem + CFG::W_BYTES + (size_t)CFG::NG * 2 * CFG::A_BYTES);      // [NST][2][C]
+    for (int q = tid; q < NST * 2 * C; q += CFG::NT) {
+        const int st = q / (2 * C), r = q - st * 2 * C;
+        const float* src = r < C ? p.b[st] : p.wsum[st];
+        Cv[q] = src ? src[r < C ? r : r - C] : 0.f;
+    }
 
     // ---- every weight of the chain -> LDS, once per block
 #pragma unroll
@@ -491,18 +500,16 @@ __global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(Chain
         }
     };
     const bool res_any = p.res_stage >= 0;
-    raw16_t xr[X_IT], rr[X_IT], xn[X_IT], rn[X_IT];
+    // input and residual rows of the current tile and of the next TWO (one block per CU: the bytes in flight hide the memory latency,
+    // not co-resident blocks -- with one tile ahead a step took 5.5 us, the latency of its own loads)
+    raw16_t xr[X_IT], rr[X_IT], xn[X_IT], rn[X_IT], xn2[X_IT], rn2[X_IT];
+    const long long mstep = (long long)2 * gridDim.x * BM;
     long long m0 = ((long long)2 * blockIdx.x + g) * BM;
     fetch_rows(m0, p.x, p.x_stride, xr);
     fetch_rows(m0, res_any ? p.res : nullptr, p.res_stride, rr);
+    fetch_rows(m0 + mstep, p.x, p.x_stride, xn);                  // (rows past the end read the zero page)
+    fetch_rows(m0 + mstep, res_any ? p.res : nullptr, p.res_stride, rn);
 
-    // per-cout vectors of every stage stay in registers for the life of the block
-    CoutRegs<CFG> bias[NST], wsum[NST];
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        bias[st].load(p.b[st], p.zero, C, 0, wn, lane);
-        wsum[st].load(p.wsum[st], p.zero, C, 0, wn, lane);
-    }
     const bool ln2 = p.ln_out != nullptr;
     float g2[VEC], b2[VEC];
     if (ln2) {
@@ -519,10 +526,10 @@ __global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(Chain
             const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
             *reinterpret_cast<raw16_t*>(A0 + (size_t)row * ARS + pcx * VEC) = xr[it];
         }
-        const long long mnext = m0 + (long long)2 * gridDim.x * BM;
-        if (iter + 1 < niter) {                                   // in flight under this tile's stages
-            fetch_rows(mnext, p.x, p.x_stride, xn);
-            fetch_rows(mnext, res_any ? p.res : nullptr, p.res_stride, rn);
+        const long long mnext = m0 + mstep;
+        if (iter + 2 < niter) {                                   // in flight under this tile's and the next tile's stages
+            fetch_rows(mnext + mstep, p.x, p.x_stride, xn2);
+            fetch_rows(mnext + mstep, res_any ? p.res : nullptr, p.res_stride, rn2);
         }
         __syncthreads();
 #pragma unroll
@@ -532,6 +539,13 @@ __global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(Chain
             T* Aoth = (st & 1) ? A0 : A1;
             T* Aout = last ? Ain : Aoth;
             const bool ln_on = p.wsum[st] != nullptr;
+            CoutRegs<CFG> bias, wsum;                              // per-cout vectors of the stage from LDS
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = wn * 32 + 8 * gq + 4 * hi;
+                bias.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + co);
+                wsum.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + C + co);
+            }
             float16_t acc[1][1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -554,9 +568,9 @@ __global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(Chain
                 const float mean = sm * inv;
                 ln[0].mean = mean;
                 ln[0].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
-                chain_stage_tile<CFG, T, true>(p.act[st], acc, Aout, bias[st], wn, lane, ln, &wsum[st]);
+                chain_stage_tile<CFG, T, true>(p.act[st], acc, Aout, bias, wn, lane, ln, &wsum);
             } else {
-                chain_stage_tile<CFG, T, false>(p.act[st], acc, Aout, bias[st], wn, lane, nullptr, nullptr);
+                chain_stage_tile<CFG, T, false>(p.act[st], acc, Aout, bias, wn, lane, nullptr, nullptr);
             }
             __syncthreads();
             if (!last) {
@@ -623,8 +637,128 @@ __global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(Chain
         }
         m0 = mnext;
 #pragma unroll
-        for (int it = 0; it < X_IT; ++it) { xr[it] = xn[it]; rr[it] = rn[it]; }
+        for (int it = 0; it < X_IT; ++it) { xr[it] = xn[it]; rr[it] = rn[it]; xn[it] = xn2[it]; rn[it] = rn2[it]; }
     }
+}
+
+
+// Fan-out only, weights-stationary (fp16, C = 128): NF C -> C layers that all read the SAME input rows -- the Q | K | V projection of an
+// attention at 1/4 and 1/8 resolution (reference attentions.py:24-28,71-74 behind the pre-norm of :117,148) as ONE pass over the rows:
+// the input tile is loaded once, the pre-LayerNorm statistics are taken once, the (NF*C, C) weight stays in LDS for the life of the block,
+// each layer's 32 x 128 output tile is staged and stored to its column block of the (rows, NF*C) output.  The K5 tile kernel it replaces
+// re-loads the input tile per 128-cout block and runs at 230 TF/s / 2.4 TB/s of its 160 MB (profiles/r03/layer_trace_eager.txt).
+template <int NF>
+__global__ __launch_bounds__(ChainWsCfg<NF>::NT) void mlp_fan_ws_kernel(ChainArgs p, int ntiles) {
+    using CFG = ChainWsCfg<NF>;
+    using T = half_t;
+    constexpr int C = CFG::C, VEC = CFG::VEC, ARS = CFG::ARS, PPR = CFG::PPR, GT = CFG::GT, X_IT = CFG::X_IT, BM = CFG::BM;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* Wt = reinterpret_cast<T*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave / CFG::NWG, wn = wave - g * CFG::NWG;
+    const int gt = tid - g * GT;
+    T* A0 = reinterpret_cast<T*>(smem + CFG::W_BYTES + (size_t)(2 * g) * CFG::A_BYTES);
+    T* A1 = A0 + BM * ARS;
+    float* Cv = reinterpret_cast<float*>(smem + CFG::W_BYTES + (size_t)CFG::NG * 2 * CFG::A_BYTES);
+    for (int q = tid; q < NF * 2 * C; q += CFG::NT) {
+        const int st = q / (2 * C), r = q - st * 2 * C;
+        const float* src = r < C ? p.fan_b : p.fan_wsum;
+        Cv[q] = src ? src[st * C + (r < C ? r : r - C)] : 0.f;
+    }
+    const T* wsrc = static_cast<const T*>(p.fan_w);
+    for (int q = tid; q < NF * C * PPR; q += CFG::NT) {
+        const int r = q / PPR, pc = q - r * PPR;                   // r: row of the stacked (NF*C, C) weight
+        *reinterpret_cast<raw16_t*>(Wt + (size_t)r * C + ((pc ^ (r & 15)) * VEC)) = global_load16(wsrc + (size_t)r * C + pc * VEC);
+    }
+    const int npair = (ntiles + 1) >> 1;
+    const int niter = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto fetch_rows = [&](long long m0, raw16_t (&r)[X_IT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
+            const long long m = m0 + row;
+            r[it] = global_load16(m < p.rows ? static_cast<const T*>(p.x) + m * p.x_stride + pcx * VEC : static_cast<const T*>(p.zero));
+        }
+    };
+    raw16_t xr[X_IT], xn[X_IT], xn2[X_IT];
+    const long long mstep = (long long)2 * gridDim.x * BM;
+    long long m0 = ((long long)2 * blockIdx.x + g) * BM;
+    fetch_rows(m0, xr);
+    fetch_rows(m0 + mstep, xn);
+    const bool ln_on = p.fan_wsum != nullptr;
+    const int sw = l31 & 15;
+    for (int iter = 0; iter < niter; ++iter) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
+            *reinterpret_cast<raw16_t*>(A0 + (size_t)row * ARS + pcx * VEC) = xr[it];
+        }
+        if (iter + 2 < niter) fetch_rows(m0 + 2 * mstep, xn2);
+        __syncthreads();
+        LnRow ln[1];
+        ln[0].mean = 0.f; ln[0].rstd = 1.f;
+#pragma unroll
+        for (int st = 0; st < NF; ++st) {
+            CoutRegs<CFG> bias, wsum;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int co = wn * 32 + 8 * gq + 4 * hi;
+                bias.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + co);
+                wsum.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + C + co);
+            }
+            float16_t acc[1][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+            float ln_s = 0.f, ln_q = 0.f;
+            const T* arow = A0 + (size_t)l31 * ARS + hi * 8;
+            const T* wrow = Wt + (size_t)(st * C + wn * 32 + l31) * C;
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
+                Frag<T> xf, wf;
+                load_frag(xf, arow + kk * 16);
+                load_frag(wf, wrow + (((2 * kk + hi) ^ sw) * VEC));
+                if (ln_on && st == 0) ln_accumulate(xf, ln_s, ln_q, 0.f);
+                mma32(acc[0][0], wf, xf);
+            }
+            if (ln_on && st == 0) {
+                const float inv = 1.0f / (float)C;
+                const float sm = ln_s + __shfl_xor(ln_s, 32), q = ln_q + __shfl_xor(ln_q, 32);
+                const float mean = sm * inv;
+                ln[0].mean = mean;
+                ln[0].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
+            }
+            if (st > 0) __syncthreads();                           // the previous layer's tile has left A1
+            if (ln_on) chain_stage_tile<CFG, T, true>(S2M2_ACT_NONE, acc, A1, bias, wn, lane, ln, &wsum);
+            else chain_stage_tile<CFG, T, false>(S2M2_ACT_NONE, acc, A1, bias, wn, lane, nullptr, nullptr);
+            __syncthreads();
+            T* outp = static_cast<T*>(p.fan_out) + (size_t)st * C;
+#pragma unroll
+            for (int it = 0; it < X_IT; ++it) {
+                const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
+                const long long m = m0 + row;
+                const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(A1 + (size_t)row * ARS + pcx * VEC);
+                if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.fan_out_stride + pcx * VEC) = v;
+            }
+        }
+        m0 += mstep;
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) { xr[it] = xn[it]; xn[it] = xn2[it]; }
+    }
+}
+
+template <int NF>
+static int launch_fan_ws(const ChainArgs& a, hipStream_t st) {
+    using CFG = ChainWsCfg<NF>;
+    auto kern = mlp_fan_ws_kernel<NF>;
+    static size_t lds_granted[kMaxDevices] = {};
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "mlp_chain")) return 1;
+    const int ntiles = (int)((a.rows + CFG::BM - 1) / CFG::BM);
+    const int npair = (ntiles + 1) / 2;
+    const int grid = npair < 256 ? npair : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::NT), CFG::LDS_BYTES, st, a, ntiles);
+    return check_launch("mlp_chain");
 }
 
 template <int NST>
@@ -665,11 +799,33 @@ extern "C" int s2m2_mlp_chain_supported(int C, int dtype) {
     return 0;
 }
 
+extern "C" int s2m2_mlp_fan_supported(int C, int nfan, int dtype) { return dtype == S2M2_F16 && C == 128 && nfan >= 1 && nfan <= 3; }
+
 extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "mlp_chain: null descriptor");
-    S2M2_REQUIRE(d->x && d->out, "mlp_chain: null x/out");
-    S2M2_REQUIRE(d->nstage >= 1 && d->nstage <= 3, "mlp_chain: nstage=%d (1..3)", d->nstage);
+    S2M2_REQUIRE(d->x, "mlp_chain: null x");
+    if (d->nstage == 0) {
+        // fan-out only: the nfan layers read the x rows themselves (weights-stationary form: fp16, C = 128, nfan 1..3) -- ask
+        // s2m2_mlp_fan_supported first
+        S2M2_REQUIRE(s2m2_mlp_fan_supported(d->C, d->nfan, d->dtype), "mlp_chain: fan-out only (nstage = 0) needs fp16, C = 128, nfan 1..3");
+        S2M2_REQUIRE(d->rows > 0 && d->rows < (1LL << 31) && d->x_stride >= d->C && d->x_stride % 8 == 0, "mlp_chain: bad rows / x_stride");
+        S2M2_REQUIRE(d->fan_weight && d->fan_out && d->fan_out_stride >= (long long)d->nfan * d->C && d->fan_out_stride % 8 == 0,
+                     "mlp_chain: fan-out stages need fan_weight, fan_out and a row stride of at least nfan * C (multiple of 8)");
+        S2M2_REQUIRE(!d->fan_ln_wsum || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
+        ChainArgs f{};
+        f.x = d->x; f.x_stride = d->x_stride; f.rows = d->rows; f.ln_eps = d->ln_eps;
+        f.fan_w = d->fan_weight; f.fan_b = d->fan_bias; f.fan_wsum = d->fan_ln_wsum; f.fan_out = d->fan_out; f.fan_out_stride = d->fan_out_stride;
+        f.nfan = d->nfan;
+        f.zero = zero_page();
+        S2M2_REQUIRE(f.zero, "mlp_chain: cannot allocate the zero page");
+        hipStream_t fst = static_cast<hipStream_t>(stream);
+        if (d->nfan == 1) return launch_fan_ws<1>(f, fst);
+        if (d->nfan == 2) return launch_fan_ws<2>(f, fst);
+        return launch_fan_ws<3>(f, fst);
+    }
+    S2M2_REQUIRE(d->out, "mlp_chain: null out");
+    S2M2_REQUIRE(d->nstage >= 1 && d->nstage <= 3, "mlp_chain: nstage=%d (0..3)", d->nstage);
     S2M2_REQUIRE(s2m2_mlp_chain_supported(d->C, d->dtype), "mlp_chain: C=%d dtype=%d is not supported (fp16: 128/256/384/512, fp32: 128/256)", d->C, d->dtype);
     S2M2_REQUIRE(d->rows > 0 && d->rows < (1LL << 31), "mlp_chain: rows=%lld", d->rows);
     S2M2_REQUIRE(d->x_stride >= d->C && d->x_stride % 8 == 0 && d->out_stride >= d->C && d->out_stride % 8 == 0,

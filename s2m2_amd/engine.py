@@ -113,6 +113,7 @@ class Engine:
         # the chain's 32-row tiles occupy 76-152 CUs and three more weight streams double its length, which costs what the separate
         # 456-block K5 launch cost -- off by default
         self.fuse_qkv = os.environ.get("S2M2_FUSE_QKV", "0") == "1"
+        self.fan_ws = os.environ.get("S2M2_FAN_WS", "1") != "0"         # A/B switch: 0 = the Q | K | V projection at 1/4 and 1/8 as a K5 launch
         self.fuse_gru = os.environ.get("S2M2_FUSE_GRU", "1") != "0"     # A/B switch: 0 = the z and r gates of ConvGRU as two launches
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
         self.cv_aligned = os.environ.get("S2M2_CV_ALIGNED", "1") != "0"  # A/B switch: 0 = dense cost-volume rows (pitch = w)
@@ -320,6 +321,11 @@ class Engine:
 
     def qkv(self, p: str, x: Tensor) -> Tensor:
         spec = self.qkv_spec(p)
+        c = x.shape[-1]
+        rows = x.numel() // c
+        if (self.fan_ws and self.fuse_ln and spec[2] == 1 and spec[3] == 1 and spec[4] == 3 * c and rows >= 32768
+                and hip.mlp_fan_supported(c, 3, self.dtype)):
+            return hip.mlp_fan(x, spec[0], spec[1], self.wsum(spec))       # one pass over the rows, the stacked weight resident in LDS
         return self.cconv(spec, [x], ln=self.fuse_ln) if self.fuse_ln else self.cconv(spec, [hip.layernorm(x)])
 
     def attn_core(self, p: str, z: Tensor, nh: int, two_d: bool, cross: bool, use_pe: bool, qkv: Optional[Tensor] = None) -> Tensor:

@@ -65,6 +65,7 @@ SIGNATURES = {
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
     "s2m2_mlp_chain_supported": (_i, [_i, _i]),
+    "s2m2_mlp_fan_supported": (_i, [_i, _i, _i]),
     "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
     "s2m2_feature_fusion_supported": (_i, [_i, _i]),
     "s2m2_feature_fusion": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -398,6 +399,33 @@ def _token_rows(x: torch.Tensor, what: str):
 
 def mlp_chain_supported(C: int, dtype: torch.dtype) -> bool:
     return bool(load().s2m2_mlp_chain_supported(C, _DT[dtype]))
+
+
+def mlp_fan_supported(C: int, nfan: int, dtype: torch.dtype) -> bool:
+    return bool(load().s2m2_mlp_fan_supported(C, nfan, _DT[dtype]))
+
+
+def mlp_fan(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ln_wsum: Optional[torch.Tensor], ln_eps: float = 1e-5) -> torch.Tensor:
+    """n stacked C -> C layers on the rows of x (..., C) -> (..., n*C) in one pass over the rows (s2m2_mlp_chain with nstage = 0: the
+    weights-stationary fan-out form; pre-LayerNorm folded in when ln_wsum is given).  weight packed (n*C, C)."""
+    C = x.shape[-1]
+    rows, xs = _token_rows(x, "mlp_fan")
+    n = weight.shape[0] // C
+    if weight.dtype != x.dtype or tuple(weight.shape) != (n * C, C) or not weight.is_contiguous() or not weight.is_cuda or not x.is_cuda:
+        raise ValueError(f"mlp_fan: weight must be a packed (n*{C}, {C}) {x.dtype} device matrix")
+    for name, t in (("bias", bias), ("ln_wsum", ln_wsum)):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != n * C or not t.is_contiguous() or not t.is_cuda):
+            raise ValueError(f"mlp_fan: {name} must be fp32 ({n * C}) on the device")
+    out = torch.empty(tuple(x.shape[:-1]) + (n * C,), device=x.device, dtype=x.dtype)
+    d = ChainDesc()
+    d.x, d.x_stride, d.rows, d.C, d.nstage, d.dtype, d.ln_eps = x.data_ptr(), xs, rows, C, 0, _DT[x.dtype], ln_eps
+    d.res_stage = -1
+    d.fan_weight, d.fan_out, d.fan_out_stride, d.nfan = weight.data_ptr(), out.data_ptr(), n * C, n
+    d.fan_bias = bias.data_ptr() if bias is not None else None
+    d.fan_ln_wsum = ln_wsum.data_ptr() if ln_wsum is not None else None
+    _check(load().s2m2_mlp_chain(ctypes.byref(d), _stream()), "s2m2_mlp_chain")
+    _meter("mlp_chain", 2.0 * rows * C * C * n)
+    return out
 
 
 def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:

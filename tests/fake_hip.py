@@ -87,6 +87,9 @@ def make():
     def mlp_chain_ln_out_supported(C, dtype):
         return C in (128, 256)
 
+    def mlp_fan_supported(C, nfan, dtype):
+        return False
+
     def corr_tiled_supported(C, dtype):
         return False                                     # (the CPU stand-in keeps row-major tokens: the fp32 wiring test never tiles)
 
@@ -216,7 +219,7 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, corr_tiled_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, corr_tiled_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
     ns.TiledTokens = TiledTokens
     return ns

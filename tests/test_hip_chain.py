@@ -213,3 +213,28 @@ def test_chain_fan_out_stages(hip, C, dtype, shp, nst, nfan, ln):
         y3, n3, q3 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=nst == 3, ln_out=(gam, bet, 1e-5), fan=(wp, bp, wsum))
         assert torch.equal(y3, y) and torch.equal(q3, q)
         assert float((n3.float() - F.layer_norm(y.float(), (C,))).abs().max()) < (2e-5 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("shp,nfan,ln", [((2, 256, 304), 3, True), ((1, 255, 303), 3, True), ((2, 128, 152), 3, True), ((1, 7, 9), 3, True),
+                                         ((1, 200, 300), 2, False), ((1, 100, 100), 1, True)])
+def test_fan_only_weights_stationary(hip, shp, nfan, ln):
+    """s2m2_mlp_chain with nstage = 0: nfan C -> C layers on the SAME input rows in one pass (the Q | K | V projection at 1/4 and 1/8
+    resolution) == the stand-alone K5 launch with the same folded pre-LayerNorm, and == F.linear(F.layer_norm(x)) in fp32."""
+    C, dtype = 128, torch.float16
+    assert hip.mlp_fan_supported(C, nfan, dtype) and not hip.mlp_fan_supported(256, 3, dtype) and not hip.mlp_fan_supported(C, 3, torch.float32)
+    g = torch.Generator(device="cuda").manual_seed(shp[1] + nfan)
+    x = (torch.randn(*shp, C, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
+    wq = (torch.randn(nfan * C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+    bq = torch.randn(nfan * C, device="cuda", generator=g) * 0.3
+    wp, bp = pack.pack_conv(wq, dtype), pack.pack_bias(bq, nfan * C)
+    wsum = wp.float().sum(1).contiguous() if ln else None
+    q = hip.mlp_fan(x, wp, bp, wsum)
+    assert q.shape == (*shp, nfan * C)
+    a = F.layer_norm(x.float(), (C,)) if ln else x.float()
+    ref = F.linear(a, wq.reshape(nfan * C, C).float(), bq)
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((q.float() - ref).abs().max()) < 4e-3 * scale
+    sep = hip.conv2d([x.reshape(1, 1, -1, C)], wp, bp, 1, 1, nfan * C, ln_wsum=wsum).reshape(q.shape)
+    assert float((q.float() - sep.float()).abs().max()) < 2 ** -7 * scale
+    q2 = hip.mlp_fan(x, wp, None, wsum)                     # no bias
+    assert float((q2.float() - (ref - bq)).abs().max()) < 4e-3 * scale
