@@ -113,6 +113,7 @@ class Engine:
         # the chain's 32-row tiles occupy 76-152 CUs and three more weight streams double its length, which costs what the separate
         # 456-block K5 launch cost -- off by default
         self.fuse_qkv = os.environ.get("S2M2_FUSE_QKV", "0") == "1"
+        self.pw_ws = os.environ.get("S2M2_PW_WS", "1") != "0"           # A/B switch: 0 = plain 1x1 128 -> 128 layers at 1/4 resolution as K5 launches
         self.fan_ws = os.environ.get("S2M2_FAN_WS", "1") != "0"         # A/B switch: 0 = the Q | K | V projection at 1/4 and 1/8 as a K5 launch
         self.fuse_gru = os.environ.get("S2M2_FUSE_GRU", "1") != "0"     # A/B switch: 0 = the z and r gates of ConvGRU as two launches
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
@@ -197,6 +198,12 @@ class Engine:
         """K5 launch.  ln: the layer is a pre-LayerNorm (no affine, attentions.py:117) followed by this 1x1 layer, folded into
         the kernel -- needs the row sums of the packed weight, computed once per layer."""
         wp, bp, kh, kw_, cout = spec
+        # a plain 1x1 C -> C layer on >= 32768 rows of 128 fp16 channels (1/4 resolution): the weights-stationary persistent form of K9 as a
+        # one-stage chain (the 32 KB weight resident in LDS, one pass over the rows) instead of the K5 tile kernel
+        if (self.pw_ws and kh == 1 and kw_ == 1 and len(srcs) == 1 and self.dtype == torch.float16 and cout == 128 and srcs[0].shape[-1] == 128
+                and tuple(wp.shape) == (128, 128) and srcs[0].numel() // 128 >= 32768 and not getattr(spec, "korder", 0)
+                and set(kw) <= {"act"} and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU) and self.chain_ok(128)):
+            return hip.mlp_chain(srcs[0], [(wp, bp, kw.get("act", hip.ACT_NONE), self.wsum(spec) if ln else None)])
         if ln:
             kw["ln_wsum"] = self.wsum(spec)
         if getattr(spec, "korder", 0):

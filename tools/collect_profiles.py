@@ -17,7 +17,8 @@ for f in ("bench_N1.json", "bench_N1_banded.json", "kbench.txt", "convbench_3x3_
           "frag_timeline.txt", "fusionbench.txt", "layer_ab_frag.txt", "layer_trace_eager.txt", "parity_c1_c3_c2.txt", "configs_all_models.txt",
           "pytest_gpu.txt", "attnbench_kt4.txt", "convbench_3x3_hot.txt", "k1_store_path.txt", "clock_probe.txt", "layer_ab_frag_pw.txt",
           "layer_ab_frag_aux_pw.txt", "parity_tables.txt", "parity_c4_c5_vs_reference.txt", "ab_k1_own_ln_dense.json", "ab_frag_pw32.json",
-          "ab_frag_aux_pw32.json", "ab_k2_notri.json", "ab_default.json"):
+          "ab_frag_aux_pw32.json", "ab_k2_notri.json", "ab_default.json", "ab_no_fan_ws.json", "ab_no_pw_ws.json", "ab_no_chain_ws.json",
+          "ab_gru_separate.json", "ab_round3_all_off.json", "chainbench.txt", "chainbench_no_ws.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 copies = {"prof_bench/bench_kernel_stats.csv": "bench_c3_S_fp16_kernel_stats.csv", "prof_k1_c3/k1_kernel_stats.csv": "k1_only_c3_kernel_stats.csv",

@@ -32,8 +32,8 @@ timeout 200 python tools/k1_store_path.py c3 2>&1 | grep -v amdgpu.ids > $OUT/k1
 S2M2_LIB_SUFFIX=_k1trace timeout 120 python tools/k1_trace.py c3 --prenorm --aligned 2>&1 | grep -v amdgpu.ids > $OUT/k1_timeline.txt
 timeout 300 python tools/clock_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/clock_probe.txt
 timeout 300 python tools/layer_trace.py --iters 3 2>&1 | grep -v amdgpu.ids > $OUT/layer_trace_eager.txt
-timeout 300 python tools/layer_trace.py --ab S2M2_FRAG_PW=32,0 --iters 5 2>&1 | grep -v amdgpu.ids > $OUT/layer_ab_frag_pw.txt
-timeout 300 python tools/layer_trace.py --ab S2M2_FRAG_AUX_PW=32,40 --iters 5 2>&1 | grep -v amdgpu.ids > $OUT/layer_ab_frag_aux_pw.txt
+timeout 300 python tools/chainbench.py 2>&1 | grep -v amdgpu.ids > $OUT/chainbench.txt
+S2M2_CHAIN_WS=0 timeout 300 python tools/chainbench.py 2>&1 | grep -v amdgpu.ids > $OUT/chainbench_no_ws.txt
 # 5. parity tables at the BASELINE sizes + the other configurations through the drop-in module
 timeout 900 python tools/parity_report.py $OUT/parity_tables.txt > /dev/null 2>&1
 timeout 600 python tools/parity_report_big.py $OUT/parity_c4_c5_vs_reference.txt > /dev/null 2>&1
@@ -44,6 +44,11 @@ bench S2M2_FUSE_K1LN=0 S2M2_CV_ALIGNED=0 > $OUT/ab_k1_own_ln_dense.json
 bench S2M2_FRAG_PW=32 S2M2_FRAG_AUX_PW=32 > $OUT/ab_frag_pw32.json
 bench S2M2_FRAG_AUX_PW=32 > $OUT/ab_frag_aux_pw32.json
 bench S2M2_K2_TRI=0 > $OUT/ab_k2_notri.json
+bench S2M2_FAN_WS=0 > $OUT/ab_no_fan_ws.json
+bench S2M2_PW_WS=0 > $OUT/ab_no_pw_ws.json
+bench S2M2_CHAIN_WS=0 > $OUT/ab_no_chain_ws.json
+bench S2M2_FUSE_GRU=0 > $OUT/ab_gru_separate.json
+bench S2M2_FAN_WS=0 S2M2_PW_WS=0 S2M2_CHAIN_WS=0 S2M2_FUSE_GRU=0 S2M2_FRAG_PW=32 S2M2_FRAG_AUX_PW=32 S2M2_K2_TRI=0 S2M2_FUSE_K1LN=0 S2M2_CV_ALIGNED=0 > $OUT/ab_round3_all_off.json
 bench A=1 > $OUT/ab_default.json
 python - <<PY
 import json, glob
