@@ -362,6 +362,9 @@ def main():
         e = 2 if use_fp16 else 4
         k1_bytes = B * (2 * h * w * C * e + h * w * w * e)         # read both feature maps once + write cv once
         k1_variant = "full volume (B,h,w,w)"
+        if eng._tokens_normed is not None:                         # DispInit's LayerNorm ran in the K9 launch that wrote the tokens (engine.features)
+            k1_variant += ", tokens normalised by the producing K9 launch (s2m2_corr), volume rows on 128-byte lines" if eng.cv_aligned else \
+                          ", tokens normalised by the producing K9 launch (s2m2_corr)"
         if eng.cv_band >= 0:                                       # opt-in banded store (S2M2_CV_BAND=1): only j <= i + band must be written
             k1_bytes = B * (2 * h * w * C * e + h * e * sum(min(w, i + 1 + eng.cv_band) for i in range(w)))
             k1_variant = f"banded volume j <= i + {eng.cv_band}"
@@ -397,7 +400,7 @@ def main():
             "config": {"workload": f"{a.model}-model {a.width}x{a.height} refine_iter={a.refine_iter} use_positivity=True, "
                                    f"{B} pair(s) per GPU per step, random-init weights (seeded LeCun normal)",
                        "pairs_per_gpu": B, "parallelism": f"dp{world} (pairs sharded, RCCL gather of outputs to rank 0)"},
-            "roofline": {"kernel": "ln_corr_kernel (K1: LayerNorm + all-pairs correlation -> cost volume)", "bound": "hbm", "variant": k1_variant,
+            "roofline": {"kernel": "ln_corr_kernel (K1: all-pairs correlation of the LayerNorm'ed tokens -> cost volume)", "bound": "hbm", "variant": k1_variant,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": k1_us,
                          "launches_timed": len(k1_ms)},
