@@ -1644,6 +1644,11 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
 }  // namespace s2m2
 
 #if S2M2_FRAG_TRACE
+extern "C" int s2m2_debug_frag_trace_clear(void) {
+    void* dev = nullptr;
+    if (hipGetSymbolAddress(&dev, HIP_SYMBOL(s2m2::g_frag_trace)) != hipSuccess) return 1;
+    return hipMemset(dev, 0, sizeof(s2m2::g_frag_trace)) == hipSuccess ? 0 : 1;
+}
 extern "C" int s2m2_debug_frag_trace(void* host, size_t bytes) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(s2m2::g_frag_trace), bytes < sizeof(s2m2::g_frag_trace) ? bytes : sizeof(s2m2::g_frag_trace)) == hipSuccess ? 0 : 1;
 }
