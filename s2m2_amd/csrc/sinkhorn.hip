@@ -129,10 +129,24 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             }
     };
     auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) { fetch_row_from(i, raw, TRI ? 2 : 0); };
-    auto decode_row = [&](int i, const raw16_t (&raw)[NCH][PPC], float (&x)[NE]) __attribute__((always_inline)) {
+    // nfast: leading chunks whose columns are valid for EVERY row of this wave in this step (regular rows, nothing masked): a plain
+    // convert.  nchw: chunks that hold any unmasked column of the wave (later ones are never touched by any sweep, see chunks_needed).
+    // The per-element compare / select (two instructions per element) is left to the one or two chunks the diagonal crosses -- measured
+    // before this split: 126 of the ~410 VALU instructions of a 4-row step were the decode of 24 elements per lane, half of them masked.
+    auto decode_row = [&](int i, const raw16_t (&raw)[NCH][PPC], float (&x)[NE], int nfast, int nchw) __attribute__((always_inline)) {
         const int jend = i < w ? (use_pos ? i + 1 : w) : (i == w ? w : 0);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < NCH; ++c) {
+            if (c >= nchw) continue;                              // (wave-uniform)
+            if (c < nfast) {
+#pragma unroll
+                for (int q = 0; q < PPC; ++q) {
+                    const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[c][q]);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) x[c * 8 + q * VEC + e] = to_f32(r.v[e]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < PPC; ++q) {
                 const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[c][q]);
@@ -142,6 +156,13 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                     x[c * 8 + q * VEC + e] = j < jend ? (i < w ? to_f32(r.v[e]) : 0.f) : -INFINITY;   // masked triangle / past the row
                 }
             }
+        }
+    };
+    // chunks fully valid for every row of this wave in the step starting at row i0 (uniform per wave)
+    auto chunks_fast = [&](int i0) {
+        const int imin = i0 + wv * RPW, imax = imin + RPW - 1;
+        if (imax >= w) return 0;                                  // a dustbin / idle row in the wave: general decode
+        return (use_pos ? imin + 1 : w) / CW;
     };
 
     const int r0 = wv * RPW + grp;                         // rows of this group: r0, r0 + RPB, ...
@@ -178,7 +199,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                 for (int q = 0; q < PPC; ++q) raw[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f};
             if (active) fetch_row_from(i, raw, use_u ? (TRI ? 2 : 0) : (TRI ? 1 : 0));
             float x[NE];
-            decode_row(active ? i : w + 1, raw, x);
+            decode_row(active ? i : w + 1, raw, x, chunks_fast(i0), nchw);
             const float ua = active ? (use_u ? u[i] : 0.f) : -INFINITY;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             const int nchw = chunks_needed(i0);
             if (i + RPB <= w) fetch_row(i + RPB, rnext);          // in flight under this row's arithmetic
             float x[NE];
-            decode_row(active ? i : w + 1, rcur, x);
+            decode_row(active ? i : w + 1, rcur, x, chunks_fast(i0), nchw);
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
 #pragma unroll
