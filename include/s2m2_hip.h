@@ -95,6 +95,14 @@ int s2m2_debug_store_pattern(void* cv, int rows, int w, int cv_pitch, int mode, 
 size_t s2m2_corr_tiled_bytes(int B, int h, int w, int C);
 int s2m2_corr_tiled(const void* tokens_tiled, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype, int band,
                     void* stream, void* start_event, void* stop_event);
+/*
+ * [A4] K1 on normalised tokens with the LEFT tokens in MFMA-fragment order (the tiled half written by s2m2_mlp_chain with
+ *   ln_out_tile_rows = B*h*w) and the RIGHT tokens row-major ((B, h, w, C) fp16): the LDS form of s2m2_corr, except that a wave's 32 left
+ *   tokens go from global memory straight into its MFMA operand registers (coalesced 1 KB fragment loads) instead of through an LDS bounce.
+ *   left_tiled: s2m2_corr_tiled_bytes(B, h, w, C) / 2 bytes.  cv, cv_pitch, band, events as s2m2_corr; fp16 tokens.
+ */
+int s2m2_corr_hybrid(const void* left_tiled, const void* right_rows, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype, int band,
+                     void* stream, void* start_event, void* stop_event);
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);
@@ -236,6 +244,10 @@ typedef struct s2m2_chain_desc {
        tokens, cut into 32-token tiles; the 16-byte piece (token x of image row r, channels 8p .. 8p+7) goes to 16-byte slot
        ((r * ceil(w/32) + x/32) * (C/16) + p/2) * 64 + (p%2) * 32 + x%32 of a buffer of s2m2_corr_tiled_bytes(); ln_out_stride is ignored. */
     int ln_out_tile_w;
+    /* > 0 (with ln_out_tile_w): only rows [0, ln_out_tile_rows) -- the LEFT images of a stereo batch -- go to the tiled buffer `ln_out`; the rows
+       from ln_out_tile_rows on are written row-major to ln_out_rows + (row - ln_out_tile_rows) * ln_out_stride (consumed by s2m2_corr_hybrid). */
+    long long ln_out_tile_rows;
+    void* ln_out_rows;
     /* fan-out stages, nfan = 0: none.  nfan further C -> C layers that ALL read the chain's `out` rows (while they are still in LDS) and
        write fan_out[:, f*C:(f+1)*C] = W_f . (fan_ln_wsum ? LayerNorm(out rows) : out rows) + b_f  -- the Q | K | V projection of the attention
        block that follows (reference attentions.py:24-28,71-74 behind the pre-norm of :117,148), fused into the launch that produces its

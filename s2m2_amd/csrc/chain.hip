@@ -51,6 +51,8 @@ struct ChainArgs {
     long long fan_out_stride;
     int nfan;
     int ln_tile_w;                      // > 0: ln_out in the MFMA-fragment order of s2m2_corr_tiled, the rows being image rows of ln_tile_w tokens
+    long long ln_tile_rows;             // > 0 (with ln_tile_w): only rows below this index go to the tiled buffer `ln_out`; rows at or above it are
+    void* ln_out_rows;                  //   written row-major to ln_out_rows + (m - ln_tile_rows) * ln_out_stride  (s2m2_corr_hybrid: left images tiled)
     // > 0: row tiles are handed to blocks so that the XCD a block runs on (hardware: block b on XCD b % 8) owns the tiles of ONE eighth of
     // every image -- xcd_tiles consecutive tiles per image and XCD.  The consumer K1 places image row y on XCD y / (h / 8): it then finds the
     // normalised tokens in the L2 of the XCD that wrote them.
@@ -278,7 +280,9 @@ struct ChainStage {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
                     if (m < p.rows) {
-                        if (sizeof(T) == 2 && p.ln_tile_w > 0) {
+                        if (sizeof(T) == 2 && p.ln_tile_w > 0 && p.ln_tile_rows > 0 && m >= p.ln_tile_rows) {
+                            *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out_rows) + (m - p.ln_tile_rows) * p.ln_out_stride + pcx * VEC) = o;
+                        } else if (sizeof(T) == 2 && p.ln_tile_w > 0) {
                             // fragment order: 32-token tile t of image row rid, k16 step kk = pcx / 2, half hh = pcx % 2 -> 16-byte slot
                             // ((rid * NT + t) * KS + kk) * 64 + hh * 32 + token % 32   (what a lane of K1 loads for its MFMA operand)
                             const long long rid = m / p.ln_tile_w;
@@ -622,7 +626,9 @@ __global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(Chain
 #pragma unroll
                         for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
                         if (m < p.rows) {
-                            if (p.ln_tile_w > 0) {
+                            if (p.ln_tile_w > 0 && p.ln_tile_rows > 0 && m >= p.ln_tile_rows) {
+                                *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out_rows) + (m - p.ln_tile_rows) * p.ln_out_stride + pcx * VEC) = o;
+                            } else if (p.ln_tile_w > 0) {
                                 const long long rid = m / p.ln_tile_w;
                                 const int xq = (int)(m - rid * p.ln_tile_w);
                                 const long long slot = ((rid * ((p.ln_tile_w + 31) >> 5) + (xq >> 5)) * (C / 16) + (pcx >> 1)) * 64 + (pcx & 1) * 32 + (xq & 31);
@@ -852,6 +858,9 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     a.res_stage = d->res_stage; a.carry = d->carry; a.ln_eps = d->ln_eps;
     a.ln_out = d->ln_out; a.ln_out_stride = d->ln_out_stride; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out_eps = d->ln_out_eps;
     a.ln_tile_w = d->ln_out_tile_w;
+    a.ln_tile_rows = d->ln_out_tile_rows; a.ln_out_rows = d->ln_out_rows;
+    S2M2_REQUIRE(d->ln_out_tile_rows == 0 || (d->ln_out_tile_w > 0 && d->ln_out_rows && d->ln_out_tile_rows % d->ln_out_tile_w == 0 && d->ln_out_tile_rows < d->rows),
+                 "mlp_chain: ln_out_tile_rows needs ln_out_tile_w, ln_out_rows and a whole number of image rows below `rows`");
     a.fan_w = d->fan_weight; a.fan_b = d->fan_bias; a.fan_wsum = d->fan_ln_wsum; a.fan_out = d->fan_out; a.fan_out_stride = d->fan_out_stride;
     a.nfan = d->nfan;
     S2M2_REQUIRE(d->nfan >= 0 && d->nfan <= 4, "mlp_chain: nfan=%d (0..4)", d->nfan);

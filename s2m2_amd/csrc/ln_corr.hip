@@ -201,7 +201,7 @@ __device__ __forceinline__ void store_cv(TO* dst, const Vec16<TO>& v, int nt) {
 template <typename CFG, typename T, typename TO>
 __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, TO* __restrict__ cv,
-                                                                 int B, int h, int w, int nstrip, int band, int pitch, int flags) {
+                                                                 int B, int h, int w, int nstrip, int band, int pitch, int flags, const raw16_t* __restrict__ left_tiled) {
     constexpr int dbg = S2M2_LNCORR_DBG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
@@ -280,6 +280,31 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
     };
     if constexpr (CFG::PRENORM) {
         static_assert(!CFG::PIPE, "the pipelined variant has no normalised-input form");
+        bool hybrid = false;
+        if constexpr (sizeof(T) == 2) {
+        if (left_tiled != nullptr) {                               // block-uniform
+            hybrid = true;
+            // hybrid (s2m2_corr_hybrid): the left tokens arrive in MFMA-fragment order -- fragment kk of this wave's 32-token tile is one
+            // coalesced 1 KB read straight into the operand registers: no LDS bounce, no wave barriers.  The right tokens are requested
+            // FIRST (loads return in order: they are what the block barrier waits for), the fragments behind them.
+            raw16_t lf[CFG::KSTEPS];
+            const int NT = (w + 31) >> 5;
+            const raw16_t* lp = left_tiled + ((size_t)((size_t)(b * h + y) * NT + (i0 >> 5)) * CFG::KSTEPS) * 64 + lane;
+            if (CFG::EARLY_B) pre_issue(pre_b, right, wv * CFG::TPW);
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) global_load16_async(lf[kk], lp + (wave_active ? kk : 0) * 64);
+            K1_T(2);
+            if (CFG::EARLY_B) {
+                wait_vmcnt<CFG::KSTEPS>();                         // the KSTEPS fragment requests may still be in flight
+                pre_stash(pre_b, 0);
+            }
+            K1_T(3);
+            wait_vmcnt<0>();
+#pragma unroll
+            for (int kk = 0; kk < CFG::KSTEPS; ++kk) { settle(lf[kk]); afrag[kk].v = __builtin_bit_cast(half8_t, lf[kk]); }
+        }
+        }
+        if (!hybrid) {
         pre_issue(pre_a, left, i0);
         if (CFG::EARLY_B) pre_issue(pre_b, right, wv * CFG::TPW);
         K1_T(2);
@@ -296,6 +321,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         if (CFG::EARLY_B) {
             wait_vmcnt<0>();
             pre_stash(pre_b, 0);
+        }
         }
     } else {
         Vec16<T> rawA[CFG::RIF][CFG::PPL];
@@ -598,6 +624,7 @@ __global__ __launch_bounds__(1024) void corr_stream_kernel(const raw16_t* __rest
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static thread_local int g_band = -1;                 // s2m2_ln_corr_banded: columns right of the diagonal that must be valid (-1: all)
 static thread_local int g_pitch = 0;                 // s2m2_corr: elements between volume rows (0: w)
+static thread_local const void* g_left_tiled = nullptr;   // s2m2_corr_hybrid: left tokens in fragment order
 
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st);
@@ -638,10 +665,10 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     }
     if (g_ev_start || g_ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
-                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
+                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags, static_cast<const raw16_t*>(g_left_tiled));
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
-                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
+                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags, static_cast<const raw16_t*>(g_left_tiled));
     return check_launch("ln_corr");
 }
 
@@ -725,6 +752,33 @@ static int launch_corr_stream(const void* frag, void* cv, int B, int h, int w, i
     hipExtLaunchKernelGGL(kern, dim3(B * h * nsplit), dim3(nwb * 64), lds, st, e0, e1, 0, static_cast<const raw16_t*>(frag),
                           static_cast<TO*>(cv), B, h, w, NT, nsplit, band, pitch, k1_flags);
     return check_launch("corr_tiled");
+}
+
+extern "C" int s2m2_corr_hybrid(const void* left_tiled, const void* right_rows, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype,
+                                int band, void* stream, void* start_event, void* stop_event) {
+    using namespace s2m2;
+    S2M2_REQUIRE(left_tiled && right_rows && cv, "corr_hybrid: null pointer");
+    S2M2_REQUIRE(B > 0 && h > 0 && w > 0 && w % 8 == 0, "corr_hybrid: bad shape B=%d h=%d w=%d (w a multiple of 8)", B, h, w);
+    S2M2_REQUIRE(C == 64 || C == 128, "corr_hybrid: C=%d (64 or 128: one chunk of right tokens per 32-token left tile)", C);
+    if (cv_pitch == 0) cv_pitch = w;
+    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "corr_hybrid: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    g_ev_start = static_cast<hipEvent_t>(start_event);
+    g_ev_stop = static_cast<hipEvent_t>(stop_event);
+    g_band = band >= 0 ? band : -1;
+    g_pitch = cv_pitch;
+    g_left_tiled = left_tiled;
+    // the kernel indexes the right images as batch entries [B, 2B) of one (2B, h, w, C) tensor: hand it a base B images before right_rows
+    const half_t* base = static_cast<const half_t*>(right_rows) - (size_t)B * h * w * C;
+    int rc;
+    if (cv_dtype == S2M2_F16) rc = dispatch_c<half_t, half_t, true>(base, nullptr, nullptr, cv, B, h, w, C, st);
+    else if (cv_dtype == S2M2_F32) rc = dispatch_c<half_t, float, true>(base, nullptr, nullptr, cv, B, h, w, C, st);
+    else rc = set_error("corr_hybrid: unsupported cv dtype %d", cv_dtype);
+    g_ev_start = g_ev_stop = nullptr;
+    g_band = -1;
+    g_pitch = 0;
+    g_left_tiled = nullptr;
+    return rc;
 }
 
 extern "C" size_t s2m2_corr_tiled_bytes(int B, int h, int w, int C) {

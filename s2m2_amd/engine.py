@@ -123,7 +123,10 @@ class Engine:
         # stand-alone like the LDS form, but 22.4 vs 19.4 us inside the forward (the right row is re-read once per wave from L2 / MALL
         # instead of once into LDS) -- off by default
         self.k1_stream = os.environ.get("S2M2_K1_STREAM", "0") == "1"
-        self._tokens_normed = None                               # Tensor (row-major) or hip.TiledTokens (fragment order)
+        # opt-in experiment (S2M2_K1_HYBRID=1, fp16, C 64 / 128): K9 writes the normalised LEFT tokens in fragment order and the right
+        # tokens row-major; K1 (hip.corr_hybrid) keeps its LDS right row but loads its left operand straight into registers
+        self.k1_hybrid = os.environ.get("S2M2_K1_HYBRID", "0") == "1"
+        self._tokens_normed = None                               # Tensor (row-major), hip.TiledTokens or hip.HybridTokens
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
@@ -381,6 +384,8 @@ class Engine:
                 n, h, w, _ = z.shape
                 grp = (h // 8) * w if h % 8 == 0 else 0
                 tiled = self.k1_stream and hip.corr_tiled_supported(c, self.dtype)     # fragment order for the streaming form of K1
+                if self.k1_hybrid and not tiled and hip.corr_hybrid_supported(c, self.dtype) and w % 8 == 0:
+                    tiled = "left"
                 out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp,
                                                          ln_out_tiled=tiled)
                 return out, None
@@ -581,6 +586,8 @@ class Engine:
                 out = self.cv_buffer(tr)
             if isinstance(normed, hip.TiledTokens):
                 return hip.corr_tiled(normed, out=out, timer=timer, band=band)
+            if isinstance(normed, hip.HybridTokens):
+                return hip.corr_hybrid(normed, out=out, timer=timer, band=band)
             return hip.corr(normed, out=out, timer=timer, band=band)
         return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer, band=band)
 

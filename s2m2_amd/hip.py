@@ -41,7 +41,7 @@ class ChainDesc(ctypes.Structure):
                 ("C", _i), ("nstage", _i), ("weight", _vp * 3), ("bias", _vp * 3), ("ln_wsum", _vp * 3), ("act", _i * 3),
                 ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
                 ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float),
-                ("ln_out_tile_w", _i), ("fan_weight", _vp), ("fan_bias", _vp), ("fan_ln_wsum", _vp), ("fan_out", _vp), ("fan_out_stride", _ll),
+                ("ln_out_tile_w", _i), ("ln_out_tile_rows", _ll), ("ln_out_rows", _vp), ("fan_weight", _vp), ("fan_bias", _vp), ("fan_ln_wsum", _vp), ("fan_out", _vp), ("fan_out_stride", _ll),
                 ("nfan", _i), ("xcd_group_rows", _ll)]
 
 
@@ -61,6 +61,7 @@ SIGNATURES = {
     "s2m2_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_corr_tiled_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "s2m2_corr_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_corr_hybrid": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
@@ -243,6 +244,51 @@ def corr_tiled(tokens: TiledTokens, cv_dtype: torch.dtype = torch.float16, out: 
                                   timer.start if timer is not None else None, timer.stop if timer is not None else None), "s2m2_corr_tiled")
     _meter("ln_corr", 2.0 * B * h * w * w * C)
     return cv
+
+
+class HybridTokens:
+    """Normalised fp16 tokens of a stereo pair batch for s2m2_corr_hybrid (written by mlp_chain(..., ln_out_tiled="left")): the B left
+    images in the MFMA-fragment order of TiledTokens (``left``, a flat buffer), the B right images row-major (``right`` (B,h,w,C))."""
+
+    def __init__(self, B: int, h: int, w: int, C: int, device):
+        self.B, self.h, self.w, self.C = B, h, w, C
+        n = int(load().s2m2_corr_tiled_bytes(B, h, w, C)) // 2
+        self.left = torch.empty(n // 2, device=device, dtype=torch.float16)
+        self.right = torch.empty((B, h, w, C), device=device, dtype=torch.float16)
+
+    @staticmethod
+    def from_rows(tokens: torch.Tensor) -> "HybridTokens":
+        """(2B,h,w,C) fp16 rows -> left tiled / right row-major (test / tool helper)"""
+        twoB, h, w, C = tokens.shape
+        t = HybridTokens(twoB // 2, h, w, C, tokens.device)
+        both = TiledTokens.from_rows(tokens)
+        t.left.copy_(both.buf[:t.left.numel()])
+        t.right.copy_(tokens[twoB // 2:])
+        return t
+
+    def to_rows(self) -> torch.Tensor:
+        nt = (self.w + 31) // 32
+        x = self.left.reshape(self.B, self.h, nt, self.C // 16, 2, 32, 8).permute(0, 1, 2, 5, 3, 4, 6)
+        return torch.cat([x.reshape(self.B, self.h, nt * 32, self.C)[:, :, :self.w], self.right], 0).contiguous()
+
+
+def corr_hybrid(tokens: HybridTokens, cv_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None,
+                timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
+    """K1 with the left tokens read in fragment order (s2m2_corr_hybrid) -> cv (B,h,w,w), a row-padded view unless ``out`` is given."""
+    B, h, w, C = tokens.B, tokens.h, tokens.w, tokens.C
+    cv = out if out is not None else cv_alloc(B, h, w, cv_dtype, tokens.left.device)
+    if tuple(cv.shape) != (B, h, w, w):
+        raise ValueError("corr_hybrid: out must be a (B,h,w,w) tensor")
+    pitch = _cv_pitch(cv, "corr_hybrid")
+    _check(load().s2m2_corr_hybrid(tokens.left.data_ptr(), tokens.right.data_ptr(), cv.data_ptr(), B, h, w, C, pitch, _DT[cv.dtype], band,
+                                   _stream(), timer.start if timer is not None else None, timer.stop if timer is not None else None),
+           "s2m2_corr_hybrid")
+    _meter("ln_corr", 2.0 * B * h * w * w * C)
+    return cv
+
+
+def corr_hybrid_supported(C: int, dtype: torch.dtype) -> bool:
+    return dtype == torch.float16 and C in (64, 128)
 
 
 def corr_tiled_supported(C: int, dtype: torch.dtype) -> bool:
@@ -435,13 +481,14 @@ def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
               ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0,
-              ln_out_tiled: bool = False, fan=None):
+              ln_out_tiled=False, fan=None):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
     res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
     ln_out = (gamma fp32 (C), beta fp32 (C), eps): also return LayerNorm(out) * gamma + beta  -> (out, normalised).
     xcd_group_rows: placement hint (s2m2_chain_desc): x is images of 8 groups of that many rows, group g runs on XCD g.
-    ln_out_tiled (x (N,h,w,C) fp16): the normalised rows come back as a TiledTokens buffer in the fragment order corr_tiled reads.
+    ln_out_tiled (x (N,h,w,C) fp16): the normalised rows come back as a TiledTokens buffer in the fragment order corr_tiled reads;
+    ln_out_tiled="left": as a HybridTokens pair (left images in fragment order, right images row-major) for corr_hybrid.
     fan = (packed weight (n*C, C), fp32 bias (n*C) or None, ln_wsum fp32 (n*C) or None): n further C -> C layers on the OUTPUT rows
     (pre-LayerNorm folded in when ln_wsum is given), returned as one (..., n*C) tensor: the fused QKV projection of the next attention.
     Return value: out, or a tuple (out[, normalised][, fan_out]) in that order."""
@@ -481,9 +528,14 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
         if ln_out_tiled:
             if x.dim() != 4 or x.dtype != torch.float16 or x.shape[0] % 2:
                 raise ValueError("mlp_chain: ln_out_tiled needs (2B,h,w,C) fp16 rows")
-            normed = TiledTokens(x.shape[0] // 2, x.shape[1], x.shape[2], C, x.device)
             d.ln_out_tile_w = x.shape[2]
-            ln_ptr = normed.buf.data_ptr()
+            if ln_out_tiled == "left":
+                normed = HybridTokens(x.shape[0] // 2, x.shape[1], x.shape[2], C, x.device)
+                d.ln_out_tile_rows, d.ln_out_rows = rows // 2, normed.right.data_ptr()
+                ln_ptr = normed.left.data_ptr()
+            else:
+                normed = TiledTokens(x.shape[0] // 2, x.shape[1], x.shape[2], C, x.device)
+                ln_ptr = normed.buf.data_ptr()
         else:
             normed = torch.empty(x.shape, device=x.device, dtype=x.dtype)
             ln_ptr = normed.data_ptr()

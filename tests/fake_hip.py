@@ -96,6 +96,12 @@ def make():
     class TiledTokens:                                   # only the isinstance() check of Engine.cost_volume needs it
         pass
 
+    class HybridTokens:
+        pass
+
+    def corr_hybrid_supported(C, dtype):
+        return False
+
     def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0, ln_out_tiled=False, fan=None):
         t, ys = x.float(), []
         for s, (w, b, act, wsum) in enumerate(stages):
@@ -219,7 +225,8 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, corr_tiled_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, corr_tiled_supported, corr_hybrid_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
     ns.TiledTokens = TiledTokens
+    ns.HybridTokens = HybridTokens
     return ns

@@ -175,6 +175,9 @@ def test_chain_layernorm_output_in_fragment_order(hip, hh):
     y1, t1 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), ln_out_tiled=True)
     assert torch.equal(y0, y1) and isinstance(t1, hip.TiledTokens)
     assert torch.equal(t1.to_rows(), n0)
+    y2, t2 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), ln_out_tiled="left")
+    assert torch.equal(y0, y2) and isinstance(t2, hip.HybridTokens)       # left image tiled, right image row-major
+    assert torch.equal(t2.to_rows(), n0) and torch.equal(t2.right, n0[1:])
 
 
 @pytest.mark.parametrize("C,dtype,shp,nst,nfan,ln", [(128, torch.float16, (2, 50, 61), 3, 3, True), (256, torch.float16, (2, 32, 38), 3, 3, True),

@@ -423,9 +423,37 @@ def test_corr_tiled_equals_corr_bit_for_bit(hip, C, h, w, B, cvdt):
         assert bool((base[..., w:] == 5.0).all())
 
 
-def test_fp16_forward_is_bit_identical_with_either_form_of_k1(monkeypatch):
-    """S2M2_K1_STREAM=1 (opt-in, fp16): K9 writes the normalised tokens in fragment order and K1 runs its streaming form; off: row-major
-    tokens and the LDS form.  Same operands, same MFMA chains -> the same cost volume and therefore the same forward, bit for bit
+@pytest.mark.parametrize("C,h,w,B,cvdt", [(128, 3, 304, 1, torch.float16), (128, 2, 160, 2, torch.float16), (64, 2, 40, 1, torch.float16),
+                                          (128, 2, 8, 1, torch.float16), (128, 1, 608, 2, torch.float16), (128, 2, 72, 1, torch.float32),
+                                          (128, 1, 1200, 1, torch.float16), (64, 3, 392, 1, torch.float16)])
+def test_corr_hybrid_equals_corr_bit_for_bit(hip, C, h, w, B, cvdt):
+    """s2m2_corr_hybrid (left tokens in fragment order straight into the MFMA operand registers, right tokens row-major through LDS):
+    same operands, same MFMA chains as s2m2_corr -> the same volume BIT FOR BIT, incl. ragged tiles, several blocks per row, bands."""
+    g = torch.Generator(device="cuda").manual_seed(C + w + 1)
+    tok = torch.nn.functional.layer_norm(torch.randn(2 * B, h, w, C, device="cuda", generator=g) * 1.5 + 0.2, (C,)).half()
+    hy = hip.HybridTokens.from_rows(tok)
+    assert torch.equal(hy.to_rows(), tok)
+    ref = hip.corr(tok, cv_dtype=cvdt)
+    cv = hip.corr_hybrid(hy, cv_dtype=cvdt)
+    assert cv.shape == ref.shape and cv.stride(2) == ref.stride(2)
+    assert torch.equal(cv, ref)
+    dense = torch.empty((B, h, w, w), device="cuda", dtype=cvdt)
+    hip.corr_hybrid(hy, out=dense)
+    assert torch.equal(dense, ref)
+    banded = torch.full_like(dense, -777.0)
+    refb = torch.full_like(dense, -777.0)
+    hip.corr_hybrid(hy, out=banded, band=11)
+    hip.corr(tok, out=refb, band=11)
+    assert torch.equal(banded, refb)
+    with pytest.raises(RuntimeError, match="C=256"):
+        t = hip.HybridTokens(1, 1, 32, 256, "cuda")
+        hip.corr_hybrid(t)
+
+
+@pytest.mark.parametrize("k1env", ["S2M2_K1_STREAM", "S2M2_K1_HYBRID"])
+def test_fp16_forward_is_bit_identical_with_either_form_of_k1(monkeypatch, k1env):
+    """S2M2_K1_STREAM=1 (opt-in, fp16): K9 writes the normalised tokens in fragment order and K1 runs its streaming form;
+    S2M2_K1_HYBRID=1: only the left tokens in fragment order, K1 keeps its LDS right row; off: row-major tokens and the LDS form.  Same operands, same MFMA chains -> the same cost volume and therefore the same forward, bit for bit
     (eager and hipGraph replay)."""
     from s2m2_amd import hip as H
     from s2m2_amd.model import S2M2
@@ -435,14 +463,15 @@ def test_fp16_forward_is_bit_identical_with_either_form_of_k1(monkeypatch):
     l, r = l.cuda(), r.cuda()
     outs = []
     for stream in ("1", "0"):
-        monkeypatch.setenv("S2M2_K1_STREAM", stream)
+        monkeypatch.setenv(k1env, stream)
         m = S2M2(128, 1, 1, use_positivity=True, refine_iter=2)
         m.load_state_dict(sd, strict=True)
         m = m.cuda().eval()
         with torch.autocast("cuda", dtype=torch.float16):
             cap = {}
             m(l, r, capture=cap)
-            assert isinstance(m.engine(torch.float16)._tokens_normed, H.TiledTokens) == (stream == "1")
+            kind = H.TiledTokens if k1env == "S2M2_K1_STREAM" else H.HybridTokens
+            assert isinstance(m.engine(torch.float16)._tokens_normed, kind) == (stream == "1")
             a = [t.clone() for t in m(l, r)]
             b = [t.clone() for t in m(l, r)]                       # graph replay
         assert all(torch.equal(x, y) for x, y in zip(a, b))
