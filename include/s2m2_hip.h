@@ -262,8 +262,16 @@ typedef struct s2m2_chain_desc {
        group g of every image is processed on XCD g (blocks are dealt to XCDs round robin by the hardware), so that a consumer which
        places its work the same way -- s2m2_corr: image row y on XCD y / (h / 8) -- reads these rows from the L2 that holds them. */
     long long xcd_group_rows;
+    /* 1: weight[s] and fan_weight are in MFMA-FRAGMENT order instead of row-major -- the same C x C (nfan*C x C) fp16 values, with the
+       16-byte piece (cout o, channels 8q .. 8q+7) at 16-byte slot ((o/32) * (C/16) + q/2) * 64 + (q%2) * 32 + o%32 (per fan-out layer for
+       fan_weight) -- and the launch runs the DIRECT form: a wave's weight fragments go from global memory straight into its MFMA operand
+       registers, one whole stage ahead, no weight tile in LDS and no block barrier inside a stage.  For SHORT row counts (the 1/32 .. 1/8
+       pyramid levels: a block lives for the latency of its weight stream, not for its arithmetic).  fp16, C = 128 / 256: ask
+       s2m2_mlp_chain_frag_supported.  Same arithmetic and rounding points as the row-major form. */
+    int weight_frag;
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);
+int s2m2_mlp_chain_frag_supported(int C, int dtype);
 /* nstage = 0 with nfan > 0 ("fan-out only": the nfan layers read the x rows themselves -- a Q | K | V projection as ONE pass over the rows,
  * the stacked weight resident in LDS): 1 where the library has that form (fp16, C = 128, nfan 1..3), else 0 */
 int s2m2_mlp_fan_supported(int C, int nfan, int dtype);

@@ -62,7 +62,11 @@ struct ChainArgs {
 template <typename T, int C_, int BM_, int NST_, int NW_, int WP_ = 4>
 struct ChainCfg {
     static constexpr int C = C_, BM = BM_, NST = NST_, NW = NW_, NT = 64 * NW_;
-    static constexpr int WP = WP_;                        // 16-byte pieces per weight row and chunk: 4 (64-byte K chunks) or 8 (128-byte)
+    // WP_ = 0: DIRECT form (fp16, weights in MFMA-fragment order, s2m2_chain_desc.weight_frag): a wave's weight fragments go from global
+    // memory straight into its MFMA operand registers -- no weight tile in LDS, no block barrier inside a stage's K loop; a "chunk" is one
+    // k16 step and a whole stage (C / 16 fragments per 32-cout tile) is in flight while the previous stage computes.
+    static constexpr bool DIRECT = WP_ == 0;
+    static constexpr int WP = DIRECT ? 2 : WP_;           // 16-byte pieces per weight row and chunk: 4 (64-byte K chunks) or 8 (128-byte)
     static constexpr int VEC = 16 / sizeof(T);
     static constexpr int BK = WP * VEC;                   // K elements per chunk
     static constexpr int RS = BK + VEC;                   // weight tile row stride in LDS (80 bytes: conflict-free b128 reads)
@@ -74,15 +78,16 @@ struct ChainCfg {
 #ifndef S2M2_CHAIN_DEPTH8
 #define S2M2_CHAIN_DEPTH8 1
 #endif
-    static constexpr int D = WP == 8 ? 2 : (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;   // weight chunks in flight
+    static constexpr int D = DIRECT ? CPS : WP == 8 ? 2 : (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;   // weight chunks in flight
     static constexpr int WROWS = NT / WP;                 // weight rows covered by one pass of the loader threads (WP pieces per row)
-    static constexpr int B_IT = C / WROWS;                // 16-byte weight pieces per thread and chunk
+    static constexpr int B_IT = DIRECT ? WN / 32 : C / WROWS;   // 16-byte weight pieces per thread and chunk (direct: one per 32-cout tile)
     static constexpr int PPR = C / VEC;                   // 16-byte pieces per activation row
     static constexpr int X_IT = BM * PPR / NT;            // activation pieces per thread
     static constexpr size_t A_BYTES = (size_t)BM * ARS * sizeof(T);
-    static constexpr size_t W_BYTES = (size_t)C * RS * sizeof(T);
+    static constexpr size_t W_BYTES = DIRECT ? 0 : (size_t)C * RS * sizeof(T);
     static constexpr size_t LDS_BYTES = 2 * A_BYTES + 2 * W_BYTES;
     static_assert(C % 128 == 0 && CPS % D == 0 && (BM * PPR) % NT == 0 && BM % 32 == 0 && WN % 32 == 0 && C % WROWS == 0, "unsupported chain tile");
+    static_assert(!DIRECT || (sizeof(T) == 2 && D * B_IT <= 24), "direct chain: fp16, at most 24 fragments (96 registers) in flight");
     static_assert(LDS_BYTES <= 160 * 1024, "chain tile does not fit the 160 KB LDS");
 };
 
@@ -98,6 +103,8 @@ struct ChainStream {
         wf = static_cast<const T*>(p.fan_w);
         lrow = tid / CFG::WP; pc = tid % CFG::WP;
         off = lrow * CFG::C + pc * CFG::VEC;
+        // direct form: the fragment of 32-cout tile t = wn * NTL + jn and k16 step ch is 64 lanes x 16 bytes at 16-byte slot (t * C/16 + ch) * 64 + lane
+        if (CFG::DIRECT) off = (((tid >> 6) * CFG::NTL * CFG::CPS) * 64 + (tid & 63)) * CFG::VEC;
     }
     __device__ __forceinline__ void fetch(int j, int SLOT) {                  // j is block-uniform; SLOT is static after unrolling
         const int st = j / CFG::CPS, ch = j - st * CFG::CPS;
@@ -105,9 +112,21 @@ struct ChainStream {
         const long long d1 = (const char*)w1 - (const char*)w0, d2 = (const char*)w2 - (const char*)w1;
         const T* wp = reinterpret_cast<const T*>((const char*)w0 + ((st >= 1 ? d1 : 0) + (st >= 2 ? d2 : 0)));
         if (st >= CFG::NST) wp = wf + (size_t)(st - CFG::NST) * CFG::C * CFG::C;      // fan-out stages (block-uniform)
-        const T* q = wp + off + ch * CFG::BK;
+        if constexpr (CFG::DIRECT) {
+            const T* q = wp + off + ch * (64 * CFG::VEC);
 #pragma unroll
-        for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + (size_t)it * CFG::WROWS * CFG::C);
+            for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + it * (CFG::CPS * 64 * CFG::VEC));
+        } else {
+            const T* q = wp + off + ch * CFG::BK;
+#pragma unroll
+            for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + (size_t)it * CFG::WROWS * CFG::C);
+        }
+    }
+    // direct form: k16 step ch of the stage whose fragment-ordered weight starts at `base` (block-uniform)
+    __device__ __forceinline__ void fetch_direct(const T* base, int ch, int SLOT) {
+        const T* q = base + off + ch * (64 * CFG::VEC);
+#pragma unroll
+        for (int it = 0; it < CFG::B_IT; ++it) r[SLOT][it] = global_load16(q + it * (CFG::CPS * 64 * CFG::VEC));
     }
     __device__ __forceinline__ void stash(T* wb, int SLOT) const {
 #pragma unroll
@@ -172,6 +191,30 @@ struct ChainStage {
 
         const T* arow = Ain + (size_t)l31 * ARS + hi * 8;
         const int brow = (wn * CFG::WN + l31) * RS + hi * 8;
+        if constexpr (CFG::DIRECT) {
+            // no LDS weight tile, no barrier: step f multiplies the fragments of ring slot f (requested a whole stage ago), then refills the
+            // slot with the same step of the next stage (unconditionally -- after the last stage this stage's fragments are read again and
+            // never used: a branch around a load would cost a full `s_waitcnt vmcnt(0)`)
+            const T* nxt = S + 1 < CFG::NST ? static_cast<const T*>(p.w[S + 1 < CFG::NST ? S + 1 : S])
+                                            : (p.nfan > 0 ? static_cast<const T*>(p.fan_w) : static_cast<const T*>(p.w[S]));
+#pragma unroll
+            for (int f = 0; f < D; ++f) {
+                Frag<T> xf[CFG::MT], wfr[CFG::NTL];
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], arow + (size_t)i * 32 * ARS + f * 16);
+#pragma unroll
+                for (int jn = 0; jn < CFG::NTL; ++jn) wfr[jn].v = __builtin_bit_cast(decltype(wfr[jn].v), ws.r[f][jn]);
+                if (ln_on) {
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < CFG::NTL; ++jn) mma32(acc[i][jn], wfr[jn], xf[i]);   // D[cout][row]
+                ws.fetch_direct(nxt, f, f);
+            }
+        } else
 #pragma unroll 1
         for (int c0 = 0; c0 < CPS; c0 += D) {
 #pragma unroll
@@ -203,6 +246,9 @@ struct ChainStage {
             }
         }
 
+        // direct form: no barrier closed the K loop, and the last stage stages its tile IN PLACE (Aout == Ain): every wave must have read
+        // its last A fragment before the first one writes
+        if constexpr (CFG::DIRECT && LAST) __syncthreads();
         // ---- epilogue: bias / folded LayerNorm / activation in registers -> Aout[row][cout]
         if (ln_on) {
             LnRow ln[CFG::MT];
@@ -332,6 +378,26 @@ __device__ __forceinline__ void chain_fan(const ChainArgs& p, ChainStream<CFG, T
             ln_shift[i] = (sizeof(T) == 4 && ln_on) ? to_f32(Afin[(size_t)(i * 32 + l31) * ARS]) : 0.f;
         }
         const bool stats = ln_on && F == 0;
+        if constexpr (CFG::DIRECT) {
+            const T* nxt = static_cast<const T*>(p.fan_w) + (size_t)(F + 1 < p.nfan ? F + 1 : F) * C * C;
+#pragma unroll
+            for (int f = 0; f < D; ++f) {
+                Frag<T> xf[CFG::MT], wfr[CFG::NTL];
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], arow + (size_t)i * 32 * ARS + f * 16);
+#pragma unroll
+                for (int jn = 0; jn < CFG::NTL; ++jn) wfr[jn].v = __builtin_bit_cast(decltype(wfr[jn].v), ws.r[f][jn]);
+                if (stats) {
+#pragma unroll
+                    for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < CFG::NTL; ++jn) mma32(acc[i][jn], wfr[jn], xf[i]);
+                ws.fetch_direct(nxt, f, f);
+            }
+        } else
 #pragma unroll 1
         for (int c0 = 0; c0 < CPS; c0 += D) {
 #pragma unroll
@@ -407,7 +473,8 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     ChainStream<CFG, T> ws;
     ws.init(p, tid);
     // the first D chunks of the weight stream and the row tile are requested together
-    ws.fetch(0, 0);
+    if constexpr (CFG::DIRECT) ws.fetch_direct(static_cast<const T*>(p.w[0]), 0, 0);
+    else ws.fetch(0, 0);
     raw16_t xr[CFG::X_IT];
 #pragma unroll
     for (int it = 0; it < CFG::X_IT; ++it) {
@@ -418,8 +485,9 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     }
 #pragma unroll
     for (int f = 1; f < D; ++f)
-        if (f < (CFG::NST + p.nfan) * CFG::CPS) ws.fetch(f, f);
-    ws.stash(W0, 0);
+        if constexpr (CFG::DIRECT) ws.fetch_direct(static_cast<const T*>(p.w[0]), f, f);     // (D = CPS: the whole first stage)
+        else if (f < (CFG::NST + p.nfan) * CFG::CPS) ws.fetch(f, f);
+    if constexpr (!CFG::DIRECT) ws.stash(W0, 0);
 #pragma unroll
     for (int it = 0; it < CFG::X_IT; ++it) {
         const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
@@ -805,12 +873,16 @@ extern "C" int s2m2_mlp_chain_supported(int C, int dtype) {
     return 0;
 }
 
+extern "C" int s2m2_mlp_chain_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 256); }
+
 extern "C" int s2m2_mlp_fan_supported(int C, int nfan, int dtype) { return dtype == S2M2_F16 && C == 128 && nfan >= 1 && nfan <= 3; }
 
 extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "mlp_chain: null descriptor");
     S2M2_REQUIRE(d->x, "mlp_chain: null x");
+    S2M2_REQUIRE(d->weight_frag == 0 || (d->weight_frag == 1 && d->nstage > 0 && s2m2_mlp_chain_frag_supported(d->C, d->dtype)),
+                 "mlp_chain: weight_frag=%d needs nstage >= 1, fp16 and C = 128 / 256", d->weight_frag);
     if (d->nstage == 0) {
         // fan-out only: the nfan layers read the x rows themselves (weights-stationary form: fp16, C = 128, nfan 1..3) -- ask
         // s2m2_mlp_fan_supported first
@@ -893,6 +965,18 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     // S2M2_CHAIN_WS_MIN: smallest row count)
     static const bool ws_off = getenv("S2M2_CHAIN_WS") != nullptr && atoi(getenv("S2M2_CHAIN_WS")) == 0;
     static const long long ws_min = getenv("S2M2_CHAIN_WS_MIN") ? atoll(getenv("S2M2_CHAIN_WS_MIN")) : 32768;
+    if (d->weight_frag) {                                         // direct form: 32-row tiles, one wave per 32 couts
+        a.xcd_tiles = (d->xcd_group_rows > 0 && !xcd_off && d->xcd_group_rows % 32 == 0 && d->rows % (8LL * d->xcd_group_rows) == 0) ? (int)(d->xcd_group_rows / 32) : 0;
+        // 32-row tiles while they fit the chip in one round (C = 256: one block per CU, C = 128: three), else 64-row tiles (half the weight
+        // traffic per row); S2M2_CHAIN_DIRECT_BM = 32 / 64 forces one (tuning)
+        static const int force_bm = getenv("S2M2_CHAIN_DIRECT_BM") ? atoi(getenv("S2M2_CHAIN_DIRECT_BM")) : 0;
+        const bool tall = force_bm ? force_bm == 64 : d->rows > (d->C == 128 ? 24576 : 8192);
+        if (tall) {
+            a.xcd_tiles = a.xcd_tiles % 2 == 0 ? a.xcd_tiles / 2 : 0;
+            return d->C == 128 ? launch_chain_n<half_t, 128, 64, 4, 0>(a, d->nstage, st) : launch_chain_n<half_t, 256, 64, 8, 0>(a, d->nstage, st);
+        }
+        return d->C == 128 ? launch_chain_n<half_t, 128, 32, 4, 0>(a, d->nstage, st) : launch_chain_n<half_t, 256, 32, 8, 0>(a, d->nstage, st);
+    }
     if (d->dtype == S2M2_F16 && d->C == 128 && d->nfan == 0 && !ws_off && d->rows >= ws_min && !(force && *force)) {
         a.xcd_tiles = 0;
         if (d->nstage == 1) return launch_chain_ws<1>(a, st);

@@ -126,6 +126,13 @@ class Engine:
         # opt-in experiment (S2M2_K1_HYBRID=1, fp16, C 64 / 128): K9 writes the normalised LEFT tokens in fragment order and the right
         # tokens row-major; K1 (hip.corr_hybrid) keeps its LDS right row but loads its left operand straight into registers
         self.k1_hybrid = os.environ.get("S2M2_K1_HYBRID", "0") == "1"
+        # direct form of K9 for SHORT row counts (the attention blocks of the 1/32 .. 1/8 levels): weights in MFMA-fragment order, from
+        # global memory straight into the operand registers (hip.mlp_chain(frag=True)); S2M2_CHAIN_DIRECT=0: off,
+        # S2M2_CHAIN_DIRECT_MAX: largest row count that takes it; S2M2_CHAIN_DIRECT_QKV=0: without the next attention's Q|K|V as fan-out
+        self.chain_direct = os.environ.get("S2M2_CHAIN_DIRECT", "1") != "0"
+        self.chain_direct_max = int(os.environ.get("S2M2_CHAIN_DIRECT_MAX", "40000"))
+        self.chain_direct_qkv = os.environ.get("S2M2_CHAIN_DIRECT_QKV", "1") != "0"
+        self._wfrag = {}
         self._tokens_normed = None                               # Tensor (row-major), hip.TiledTokens or hip.HybridTokens
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -263,7 +270,9 @@ class Engine:
         c0, c2 = self.std(p + ".convs_1x.0"), self.std(p + ".convs_1x.2")
         chain = self.use_chain and self.chain_ok(z.shape[-1]) and c0[4] == z.shape[-1] and c2[4] == z.shape[-1]
         with self.fork():                                         # 1x1 branch in parallel with the first 3x3
-            if chain:
+            if chain and self.chain_direct and z.numel() // z.shape[-1] <= self.chain_direct_max and hip.mlp_chain_frag_supported(z.shape[-1], self.dtype):
+                u = b = hip.mlp_chain(z, [(self.wfrag(c0), c0[1], hip.ACT_RELU, None), (self.wfrag(c2), c2[1], hip.ACT_NONE, None)], frag=True)
+            elif chain:
                 u = b = hip.mlp_chain(z, [(c0[0], c0[1], hip.ACT_RELU, None), (c2[0], c2[1], hip.ACT_NONE, None)])
             else:
                 u = self.cconv(c0, [z], act=hip.ACT_RELU)
@@ -364,6 +373,14 @@ class Engine:
             self._wsum[wp.data_ptr()] = ws
         return ws
 
+    def wfrag(self, spec: Spec) -> Tensor:
+        """a packed 1x1 weight in the MFMA-fragment order of the direct K9 form (pack.chain_frag), permuted once per layer"""
+        wp = spec[0]
+        wf = self._wfrag.get(wp.data_ptr())
+        if wf is None:
+            wf = self._wfrag[wp.data_ptr()] = pack.chain_frag(wp)
+        return wf
+
     def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor, ln_out=None, next_attn: Optional[str] = None):
         """z' = z + proj(o);  z' + ffn.2(GELU(ffn.0(LayerNorm(z')))) (attentions.py:311-321,347-355): one K9 launch when the width
         is supported, else three K5 launches (pre-LN folded into the first FFN layer).  ln_out = (gamma, beta, eps): the K9 launch also
@@ -374,6 +391,17 @@ class Engine:
         proj, f0, f2 = self.std(pa + ".attn.proj"), self.std(pf + ".ffn.0"), self.std(pf + ".ffn.2")
         if self.use_chain and self.chain_ok(c):
             stages = [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)), (f2[0], f2[1], hip.ACT_NONE, None)]
+            if (self.chain_direct and ln_out is None and z.numel() // c <= self.chain_direct_max and self.fuse_ln
+                    and hip.mlp_chain_frag_supported(c, self.dtype)):
+                # short row counts: the launch lives for the latency of its weight stream -- fragments straight into registers, and the
+                # next attention's Q | K | V projection rides along as fan-out stages (one launch and one round trip of the rows less)
+                fstages = [(self.wfrag(sp), sp[1], act, ws) for sp, (_, _, act, ws) in zip((proj, f0, f2), stages)]
+                if next_attn is not None and self.chain_direct_qkv:
+                    qs = self.qkv_spec(next_attn)
+                    if qs[2] == 1 and qs[3] == 1 and qs[4] == 3 * c:
+                        out, qkv = hip.mlp_chain(o, fstages, res=z, res_stage=0, carry=True, fan=(self.wfrag(qs), qs[1], self.wsum(qs)), frag=True)
+                        return out, qkv
+                return hip.mlp_chain(o, fstages, res=z, res_stage=0, carry=True, frag=True), None
             if next_attn is not None and self.fuse_qkv and self.fuse_ln and ln_out is None:
                 qs = self.qkv_spec(next_attn)
                 if qs[2] == 1 and qs[3] == 1 and qs[4] == 3 * c:

@@ -42,7 +42,7 @@ class ChainDesc(ctypes.Structure):
                 ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
                 ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float),
                 ("ln_out_tile_w", _i), ("ln_out_tile_rows", _ll), ("ln_out_rows", _vp), ("fan_weight", _vp), ("fan_bias", _vp), ("fan_ln_wsum", _vp), ("fan_out", _vp), ("fan_out_stride", _ll),
-                ("nfan", _i), ("xcd_group_rows", _ll)]
+                ("nfan", _i), ("xcd_group_rows", _ll), ("weight_frag", _i)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -66,6 +66,7 @@ SIGNATURES = {
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
     "s2m2_mlp_chain_supported": (_i, [_i, _i]),
+    "s2m2_mlp_chain_frag_supported": (_i, [_i, _i]),
     "s2m2_mlp_fan_supported": (_i, [_i, _i, _i]),
     "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
     "s2m2_feature_fusion_supported": (_i, [_i, _i]),
@@ -474,6 +475,11 @@ def mlp_fan(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
     return out
 
 
+def mlp_chain_frag_supported(C: int, dtype: torch.dtype) -> bool:
+    """the direct form of mlp_chain (weights in MFMA-fragment order, pack.chain_frag) exists for this width"""
+    return bool(load().s2m2_mlp_chain_frag_supported(C, _DT[dtype]))
+
+
 def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
     """the optional LayerNorm output of mlp_chain needs a row of 16 / 32 / 64 16-byte pieces"""
     return mlp_chain_supported(C, dtype) and C * (2 if dtype == torch.float16 else 4) // 16 in (16, 32, 64)
@@ -481,7 +487,7 @@ def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
               ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0,
-              ln_out_tiled=False, fan=None):
+              ln_out_tiled=False, fan=None, frag: bool = False):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
     res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
@@ -491,6 +497,8 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
     ln_out_tiled="left": as a HybridTokens pair (left images in fragment order, right images row-major) for corr_hybrid.
     fan = (packed weight (n*C, C), fp32 bias (n*C) or None, ln_wsum fp32 (n*C) or None): n further C -> C layers on the OUTPUT rows
     (pre-LayerNorm folded in when ln_wsum is given), returned as one (..., n*C) tensor: the fused QKV projection of the next attention.
+    frag: every weight (stages and fan) is in MFMA-fragment order (pack.chain_frag) -> the direct form of the kernel, meant for short row
+    counts (mlp_chain_frag_supported).
     Return value: out, or a tuple (out[, normalised][, fan_out]) in that order."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_chain")
@@ -513,6 +521,7 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
         raise ValueError("mlp_chain: tensors must live on the GPU")
     d.res_stage, d.carry, d.ln_eps = res_stage, int(carry), ln_eps
     d.xcd_group_rows = int(xcd_group_rows)
+    d.weight_frag = int(bool(frag))
     if res_stage >= 0:
         if res is None or res.dtype != x.dtype or tuple(res.shape) != tuple(x.shape):
             raise ValueError("mlp_chain: res must match x")

@@ -89,6 +89,16 @@ def pack_conv_frag(w: torch.Tensor, dtype: torch.dtype, splits: Optional[Sequenc
     return t.reshape(cop, ntap * nchunk * FRAG_CH).to(dtype).contiguous()
 
 
+def chain_frag(wp: torch.Tensor) -> torch.Tensor:
+    """packed 1x1 weight (n*C, C) (pack_conv: row = cout, column = input channel) -> the MFMA-fragment order of s2m2_chain_desc.weight_frag,
+    per C x C layer [cout / 32][k16 step][lane][8] with lane l holding cout 32t + l % 32, channels 16*step + 8*(l // 32) + e.  Same
+    shape and values, permuted."""
+    rows, C = wp.shape
+    assert rows % C == 0 and C % 32 == 0, (rows, C)
+    t = wp.reshape(rows // C, C // 32, 32, C // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)       # (layer, tile, step, half, l % 32, e)
+    return t.contiguous().reshape(rows, C)
+
+
 def pack_bias(b: Optional[torch.Tensor], cout: int, cout_pad: Optional[int] = None) -> Optional[torch.Tensor]:
     if b is None:
         return None

@@ -241,3 +241,70 @@ def test_fan_only_weights_stationary(hip, shp, nfan, ln):
     assert float((q.float() - sep.float()).abs().max()) < 2 ** -7 * scale
     q2 = hip.mlp_fan(x, wp, None, wsum)                     # no bias
     assert float((q2.float() - (ref - bq)).abs().max()) < 4e-3 * scale
+
+
+# ---- direct form (s2m2_chain_desc.weight_frag: weights in MFMA-fragment order, straight into the operand registers) ------------------------
+def _frag(packed):
+    return [(pack.chain_frag(w), b, act, ws) for w, b, act, ws in packed]
+
+
+@pytest.mark.parametrize("C,shp,nst,res_stage,carry,ln_stage,acts,nfan,fan_ln", [
+    (256, (2, 32, 38), 3, 0, True, 1, (0, 1, 0), 3, True),          # the 1/32 attention block of the S model with the next Q|K|V
+    (256, (1, 64, 76), 3, 0, True, 1, (0, 1, 0), 0, False),
+    (128, (2, 20, 31), 3, 0, True, 1, (0, 1, 0), 3, True),          # ragged last tile
+    (128, (1, 128, 152), 2, -1, False, -1, (2, 0), 0, False),       # > 8192 rows: the row-major form runs 64-row tiles
+    (128, (1, 1, 1), 1, 0, False, 0, (1,), 1, False),
+    (256, (1, 5, 7), 2, 1, False, 0, (1, 2), 2, True),
+    (256, (2, 64, 76), 3, 0, True, 1, (0, 1, 0), 3, True),          # 304 blocks
+    (128, (2, 128, 152), 3, 0, True, 1, (0, 1, 0), 3, True),        # 1216 blocks
+])
+def test_chain_direct_form_equals_row_major_form_bit_for_bit(hip, C, shp, nst, res_stage, carry, ln_stage, acts, nfan, fan_ln):
+    """Same fp16 operands, same k16 order of every MFMA chain, same epilogues: the direct form (fragments from global memory into the operand
+    registers, no weight tile in LDS) must reproduce the row-major form BIT FOR BIT -- chain output and fan-out stages."""
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(3 * C + nst + nfan)
+    x = (torch.randn(*shp, C, device="cuda", generator=g) * 1.5).to(dtype)
+    res = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 1).to(dtype)
+    raw, packed = _make(C, nst, dtype, ln_stage, acts, 13 * C + nst)
+    kw = dict(res=res if res_stage >= 0 else None, res_stage=res_stage, carry=carry)
+    fan = fanf = None
+    if nfan:
+        wq = (torch.randn(nfan * C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+        wp = pack.pack_conv(wq, dtype)
+        bp = pack.pack_bias(torch.randn(nfan * C, device="cuda", generator=g) * 0.3, nfan * C)
+        ws = wp.float().sum(1).contiguous() if fan_ln else None
+        fan, fanf = (wp, bp, ws), (pack.chain_frag(wp), bp, ws)
+    a = hip.mlp_chain(x, packed, fan=fan, **kw)
+    a = a if nfan else (a,)
+    fpacked = _frag(packed)
+    for _ in range(6):                                              # (repeated: the form has no barrier inside a stage -- a race would show as a flaky mismatch)
+        b = hip.mlp_chain(x, fpacked, fan=fanf, frag=True, **kw)
+        b = b if nfan else (b,)
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            assert u.shape == v.shape and torch.equal(u, v)
+    ref = _ref(x, raw, res, res_stage, carry, dtype)
+    assert float((b[0].float() - ref).abs().max()) < 1.5e-2
+
+
+def test_chain_direct_form_layernorm_output_and_strided_rows(hip):
+    C, dtype = 128, torch.float16
+    g = torch.Generator(device="cuda").manual_seed(17)
+    wide = (torch.randn(2, 24, 40, 3 * C, device="cuda", generator=g)).to(dtype)
+    o = wide[..., C:2 * C]                                          # row stride 3C
+    z = torch.randn(2, 24, 40, C, device="cuda", generator=g).to(dtype)
+    raw, packed = _make(C, 3, dtype, 1, (0, 1, 0), 23)
+    gam = 1 + 0.1 * torch.randn(C, device="cuda", generator=g)
+    bet = 0.05 * torch.randn(C, device="cuda", generator=g)
+    y0, n0 = hip.mlp_chain(o, packed, res=z, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5))
+    y1, n1 = hip.mlp_chain(o, _frag(packed), res=z, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), frag=True)
+    assert torch.equal(y0, y1) and torch.equal(n0, n1)
+
+
+def test_chain_direct_form_rejects_unsupported(hip):
+    assert hip.mlp_chain_frag_supported(128, torch.float16) and hip.mlp_chain_frag_supported(256, torch.float16)
+    assert not hip.mlp_chain_frag_supported(384, torch.float16) and not hip.mlp_chain_frag_supported(128, torch.float32)
+    x = torch.randn(4, 384, device="cuda").half()
+    w = torch.randn(384, 384, device="cuda").half()
+    with pytest.raises(RuntimeError, match="weight_frag"):
+        hip.mlp_chain(x, [(w, None, 0, None)], frag=True)

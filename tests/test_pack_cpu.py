@@ -54,3 +54,13 @@ def test_transposed_conv_packings():
     z = torch.einsum("rk,nkyx->nryx", g, xin).reshape(1, 2, 2, 8, 3, 4)          # rows ordered (dy, dx, c')
     z = z.permute(0, 3, 4, 1, 5, 2).reshape(1, 8, 6, 8)[:, :5]
     assert float((z - y).abs().max()) < 1e-5
+
+
+def test_chain_frag_is_a_permutation():
+    """pack.chain_frag: slot ((o/32) * (C/16) + q/2) * 64 + (q%2) * 32 + o%32 holds the 16-byte piece (cout o, channels 8q .. 8q+7)"""
+    C = 128
+    w = torch.arange(2 * C * C, dtype=torch.float32).reshape(2 * C, C)
+    f = pack.chain_frag(w).reshape(2, C * C // 8, 8)
+    for layer, o, q in ((0, 0, 0), (0, 33, 5), (1, 127, 15), (1, 64, 2)):
+        slot = ((o // 32) * (C // 16) + q // 2) * 64 + (q % 2) * 32 + o % 32
+        assert torch.equal(f[layer, slot], w[layer * C + o, 8 * q:8 * q + 8])
