@@ -292,6 +292,18 @@ int s2m2_feature_fusion_supported(int C, int dtype);
 int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
                         long long rows, int C, const void* w1, const float* b1, const void* w2, const float* bg, const float* bf,
                         int z1_coarse_h, int z1_coarse_w, int dtype, void* stream);
+/*
+ * K10, direct form (fp16, C = 128 / 256: ask s2m2_feature_fusion_frag_supported) for SHORT row counts: the same block, with the weights of
+ *   both layers as ONE stream of 1 KB MFMA fragments per 32-cout tile, in the order the kernel consumes them, read from global memory
+ *   straight into the operand registers (no weight tile in LDS, 6 block barriers per block instead of one per 64-byte K chunk).
+ *   w_stream: 9*C*C fp16 values; fragment j of cout tile t at 16-byte slot (t * 9C/16 + j) * 64 + lane, lane l holding 8 consecutive K
+ *   elements (k16 step, half l/32) of row 32t + l%32 of:  for slice s = 0, 1, 2:  w1 rows [sC, sC + C) (k16 steps 0 .. 2C/16),  then
+ *   w2 = [Wg | Wf] columns [sC, sC + C) (steps 0 .. C/16)  -- w1, w2 as in s2m2_feature_fusion.  Same arithmetic and rounding points.
+ */
+int s2m2_feature_fusion_frag_supported(int C, int dtype);
+int s2m2_feature_fusion_frag(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+                             long long rows, int C, const void* w_stream, const float* b1, const float* bg, const float* bf,
+                             int z1_coarse_h, int z1_coarse_w, int dtype, void* stream);
 
 /*
  * [A2,A3] pre-norm LayerNorm without affine over the channel axis (attentions.py:117,148,182,213,243; eps 1e-5, biased var).

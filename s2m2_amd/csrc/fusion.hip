@@ -17,6 +17,7 @@
 #include "common.h"
 #include "epilogue.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace s2m2 {
 
@@ -96,21 +97,10 @@ template <typename T> struct Quad;                                  // 4 consecu
 template <> struct Quad<half_t> { half4_t v; };
 template <> struct Quad<float> { float4_t v; };
 
+// the z0 | z1 row tile of a block: 16-byte pieces requested into registers (z1 optionally through the x2 bilinear resampling)
 template <typename CFG, typename T>
-__global__ __launch_bounds__(CFG::NT) void feature_fusion_kernel(FusionArgs p) {
-    constexpr int C = CFG::C, BM = CFG::BM, VEC = CFG::VEC, BK = CFG::BK, RS = CFG::RS, XRS = CFG::XRS, HRS = CFG::HRS, D = CFG::D;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* X = reinterpret_cast<T*>(smem);                                                   // [BM][2C + pad]: z0 | z1
-    T* H = reinterpret_cast<T*>(smem + CFG::X_BYTES);                                    // [BM][C + pad]: one slice of h; staging tile at the end
-    T* W0 = reinterpret_cast<T*>(smem + CFG::X_BYTES + CFG::H_BYTES);
-    T* W1 = reinterpret_cast<T*>(smem + CFG::X_BYTES + CFG::H_BYTES + CFG::W_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * BM;
-
-    FusionStream<CFG, T> ws;
-    ws.init(p, tid);
-    ws.fetch(0, 0);
-    raw16_t xr0[CFG::X_IT], xr1[CFG::X_IT];
+__device__ __forceinline__ void fusion_request_rows(const FusionArgs& p, long long m0, int tid, raw16_t (&xr0)[CFG::X_IT], raw16_t (&xr1)[CFG::X_IT]) {
+    constexpr int VEC = CFG::VEC;
 #pragma unroll
     for (int it = 0; it < CFG::X_IT; ++it) {
         const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
@@ -144,15 +134,92 @@ __global__ __launch_bounds__(CFG::NT) void feature_fusion_kernel(FusionArgs p) {
             xr1[it] = __builtin_bit_cast(raw16_t, o);
         }
     }
-#pragma unroll
-    for (int f = 1; f < D; ++f) ws.fetch(f, f);
-    ws.stash(W0, 0);
+}
+template <typename CFG, typename T>
+__device__ __forceinline__ void fusion_stash_rows(T* X, int tid, const raw16_t (&xr0)[CFG::X_IT], const raw16_t (&xr1)[CFG::X_IT]) {
 #pragma unroll
     for (int it = 0; it < CFG::X_IT; ++it) {
         const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
-        *reinterpret_cast<raw16_t*>(X + (size_t)row * XRS + pcx * VEC) = xr0[it];
-        *reinterpret_cast<raw16_t*>(X + (size_t)row * XRS + C + pcx * VEC) = xr1[it];
+        *reinterpret_cast<raw16_t*>(X + (size_t)row * CFG::XRS + pcx * CFG::VEC) = xr0[it];
+        *reinterpret_cast<raw16_t*>(X + (size_t)row * CFG::XRS + CFG::C + pcx * CFG::VEC) = xr1[it];
     }
+}
+
+// out = round(round(accf + bf) + round(g * z0 + (1 - g) * z1)), g = clamp(round(sigmoid(accg + bg)), .01, .99): staged through H, stored coalesced
+template <typename CFG, typename T>
+__device__ __forceinline__ void fusion_mix_store(const FusionArgs& p, const float16_t (&accg)[CFG::MT][CFG::NTL], const float16_t (&accf)[CFG::MT][CFG::NTL],
+                                                 const T* X, T* H, int tid, long long m0, const float* cv_lds = nullptr) {
+    constexpr int C = CFG::C, VEC = CFG::VEC, XRS = CFG::XRS, HRS = CFG::HRS;
+    const int lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    // ---- epilogue: out = round(round(accf + bf) + round(g * z0 + (1 - g) * z1)), g = clamp(round(sigmoid(accg + bg)), .01, .99)
+    CoutRegs<CFG> bg, bf;
+    if (cv_lds != nullptr) {                                         // (direct form: the per-cout vectors were copied to LDS by the prologue)
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = wn * CFG::WN + j * 32 + 8 * g + 4 * hi;
+                bg.v[j][g] = *reinterpret_cast<const raw16_t*>(cv_lds + 3 * C + co);
+                bf.v[j][g] = *reinterpret_cast<const raw16_t*>(cv_lds + 4 * C + co);
+            }
+    } else {
+        bg.load(p.bg, p.zero, C, 0, wn, lane);
+        bf.load(p.bf, p.zero, C, 0, wn, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < CFG::MT; ++i) {
+        const int row = i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < CFG::NTL; ++j) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int cl = wn * CFG::WN + j * 32 + 8 * g4 + 4 * hi;
+                const Quad<T> q0 = *reinterpret_cast<const Quad<T>*>(X + (size_t)row * XRS + cl);
+                const Quad<T> q1 = *reinterpret_cast<const Quad<T>*>(X + (size_t)row * XRS + C + cl);
+                Quad<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gate = to_f32(from_f32<T>(activate<S2M2_ACT_SIGMOID>(accg[i][j][4 * g4 + e] + bg.v[j][g4][e])));
+                    const float gc = fminf(fmaxf(gate, 0.01f), 0.99f);
+                    const float mix = to_f32(from_f32<T>(gc * to_f32(q0.v[e]) + (1.0f - gc) * to_f32(q1.v[e])));
+                    const float fus = to_f32(from_f32<T>(accf[i][j][4 * g4 + e] + bf.v[j][g4][e]));
+                    o.v[e] = from_f32<T>(fus + mix);
+                }
+                *reinterpret_cast<Quad<T>*>(H + (size_t)row * HRS + cl) = o;
+            }
+        }
+    }
+    __syncthreads();
+    T* outp = static_cast<T*>(p.out);
+#pragma unroll
+    for (int it = 0; it < CFG::X_IT; ++it) {
+        const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
+        const long long m = m0 + row;
+        if (m < p.rows)
+            *reinterpret_cast<raw16_t*>(outp + m * p.out_stride + pcx * VEC) = *reinterpret_cast<const raw16_t*>(H + (size_t)row * HRS + pcx * VEC);
+    }
+}
+
+template <typename CFG, typename T>
+__global__ __launch_bounds__(CFG::NT) void feature_fusion_kernel(FusionArgs p) {
+    constexpr int C = CFG::C, BM = CFG::BM, BK = CFG::BK, RS = CFG::RS, XRS = CFG::XRS, HRS = CFG::HRS, D = CFG::D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* X = reinterpret_cast<T*>(smem);                                                   // [BM][2C + pad]: z0 | z1
+    T* H = reinterpret_cast<T*>(smem + CFG::X_BYTES);                                    // [BM][C + pad]: one slice of h; staging tile at the end
+    T* W0 = reinterpret_cast<T*>(smem + CFG::X_BYTES + CFG::H_BYTES);
+    T* W1 = reinterpret_cast<T*>(smem + CFG::X_BYTES + CFG::H_BYTES + CFG::W_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * BM;
+
+    FusionStream<CFG, T> ws;
+    ws.init(p, tid);
+    ws.fetch(0, 0);
+    raw16_t xr0[CFG::X_IT], xr1[CFG::X_IT];
+    fusion_request_rows<CFG, T>(p, m0, tid, xr0, xr1);
+#pragma unroll
+    for (int f = 1; f < D; ++f) ws.fetch(f, f);
+    ws.stash(W0, 0);
+    fusion_stash_rows<CFG, T>(X, tid, xr0, xr1);
     __syncthreads();
 
     float16_t accg[CFG::MT][CFG::NTL], accf[CFG::MT][CFG::NTL];                          // second layer: gate / fusion
@@ -222,42 +289,140 @@ __global__ __launch_bounds__(CFG::NT) void feature_fusion_kernel(FusionArgs p) {
         // (the trailing barrier of the last chunk: every wave is done with the h slice before the next one overwrites it)
     }
 
-    // ---- epilogue: out = round(round(accf + bf) + round(g * z0 + (1 - g) * z1)), g = clamp(round(sigmoid(accg + bg)), .01, .99)
-    CoutRegs<CFG> bg, bf;
-    bg.load(p.bg, p.zero, C, 0, wn, lane);
-    bf.load(p.bf, p.zero, C, 0, wn, lane);
-#pragma unroll
-    for (int i = 0; i < CFG::MT; ++i) {
-        const int row = i * 32 + l31;
-#pragma unroll
-        for (int j = 0; j < CFG::NTL; ++j) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int cl = wn * CFG::WN + j * 32 + 8 * g4 + 4 * hi;
-                const Quad<T> q0 = *reinterpret_cast<const Quad<T>*>(X + (size_t)row * XRS + cl);
-                const Quad<T> q1 = *reinterpret_cast<const Quad<T>*>(X + (size_t)row * XRS + C + cl);
-                Quad<T> o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float gate = to_f32(from_f32<T>(activate<S2M2_ACT_SIGMOID>(accg[i][j][4 * g4 + e] + bg.v[j][g4][e])));
-                    const float gc = fminf(fmaxf(gate, 0.01f), 0.99f);
-                    const float mix = to_f32(from_f32<T>(gc * to_f32(q0.v[e]) + (1.0f - gc) * to_f32(q1.v[e])));
-                    const float fus = to_f32(from_f32<T>(accf[i][j][4 * g4 + e] + bf.v[j][g4][e]));
-                    o.v[e] = from_f32<T>(fus + mix);
-                }
-                *reinterpret_cast<Quad<T>*>(H + (size_t)row * HRS + cl) = o;
-            }
-        }
+    fusion_mix_store<CFG, T>(p, accg, accf, X, H, tid, m0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K10, DIRECT form (fp16; weights in MFMA-fragment order, s2m2_feature_fusion_frag).  The kernel above stages every 64 / 128-byte K chunk
+// of the weights through LDS behind a block barrier (36 - 72 barriers per block); on the short row counts of the coarse pyramid levels a
+// block lives for the latency of that chain.  Here a wave owns 32 couts and reads ITS weight fragments -- one contiguous stream of
+// 1 KB fragments in exactly the order it consumes them, packed once on the host (pack.fusion_frag) -- from global memory straight into
+// MFMA operand registers, D fragments ahead; block barriers only where the h slice changes hands (6 per block).  Same arithmetic,
+// k16 order and rounding points as the kernel above (tests/test_hip_fusion.py: bit-identical).
+//   stream of wave tile t:  for slice s = 0, 1, 2:  W1[sC + 32t .. + 32, k16 steps 0 .. 2C/16),  then  [Wg | Wf][32t .. + 32, steps sC/16 .. (s+1)C/16)
+// ---------------------------------------------------------------------------------------------------------------
+// f(integral_constant<int, J0>), f(integral_constant<int, J0 + 1>), ... N times: a loop whose index is a constant expression inside the body
+template <int J0, int N, typename F>
+__device__ __forceinline__ void static_steps(F&& f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, J0>{});
+        static_steps<J0 + 1, N - 1>(f);
     }
+}
+
+template <int C_, int BM_, int NW_, int D_>
+struct FusionDirectCfg {
+    static constexpr int C = C_, BM = BM_, NW = NW_, NT = 64 * NW_, D = D_;
+    static constexpr int VEC = 8;
+    static constexpr int XRS = 2 * C + VEC, HRS = C + VEC, CRS = HRS;
+    static constexpr int WM = BM, MT = BM / 32, WN = C / NW, NTL = WN / 32;
+    static constexpr int KS0 = 2 * C / 16, KS1 = C / 16, PER = KS0 + KS1, TOTAL = 3 * PER;    // k16 steps per slice: first layer, second layer
+    static constexpr int PPR = C / VEC, X_IT = BM * PPR / NT;
+    static constexpr size_t X_BYTES = (size_t)BM * XRS * sizeof(half_t);
+    static constexpr size_t H_BYTES = (size_t)BM * HRS * sizeof(half_t);
+    static constexpr size_t CV_BYTES = (size_t)5 * C * sizeof(float);                  // b1 (3C) | bg (C) | bf (C)
+    static constexpr size_t LDS_BYTES = X_BYTES + H_BYTES + CV_BYTES;
+    static_assert(NTL == 1 && BM % 32 == 0 && (BM * PPR) % NT == 0 && D <= PER && D * 4 <= 128 && 5 * C / 4 <= NT * 2, "unsupported direct fusion tile");
+};
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::NT) void feature_fusion_direct_kernel(FusionArgs p) {
+    using T = half_t;
+    constexpr int C = CFG::C, BM = CFG::BM, XRS = CFG::XRS, HRS = CFG::HRS, D = CFG::D;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* X = reinterpret_cast<T*>(smem);                              // [BM][2C + pad]: z0 | z1
+    T* H = reinterpret_cast<T*>(smem + CFG::X_BYTES);               // [BM][C + pad]: one slice of h; staging tile at the end
+    const int tid = threadIdx.x, lane = tid & 63, wn = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * BM;
+
+    // this wave's fragment stream (p.w1: the whole stream, w2 unused): position j at 16-byte slot (wn * TOTAL + j) * 64 + lane
+    const raw16_t* wq = reinterpret_cast<const raw16_t*>(p.w1) + (size_t)wn * CFG::TOTAL * 64 + lane;
+    // per-cout fp32 vectors -> LDS first (a load requested inside the K loops would be waited for with the whole ring ahead of it: loads
+    // return in order), then the row tile, then the first D fragments
+    float* Cv = reinterpret_cast<float*>(smem + CFG::X_BYTES + CFG::H_BYTES);            // b1 (3C) | bg (C) | bf (C)
+    raw16_t cvr[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = tid + CFG::NT * it;                           // 16-byte piece of the 5C floats
+        const float* src = q < 3 * C / 4 ? p.b1 + 4 * q : q < 4 * C / 4 ? p.bg + 4 * q - 3 * C : q < 5 * C / 4 ? p.bf + 4 * q - 4 * C
+                                                                                                                 : static_cast<const float*>(p.zero);
+        cvr[it] = global_load16(src);
+    }
+    raw16_t xr0[CFG::X_IT], xr1[CFG::X_IT];
+    fusion_request_rows<CFG, T>(p, m0, tid, xr0, xr1);
+    // the ring: untracked loads + counted waits (common.h: the compiler's own load tracking sinks the refills towards their use and the
+    // prefetch distance collapses to one or two fragments -- seen in the ISA).  Fragment j is request number j; before step j at most
+    // min(D, TOTAL - j) - 1 younger requests may be in flight.
+    raw16_t ring[D];
+#pragma unroll
+    for (int f = 0; f < D; ++f) global_load16_async(ring[f], wq + f * 64);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = tid + CFG::NT * it;
+        if (q < 5 * C / 4) *reinterpret_cast<raw16_t*>(Cv + 4 * q) = cvr[it];
+    }
+    fusion_stash_rows<CFG, T>(X, tid, xr0, xr1);
     __syncthreads();
-    T* outp = static_cast<T*>(p.out);
+
+    float16_t accg[CFG::MT][1], accf[CFG::MT][1];                    // second layer: gate / fusion
 #pragma unroll
-    for (int it = 0; it < CFG::X_IT; ++it) {
-        const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
-        const long long m = m0 + row;
-        if (m < p.rows)
-            *reinterpret_cast<raw16_t*>(outp + m * p.out_stride + pcx * VEC) = *reinterpret_cast<const raw16_t*>(H + (size_t)row * HRS + pcx * VEC);
-    }
+    for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accg[i][0][r] = accf[i][0][r] = 0.f;
+
+    // one k16 step at stream position J: acc += fragment(J) . A[:, 16 k .. 16 k + 16), then the ring slot is refilled with fragment J + D
+    auto step = [&](float16_t (&acc)[CFG::MT][1], const T* arow, int ars, auto jc) __attribute__((always_inline)) {
+        constexpr int J = decltype(jc)::value;
+        Frag<T> wf, xf[CFG::MT];
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], arow + (size_t)i * 32 * ars);
+        wait_vmcnt<(J + D <= CFG::TOTAL ? D : CFG::TOTAL - J) - 1>();
+        settle(ring[J % D]);
+        wf.v = __builtin_bit_cast(half8_t, ring[J % D]);
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i) mma32(acc[i][0], wf, xf[i]);
+        if constexpr (J + D < CFG::TOTAL) global_load16_async(ring[J % D], wq + (size_t)(J + D) * 64);
+    };
+
+    const T* xrow = X + (size_t)l31 * XRS + hi * 8;
+    const T* hrow = H + (size_t)l31 * HRS + hi * 8;
+    static_steps<0, 3>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        // ---- first layer, slice S: h[:, SC .. SC + C) = GELU(W1[SC .. SC + C, :] . z + b1)
+        CoutRegs<CFG> b1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b1.v[0][g] = *reinterpret_cast<const raw16_t*>(Cv + S * C + wn * CFG::WN + 8 * g + 4 * hi);
+        float16_t acc[CFG::MT][1];
+#pragma unroll
+        for (int i = 0; i < CFG::MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+        static_steps<0, CFG::KS0>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value;
+            step(acc, xrow + K * 16, XRS, std::integral_constant<int, S * CFG::PER + K>{});
+        });
+        if constexpr (S > 0) __syncthreads();                       // every wave has read the previous h slice
+        stage_tile<CFG, T, S2M2_ACT_GELU>(acc, H, b1, 1.0f, 0, wn, lane);
+        __syncthreads();
+        // ---- second layer, K range S: gate (S == 0) or fusion (S == 1, 2) accumulators += [Wg | Wf][:, SC .. SC + C) . h slice
+        static_steps<0, CFG::KS1>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int K = decltype(kc)::value;
+            if constexpr (S == 0) step(accg, hrow + K * 16, HRS, std::integral_constant<int, S * CFG::PER + CFG::KS0 + K>{});
+            else step(accf, hrow + K * 16, HRS, std::integral_constant<int, S * CFG::PER + CFG::KS0 + K>{});
+        });
+    });
+    __syncthreads();                                                // the last h slice has been read: H becomes the staging tile
+    fusion_mix_store<CFG, T>(p, accg, accf, X, H, tid, m0, Cv);
+}
+
+template <int C, int BM, int NW, int D>
+static int launch_fusion_direct(const FusionArgs& a, hipStream_t st) {
+    using CFG = FusionDirectCfg<C, BM, NW, D>;
+    auto kern = feature_fusion_direct_kernel<CFG>;
+    static size_t lds_granted[kMaxDevices] = {};
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "feature_fusion")) return 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((a.rows + BM - 1) / BM)), dim3(CFG::NT), CFG::LDS_BYTES, st, a);
+    return check_launch("feature_fusion");
 }
 
 template <typename T, int C, int BM, int NW, int WP = 4>
@@ -274,6 +439,33 @@ static int launch_fusion(const FusionArgs& a, hipStream_t st) {
 
 extern "C" int s2m2_feature_fusion_supported(int C, int dtype) {
     return (dtype == S2M2_F16 || dtype == S2M2_F32) && (C == 128 || C == 256);
+}
+
+extern "C" int s2m2_feature_fusion_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 256); }
+
+extern "C" int s2m2_feature_fusion_frag(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+                                        long long rows, int C, const void* w_stream, const float* b1, const float* bg, const float* bf,
+                                        int z1_coarse_h, int z1_coarse_w, int dtype, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(z0 && z1 && out && w_stream && b1 && bg && bf, "feature_fusion_frag: null pointer");
+    S2M2_REQUIRE(s2m2_feature_fusion_frag_supported(C, dtype), "feature_fusion_frag: C=%d dtype=%d is not supported (fp16, C = 128 or 256)", C, dtype);
+    S2M2_REQUIRE(rows > 0 && rows < (1LL << 31), "feature_fusion_frag: rows=%lld", rows);
+    S2M2_REQUIRE(z0_stride >= C && z1_stride >= C && out_stride >= C && z0_stride % 8 == 0 && z1_stride % 8 == 0 && out_stride % 8 == 0,
+                 "feature_fusion_frag: row strides must be multiples of 8 and at least C");
+    S2M2_REQUIRE((z1_coarse_h == 0 && z1_coarse_w == 0) || (z1_coarse_h > 0 && z1_coarse_w > 0 && rows % (4LL * z1_coarse_h * z1_coarse_w) == 0),
+                 "feature_fusion_frag: rows=%lld is not a whole number of (2*%d) x (2*%d) images", rows, z1_coarse_h, z1_coarse_w);
+    FusionArgs a;
+    a.z0 = z0; a.z1 = z1; a.out = out; a.z0_stride = z0_stride; a.z1_stride = z1_stride; a.out_stride = out_stride; a.rows = rows;
+    a.w1 = w_stream; a.w2 = nullptr; a.b1 = b1; a.bg = bg; a.bf = bf;
+    a.up_h = z1_coarse_h; a.up_w = z1_coarse_w;
+    a.zero = zero_page();
+    S2M2_REQUIRE(a.zero, "feature_fusion_frag: cannot allocate the zero page");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // 32-row tiles while one round of them fits the chip, else 64-row tiles (half the weight traffic per row); S2M2_FUSION_DIRECT_BM forces one
+    static const int force_bm = getenv("S2M2_FUSION_DIRECT_BM") ? atoi(getenv("S2M2_FUSION_DIRECT_BM")) : 0;
+    const bool tall = force_bm ? force_bm == 64 : rows > (C == 128 ? 24576 : 8192);
+    if (C == 128) return tall ? launch_fusion_direct<128, 64, 4, 12>(a, st) : launch_fusion_direct<128, 32, 4, 24>(a, st);
+    return tall ? launch_fusion_direct<256, 64, 8, 16>(a, st) : launch_fusion_direct<256, 32, 8, 24>(a, st);
 }
 
 extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,

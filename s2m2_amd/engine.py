@@ -133,6 +133,9 @@ class Engine:
         self.chain_direct_max = int(os.environ.get("S2M2_CHAIN_DIRECT_MAX", "40000"))
         self.chain_direct_qkv = os.environ.get("S2M2_CHAIN_DIRECT_QKV", "1") != "0"
         self._wfrag = {}
+        # the same for K10 (hip.feature_fusion(frag=True)): S2M2_FUSION_DIRECT=0: off, S2M2_FUSION_DIRECT_MAX: largest row count
+        self.fusion_direct = os.environ.get("S2M2_FUSION_DIRECT", "1") != "0"
+        self.fusion_direct_max = int(os.environ.get("S2M2_FUSION_DIRECT_MAX", str(1 << 30)))
         self._tokens_normed = None                               # Tensor (row-major), hip.TiledTokens or hip.HybridTokens
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -296,6 +299,18 @@ class Engine:
             ok = self._fusion_ok[c] = hip.feature_fusion_supported(c, self.dtype)
         return ok
 
+    def k10(self, p: str, z0: Tensor, z1: Tensor, first: Spec, z1_coarse: bool = False) -> Tensor:
+        """one K10 launch; short row counts take the direct form (weights as one fragment stream, permuted once per layer)"""
+        dual = self.dual_heads(p)
+        c = z0.shape[-1]
+        if self.fusion_direct and z0.numel() // c <= self.fusion_direct_max and hip.feature_fusion_frag_supported(c, self.dtype):
+            key = p + "|k10 fragment stream"
+            ws = self._packed.get(key)
+            if ws is None:
+                ws = self._packed[key] = pack.fusion_frag(first[0], dual[0])
+            return hip.feature_fusion(z0, z1, ws, first[1], None, dual[1], dual[2], z1_coarse=z1_coarse, frag=True)
+        return hip.feature_fusion(z0, z1, first[0], first[1], dual[0], dual[1], dual[2], z1_coarse=z1_coarse)
+
     def fusion_up(self, p: str, z0: Tensor, pu: str, xc: Tensor) -> Tensor:
         """fusion(z0, up_conv(xc)) of the decoders (unet.py:98-110, stacked_MRT.py:113-121): the 1x1 up_conv runs on the coarse grid
         (see up()) and K10 reads its output through the bilinear resampling -- no stand-alone K7 launch, no upsampled tensor."""
@@ -304,8 +319,7 @@ class Engine:
         first = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
         if (self.fuse_fusion and self.fuse_up and spec[2] == 1 and spec[3] == 1 and spec[4] == c and first[2] == 1 and first[3] == 1
                 and self.p[p + ".feature_gate.0.weight"].shape[0] == c and self.fusion_ok(c)):
-            dual = self.dual_heads(p)
-            return hip.feature_fusion(z0, self.cconv(spec, [xc]), first[0], first[1], dual[0], dual[1], dual[2], z1_coarse=True)
+            return self.k10(p, z0, self.cconv(spec, [xc]), first, z1_coarse=True)
         return self.fusion(p, z0, self.up(pu, xc))
 
     def fusion(self, p: str, z0: Tensor, z1: Tensor) -> Tensor:
@@ -315,8 +329,7 @@ class Engine:
         cg = self.p[p + ".feature_gate.0.weight"].shape[0]
         spec = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
         if self.fuse_fusion and spec[2] == 1 and spec[3] == 1 and cg == c and self.fusion_ok(c):
-            dual = self.dual_heads(p)                              # K10: the whole block in one launch, h never leaves the CU
-            return hip.feature_fusion(z0, z1, spec[0], spec[1], dual[0], dual[1], dual[2])
+            return self.k10(p, z0, z1, spec)                       # K10: the whole block in one launch, h never leaves the CU
         gf = self.cconv(spec, [z0, z1], act=hip.ACT_GELU)
         if self.fuse_heads and cg % 64 == 0:
             # both second layers in one launch: weight rows [gate.2 | fusion.2] along K (= the channel order of gf), two accumulators

@@ -71,6 +71,8 @@ SIGNATURES = {
     "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
     "s2m2_feature_fusion_supported": (_i, [_i, _i]),
     "s2m2_feature_fusion": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "s2m2_feature_fusion_frag_supported": (_i, [_i, _i]),
+    "s2m2_feature_fusion_frag": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "s2m2_convex_upsample": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, _ll, _i, _vp]),
     "s2m2_attention": (_i, [_vp, _vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp, _ll,
                             _i, _i, _i, _vp]),
@@ -573,11 +575,17 @@ def feature_fusion_supported(C: int, dtype: torch.dtype) -> bool:
     return bool(load().s2m2_feature_fusion_supported(C, _DT[dtype]))
 
 
-def feature_fusion(z0: torch.Tensor, z1: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, bg: torch.Tensor,
-                   bf: torch.Tensor, z1_coarse: bool = False) -> torch.Tensor:
+def feature_fusion_frag_supported(C: int, dtype: torch.dtype) -> bool:
+    """the direct form of K10 (weights as a fragment stream, pack.fusion_frag) exists for this width"""
+    return bool(load().s2m2_feature_fusion_frag_supported(C, _DT[dtype]))
+
+
+def feature_fusion(z0: torch.Tensor, z1: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: Optional[torch.Tensor], bg: torch.Tensor,
+                   bf: torch.Tensor, z1_coarse: bool = False, frag: bool = False) -> torch.Tensor:
     """FeatureFusion with 1x1 kernels in one launch (s2m2_feature_fusion): z0, z1 (..., C); w1 packed (3C, 2C) = [gate.0; fusion.0],
     w2 packed (C, 3C) = [gate.2 | fusion.2]; biases fp32.  z1_coarse: z0 is (N, 2h, 2w, C) and z1 the coarse (N, h, w, C) tensor,
-    read through the bilinear x2 resampling."""
+    read through the bilinear x2 resampling.  frag: w1 is the fragment stream of BOTH layers (pack.fusion_frag(w1, w2), 9*C*C values),
+    w2 is None -> the direct form (s2m2_feature_fusion_frag), meant for short row counts."""
     C = z0.shape[-1]
     if z1.dtype != z0.dtype or z1.shape[-1] != C:
         raise ValueError("feature_fusion: z0 and z1 must match")
@@ -588,15 +596,23 @@ def feature_fusion(z0: torch.Tensor, z1: torch.Tensor, w1: torch.Tensor, b1: tor
         hc, wc = z1.shape[1], z1.shape[2]
     elif z1.shape != z0.shape:
         raise ValueError("feature_fusion: z0 and z1 must match")
-    if tuple(w1.shape) != (3 * C, 2 * C) or tuple(w2.shape) != (C, 3 * C) or w1.dtype != z0.dtype or w2.dtype != z0.dtype:
+    if frag:
+        if w2 is not None or w1.numel() != 9 * C * C or w1.dtype != z0.dtype or not w1.is_contiguous():
+            raise ValueError(f"feature_fusion: frag needs the {9 * C * C}-value fragment stream as w1 and w2 = None")
+    elif tuple(w1.shape) != (3 * C, 2 * C) or tuple(w2.shape) != (C, 3 * C) or w1.dtype != z0.dtype or w2.dtype != z0.dtype:
         raise ValueError(f"feature_fusion: w1 must be ({3 * C}, {2 * C}) and w2 ({C}, {3 * C}) in {z0.dtype}")
     for t, n in ((b1, 3 * C), (bg, C), (bf, C)):
         if t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
             raise ValueError("feature_fusion: biases must be fp32 (3C), (C), (C)")
-    _dev(w1, w2, b1, bg, bf)
+    _dev(w1, b1, bg, bf) if frag else _dev(w1, w2, b1, bg, bf)
     rows, s0 = _token_rows(z0, "feature_fusion")
     _, s1 = _token_rows(z1, "feature_fusion")
     out = torch.empty(z0.shape, device=z0.device, dtype=z0.dtype)
+    if frag:
+        _check(load().s2m2_feature_fusion_frag(z0.data_ptr(), z1.data_ptr(), out.data_ptr(), s0, s1, C, rows, C, w1.data_ptr(), b1.data_ptr(),
+                                               bg.data_ptr(), bf.data_ptr(), hc, wc, _DT[z0.dtype], _stream()), "s2m2_feature_fusion_frag")
+        _meter("feature_fusion", 2.0 * rows * C * C * 9)
+        return out
     _check(load().s2m2_feature_fusion(z0.data_ptr(), z1.data_ptr(), out.data_ptr(), s0, s1, C, rows, C, w1.data_ptr(), b1.data_ptr(),
                                       w2.data_ptr(), bg.data_ptr(), bf.data_ptr(), hc, wc, _DT[z0.dtype], _stream()), "s2m2_feature_fusion")
     _meter("feature_fusion", 2.0 * rows * C * C * 9)                # (2C -> 3C) + (C -> C) + (2C -> C)

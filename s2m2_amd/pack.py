@@ -99,6 +99,25 @@ def chain_frag(wp: torch.Tensor) -> torch.Tensor:
     return t.contiguous().reshape(rows, C)
 
 
+def _frag_rows(w: torch.Tensor) -> torch.Tensor:
+    """(R, K) -> (R/32, K/16, 64, 8): per 32-row tile and k16 step the MFMA A-fragment (lane l: row 32t + l % 32, k 16*step + 8*(l // 32) + e)"""
+    R, K = w.shape
+    return w.reshape(R // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(R // 32, K // 16, 64, 8)
+
+
+def fusion_frag(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """K10 weights, w1 packed (3C, 2C) and w2 packed (C, 3C) = [Wg | Wf] -> the fragment stream of s2m2_feature_fusion_frag: per 32-cout
+    tile t, for slice s = 0, 1, 2: the fragments of w1[sC + 32t .. + 32, :] (2C/16 steps), then of w2[32t .. + 32, sC : (s + 1)C] (C/16 steps).
+    Flat tensor of 9*C*C values."""
+    C = w2.shape[0]
+    assert tuple(w1.shape) == (3 * C, 2 * C) and tuple(w2.shape) == (C, 3 * C) and C % 32 == 0
+    parts = []
+    for s in range(3):
+        parts.append(_frag_rows(w1[s * C:(s + 1) * C]))                          # (C/32, 2C/16, 64, 8)
+        parts.append(_frag_rows(w2[:, s * C:(s + 1) * C].contiguous()))          # (C/32, C/16, 64, 8)
+    return torch.cat(parts, dim=1).contiguous().reshape(-1)                      # (C/32, 9C/16, 64, 8)
+
+
 def pack_bias(b: Optional[torch.Tensor], cout: int, cout_pad: Optional[int] = None) -> Optional[torch.Tensor]:
     if b is None:
         return None

@@ -93,6 +93,9 @@ def make():
     def mlp_chain_frag_supported(C, dtype):
         return False                                     # (the CPU stand-in keeps row-major weights)
 
+    def feature_fusion_frag_supported(C, dtype):
+        return False
+
     def corr_tiled_supported(C, dtype):
         return False                                     # (the CPU stand-in keeps row-major tokens: the fp32 wiring test never tiles)
 
@@ -228,7 +231,7 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, corr_tiled_supported, corr_hybrid_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, corr_tiled_supported, corr_hybrid_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
     ns.TiledTokens = TiledTokens
     ns.HybridTokens = HybridTokens

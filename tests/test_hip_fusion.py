@@ -87,3 +87,40 @@ def test_feature_fusion_reads_z1_through_the_bilinear_upsampling(hip, dtype, sha
     assert torch.equal(y, y2)
     ref_up = F.interpolate(zc.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
     assert float((up.float() - ref_up).abs().max()) < (1e-5 if dtype == torch.float32 else 4e-3)
+
+
+# ---- direct form (s2m2_feature_fusion_frag: both layers' weights as one fragment stream, straight into the MFMA operand registers) -------
+@pytest.mark.parametrize("C,shp,coarse", [(256, (1, 64, 76), False), (256, (2, 32, 38), True), (256, (2, 64, 76), True),     # 9728 rows: 64-row tiles
+                                          (128, (1, 128, 152), True), (128, (2, 128, 152), False),                          # 38912 rows: 64-row tiles
+                                          (128, (2, 13, 21), False), (128, (1, 1, 1), False), (256, (1, 9, 7), True)])
+def test_feature_fusion_direct_form_equals_lds_form_bit_for_bit(hip, C, shp, coarse):
+    """Same fp16 operands, same k16 order of every MFMA chain, same epilogues and rounding points -> bit-identical outputs, incl. ragged
+    last tiles, strided z0 rows and the bilinear z1 path; repeated launches (the form has 6 block barriers: a race would be a flaky mismatch)."""
+    dtype = torch.float16
+    assert hip.feature_fusion_frag_supported(C, dtype) and not hip.feature_fusion_frag_supported(C, torch.float32)
+    g = torch.Generator(device="cuda").manual_seed(C + shp[1] + 3)
+    n, h, w = shp
+    if coarse:
+        wide = torch.randn(n, 2 * h, 2 * w, C + 8, device="cuda", generator=g).to(dtype)
+        z1 = (torch.randn(n, h, w, C, device="cuda", generator=g) * 1.5).to(dtype)
+    else:
+        wide = torch.randn(n, h, w, C + 8, device="cuda", generator=g).to(dtype)
+        z1 = (torch.randn(n, h, w, C, device="cuda", generator=g) * 1.5).to(dtype)
+    z0 = wide[..., :C]                                            # strided rows
+    w1, wg, wf, b1, bg, bf = _weights(C, dtype, 7 * C)
+    p1 = pack.pack_conv(w1, dtype)
+    p2 = torch.cat([pack.pack_conv(wg, dtype), pack.pack_conv(wf, dtype)], dim=1).contiguous()
+    bs = (pack.pack_bias(b1, 3 * C), pack.pack_bias(bg, C), pack.pack_bias(bf, C))
+    ref = hip.feature_fusion(z0, z1, p1, bs[0], p2, bs[1], bs[2], z1_coarse=coarse)
+    stream = pack.fusion_frag(p1, p2)
+    assert stream.numel() == 9 * C * C
+    for _ in range(5):
+        y = hip.feature_fusion(z0, z1, stream, bs[0], None, bs[1], bs[2], z1_coarse=coarse, frag=True)
+        assert y.shape == ref.shape and torch.equal(y, ref)
+
+
+def test_feature_fusion_direct_form_rejects_unsupported(hip):
+    z = torch.zeros(4, 384, device="cuda").half()
+    with pytest.raises(RuntimeError, match="not supported"):
+        hip.feature_fusion(z, z, torch.zeros(9 * 384 * 384, device="cuda").half(), torch.zeros(3 * 384, device="cuda"), None,
+                           torch.zeros(384, device="cuda"), torch.zeros(384, device="cuda"), frag=True)

@@ -64,3 +64,19 @@ def test_chain_frag_is_a_permutation():
     for layer, o, q in ((0, 0, 0), (0, 33, 5), (1, 127, 15), (1, 64, 2)):
         slot = ((o // 32) * (C // 16) + q // 2) * 64 + (q % 2) * 32 + o % 32
         assert torch.equal(f[layer, slot], w[layer * C + o, 8 * q:8 * q + 8])
+
+
+def test_fusion_frag_stream_order():
+    """pack.fusion_frag: fragment j of cout tile t at 16-byte slot (t * 9C/16 + j) * 64 + lane; slice s: 2C/16 fragments of w1 rows sC + 32t ..,
+    then C/16 fragments of w2 columns sC .. (include/s2m2_hip.h, s2m2_feature_fusion_frag)"""
+    C = 128
+    w1 = torch.arange(3 * C * 2 * C, dtype=torch.float32).reshape(3 * C, 2 * C)
+    w2 = -torch.arange(C * 3 * C, dtype=torch.float32).reshape(C, 3 * C) - 1
+    f = pack.fusion_frag(w1, w2).reshape(C // 32, 9 * C // 16, 64, 8)
+    per = 3 * C // 16
+    for t, s, step, lane in ((0, 0, 0, 0), (1, 0, 15, 33), (3, 2, 7, 63), (2, 1, 0, 31)):
+        row, k = 32 * t + lane % 32, 16 * step + 8 * (lane // 32)
+        assert torch.equal(f[t, s * per + step, lane], w1[s * C + row, k:k + 8])
+    for t, s, step, lane in ((0, 0, 0, 0), (1, 1, 3, 40), (3, 2, 7, 63)):
+        row, k = 32 * t + lane % 32, s * C + 16 * step + 8 * (lane // 32)
+        assert torch.equal(f[t, s * per + 2 * C // 16 + step, lane], w2[row, k:k + 8])
