@@ -130,7 +130,7 @@ class Engine:
         # global memory straight into the operand registers (hip.mlp_chain(frag=True)); S2M2_CHAIN_DIRECT=0: off,
         # S2M2_CHAIN_DIRECT_MAX: largest row count that takes it; S2M2_CHAIN_DIRECT_QKV=0: without the next attention's Q|K|V as fan-out
         self.chain_direct = os.environ.get("S2M2_CHAIN_DIRECT", "1") != "0"
-        self.chain_direct_max = int(os.environ.get("S2M2_CHAIN_DIRECT_MAX", "40000"))
+        self.chain_direct_max = int(os.environ.get("S2M2_CHAIN_DIRECT_MAX", str(1 << 30)))
         self.chain_direct_qkv = os.environ.get("S2M2_CHAIN_DIRECT_QKV", "1") != "0"
         self._wfrag = {}
         # the same for K10 (hip.feature_fusion(frag=True)): S2M2_FUSION_DIRECT=0: off, S2M2_FUSION_DIRECT_MAX: largest row count

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Build-time guard of the scheduling assumptions behind K5 v5 (conv_frag_kernel, s2m2_amd/csrc/conv.hip).
+"""Build-time guard of the scheduling assumptions behind K5 v5 (conv_frag_kernel, s2m2_amd/csrc/conv.hip) and the direct form of K10
+(feature_fusion_direct_kernel, s2m2_amd/csrc/fusion.hip).
 
 The kernel prefetches its weight fragments with loads the compiler does NOT track (common.h: global_load16_async) and waits for them with
 hand-counted ``s_waitcnt vmcnt(N)``.  That is only correct while, inside the K loop,
@@ -12,6 +13,11 @@ hand-counted ``s_waitcnt vmcnt(N)``.  That is only correct while, inside the K l
 This script compiles conv.hip to gfx950 assembly (device only), finds the K-loop basic blocks of every conv_frag_kernel instantiation
 (blocks that hold both MFMAs and 16-byte global loads) and fails when either property is violated.  ``__graft_entry__.build()`` runs it
 when the library is (re)built;  python tools/check_isa.py [--keep-asm PATH]  runs it alone (about a minute: one device-only compile).
+
+feature_fusion_direct_kernel is one straight-line block (fully unrolled k16 steps): there the checked region runs from the first MFMA to the
+last fragment request -- while the ring is being refilled every ring register is either in flight or about to feed an MFMA -- and, besides
+the two properties above, every ``s_waitcnt vmcnt(N)`` in the region must carry the same N >= 8 (ring depth - 1: the prefetch distance the
+kernel was written for is what the generated code has).
 """
 import os
 import re
@@ -70,16 +76,95 @@ def check_function(name: str, lines):
     return problems, nloops
 
 
+def check_straight_line(name: str, lines):
+    """feature_fusion_direct_kernel: region = first MFMA .. last 16-byte global load of the kernel's instruction stream"""
+    ins = [l.split(";")[0].strip() for l in lines if l.strip() and not l.strip().startswith((".", ";"))]
+    mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
+    ld = [i for i, l in enumerate(ins) if l.startswith("global_load_dwordx4")]
+    if len(mf) < 16 or not ld or ld[-1] < mf[0]:
+        return [f"{name}: no MFMA / fragment-load region found (the check no longer matches the generated code)"], 0
+    lo, hi = mf[0], ld[-1]
+    # registers whose fragment request may still be in flight: set by a 16-byte load, cleared by the MFMA that consumes them (the allocator
+    # moves a ring slot to other registers between refills, so the set is tracked instruction by instruction)
+    flying = set()
+    problems, waits = [], set()
+    for idx, l in enumerate(ins[:hi + 1]):
+        inside = idx >= lo
+        m = re.search(r"s_waitcnt\b.*vmcnt\((\d+)\)", l)
+        if m and inside:
+            waits.add(int(m.group(1)))
+        ops = [t.strip().rstrip(",") for t in l.split()[1:]]
+        if l.startswith("global_load_dwordx4"):
+            flying |= regs_of(ops[0])
+            continue
+        if l.startswith("v_mfma"):
+            for t in ops[1:3]:
+                flying -= regs_of(t)
+            continue
+        if l.startswith("ds_write"):                              # (the prologue's tracked loads -- row tile, bias vectors -- end in LDS)
+            for t in ops[1:]:
+                flying -= regs_of(t)
+            continue
+        if l.startswith(("s_", "buffer_")):
+            continue
+        srcs, dsts = ([], ops[:1]) if l.startswith("ds_read") else (ops[1:], ops[:1])
+        if not inside:                                            # prologue: tracked loads (bilinear z1 path) are consumed by plain arithmetic
+            for t in srcs:
+                flying -= regs_of(t)
+            continue
+        for t in srcs:
+            if regs_of(t) & flying:
+                problems.append(f"{name}: non-MFMA instruction reads a register whose fragment may be in flight: {l}")
+        for t in dsts:
+            if regs_of(t) & flying:
+                problems.append(f"{name}: instruction overwrites a register whose fragment may be in flight: {l}")
+    if len(waits) != 1 or min(waits) < 8:
+        problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected one value >= 8: ring depth - 1)")
+    return problems, 1
+
+
+def compile_asm(src: str, asm: str):
+    defines = os.environ.get("S2M2_BUILD_DEFINES", "").split()
+    r = subprocess.run([HIPCC, *FLAGS, *defines, src, "-o", asm], capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-4000:])
+        return None
+    return open(asm).read().splitlines()
+
+
+def functions(text, prefix: str):
+    funcs, cur = {}, None
+    for ln in text:
+        m = re.match(r"^(" + prefix + r"\S*):", ln)
+        if m:
+            cur = []
+            funcs[m.group(1)] = cur
+            continue
+        if cur is not None:
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                cur.append(ln)
+    return funcs
+
+
 def main() -> int:
     keep = sys.argv[sys.argv.index("--keep-asm") + 1] if "--keep-asm" in sys.argv else None
     with tempfile.TemporaryDirectory() as td:
-        asm = keep or os.path.join(td, "conv.s")
-        defines = os.environ.get("S2M2_BUILD_DEFINES", "").split()
-        r = subprocess.run([HIPCC, *FLAGS, *defines, SRC, "-o", asm], capture_output=True, text=True)
-        if r.returncode != 0:
-            sys.stderr.write(r.stderr[-4000:])
+        text = compile_asm(SRC, keep or os.path.join(td, "conv.s"))
+        ftext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "fusion.hip"), os.path.join(td, "fusion.s"))
+        if text is None or ftext is None:
             return 2
-        text = open(asm).read().splitlines()
+    bad = []
+    ffuncs = functions(ftext, "_ZN4s2m228feature_fusion_direct_kernel")
+    if not ffuncs:
+        print("check_isa: no feature_fusion_direct_kernel instantiation found in the assembly")
+        return 1
+    for name, lines in ffuncs.items():
+        problems, n = check_straight_line(name, lines)
+        short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0][:110]
+        print(f"check_isa: {short}: {n} refill region(s), {len(problems)} problem(s)")
+        bad += problems
     funcs, cur, name = {}, None, None
     for ln in text:
         m = re.match(r"^(_ZN4s2m216conv_frag_kernel\S*):", ln)
@@ -95,7 +180,6 @@ def main() -> int:
     if not funcs:
         print("check_isa: no conv_frag_kernel instantiation found in the assembly")
         return 1
-    bad = []
     for name, lines in funcs.items():
         problems, nloops = check_function(name, lines)
         short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().split("(")[0][:110]
