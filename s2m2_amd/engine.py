@@ -133,6 +133,8 @@ class Engine:
         self.chain_direct_max = int(os.environ.get("S2M2_CHAIN_DIRECT_MAX", str(1 << 30)))
         self.chain_direct_qkv = os.environ.get("S2M2_CHAIN_DIRECT_QKV", "1") != "0"
         self._wfrag = {}
+        self.pw_direct = os.environ.get("S2M2_PW_DIRECT", "1") != "0"
+        self.chain_direct_ln = os.environ.get("S2M2_CHAIN_DIRECT_LN", "1") != "0"    # the launch that also writes K1's normalised tokens
         # the same for K10 (hip.feature_fusion(frag=True)): S2M2_FUSION_DIRECT=0: off, S2M2_FUSION_DIRECT_MAX: largest row count
         self.fusion_direct = os.environ.get("S2M2_FUSION_DIRECT", "1") != "0"
         self.fusion_direct_max = int(os.environ.get("S2M2_FUSION_DIRECT_MAX", str(1 << 30)))
@@ -211,6 +213,18 @@ class Engine:
         """K5 launch.  ln: the layer is a pre-LayerNorm (no affine, attentions.py:117) followed by this 1x1 layer, folded into
         the kernel -- needs the row sums of the packed weight, computed once per layer."""
         wp, bp, kh, kw_, cout = spec
+        # a plain 1x1 C -> C layer (C = 128 / 256, fp16, optionally + residual): the direct form of K9 as a one-stage chain -- the weight as
+        # MFMA fragments straight into the operand registers instead of K5's LDS-staged K tiles (S2M2_PW_DIRECT=0: off)
+        if (self.pw_direct and self.chain_direct and kh == 1 and kw_ == 1 and len(srcs) == 1 and self.dtype == torch.float16
+                and srcs[0].shape[-1] == cout and tuple(wp.shape) == (cout, cout) and not getattr(spec, "korder", 0)
+                and set(kw) <= {"act", "epi", "aux0"} and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
+                and kw.get("epi", hip.EPI_NONE) in (hip.EPI_NONE, hip.EPI_ADD) and ("aux0" in kw) == (kw.get("epi", hip.EPI_NONE) == hip.EPI_ADD)
+                and ("aux0" not in kw or tuple(kw["aux0"].shape) == tuple(srcs[0].shape))
+                and srcs[0].numel() // cout <= self.chain_direct_max and hip.mlp_chain_frag_supported(cout, self.dtype)):
+            st = [(self.wfrag(spec), bp, kw.get("act", hip.ACT_NONE), self.wsum(spec) if ln else None)]
+            if "aux0" in kw:
+                return hip.mlp_chain(srcs[0], st, res=kw["aux0"], res_stage=0, frag=True)
+            return hip.mlp_chain(srcs[0], st, frag=True)
         # a plain 1x1 C -> C layer on >= 32768 rows of 128 fp16 channels (1/4 resolution): the weights-stationary persistent form of K9 as a
         # one-stage chain (the 32 KB weight resident in LDS, one pass over the rows) instead of the K5 tile kernel
         if (self.pw_ws and kh == 1 and kw_ == 1 and len(srcs) == 1 and self.dtype == torch.float16 and cout == 128 and srcs[0].shape[-1] == 128
@@ -427,6 +441,11 @@ class Engine:
                 tiled = self.k1_stream and hip.corr_tiled_supported(c, self.dtype)     # fragment order for the streaming form of K1
                 if self.k1_hybrid and not tiled and hip.corr_hybrid_supported(c, self.dtype) and w % 8 == 0:
                     tiled = "left"
+                if (self.chain_direct and self.chain_direct_ln and not tiled and self.fuse_ln and z.numel() // c <= self.chain_direct_max
+                        and hip.mlp_chain_frag_supported(c, self.dtype)):
+                    fstages = [(self.wfrag(sp), sp[1], act, ws) for sp, (_, _, act, ws) in zip((proj, f0, f2), stages)]
+                    out, self._tokens_normed = hip.mlp_chain(o, fstages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp, frag=True)
+                    return out, None
                 out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp,
                                                          ln_out_tiled=tiled)
                 return out, None
