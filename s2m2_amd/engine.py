@@ -220,7 +220,7 @@ class Engine:
                 and set(kw) <= {"act", "epi", "aux0"} and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
                 and kw.get("epi", hip.EPI_NONE) in (hip.EPI_NONE, hip.EPI_ADD) and ("aux0" in kw) == (kw.get("epi", hip.EPI_NONE) == hip.EPI_ADD)
                 and ("aux0" not in kw or tuple(kw["aux0"].shape) == tuple(srcs[0].shape))
-                and srcs[0].numel() // cout <= self.chain_direct_max and hip.mlp_chain_frag_supported(cout, self.dtype)):
+                and srcs[0].numel() // cout <= self.chain_direct_max and self.chain_frag_ok(cout, self.dtype)):
             st = [(self.wfrag(spec), bp, kw.get("act", hip.ACT_NONE), self.wsum(spec) if ln else None)]
             if "aux0" in kw:
                 return hip.mlp_chain(srcs[0], st, res=kw["aux0"], res_stage=0, frag=True)
@@ -287,7 +287,7 @@ class Engine:
         c0, c2 = self.std(p + ".convs_1x.0"), self.std(p + ".convs_1x.2")
         chain = self.use_chain and self.chain_ok(z.shape[-1]) and c0[4] == z.shape[-1] and c2[4] == z.shape[-1]
         with self.fork():                                         # 1x1 branch in parallel with the first 3x3
-            if chain and self.chain_direct and z.numel() // z.shape[-1] <= self.chain_direct_max and hip.mlp_chain_frag_supported(z.shape[-1], self.dtype):
+            if chain and self.chain_direct and z.numel() // z.shape[-1] <= self.chain_direct_max and self.chain_frag_ok(z.shape[-1], self.dtype):
                 u = b = hip.mlp_chain(z, [(self.wfrag(c0), c0[1], hip.ACT_RELU, None), (self.wfrag(c2), c2[1], hip.ACT_NONE, None)], frag=True)
             elif chain:
                 u = b = hip.mlp_chain(z, [(c0[0], c0[1], hip.ACT_RELU, None), (c2[0], c2[1], hip.ACT_NONE, None)])
@@ -317,7 +317,7 @@ class Engine:
         """one K10 launch; short row counts take the direct form (weights as one fragment stream, permuted once per layer)"""
         dual = self.dual_heads(p)
         c = z0.shape[-1]
-        if self.fusion_direct and z0.numel() // c <= self.fusion_direct_max and hip.feature_fusion_frag_supported(c, self.dtype):
+        if self.fusion_direct and z0.numel() // c <= self.fusion_direct_max and self.fusion_frag_ok(c):
             key = p + "|k10 fragment stream"
             ws = self._packed.get(key)
             if ws is None:
@@ -419,7 +419,7 @@ class Engine:
         if self.use_chain and self.chain_ok(c):
             stages = [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)), (f2[0], f2[1], hip.ACT_NONE, None)]
             if (self.chain_direct and ln_out is None and z.numel() // c <= self.chain_direct_max and self.fuse_ln
-                    and hip.mlp_chain_frag_supported(c, self.dtype)):
+                    and self.chain_frag_ok(c, self.dtype)):
                 # short row counts: the launch lives for the latency of its weight stream -- fragments straight into registers, and the
                 # next attention's Q | K | V projection rides along as fan-out stages (one launch and one round trip of the rows less)
                 fstages = [(self.wfrag(sp), sp[1], act, ws) for sp, (_, _, act, ws) in zip((proj, f0, f2), stages)]
@@ -442,7 +442,7 @@ class Engine:
                 if self.k1_hybrid and not tiled and hip.corr_hybrid_supported(c, self.dtype) and w % 8 == 0:
                     tiled = "left"
                 if (self.chain_direct and self.chain_direct_ln and not tiled and self.fuse_ln and z.numel() // c <= self.chain_direct_max
-                        and hip.mlp_chain_frag_supported(c, self.dtype)):
+                        and self.chain_frag_ok(c, self.dtype)):
                     fstages = [(self.wfrag(sp), sp[1], act, ws) for sp, (_, _, act, ws) in zip((proj, f0, f2), stages)]
                     out, self._tokens_normed = hip.mlp_chain(o, fstages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp, frag=True)
                     return out, None
@@ -456,6 +456,19 @@ class Engine:
         else:
             hdn = self.cconv(f0, [hip.layernorm(z)], act=hip.ACT_GELU)
         return self.cconv(f2, [hdn], epi=hip.EPI_ADD, aux0=z), None
+
+    def chain_frag_ok(self, c: int, dtype=None) -> bool:
+        """the direct form of K9 exists for this width (asked once per width: the query is a ctypes call)"""
+        ok = self._chain_ok.get(("frag", c))
+        if ok is None:
+            ok = self._chain_ok[("frag", c)] = hip.mlp_chain_frag_supported(c, self.dtype)
+        return ok
+
+    def fusion_frag_ok(self, c: int) -> bool:
+        ok = self._fusion_ok.get(("frag", c))
+        if ok is None:
+            ok = self._fusion_ok[("frag", c)] = hip.feature_fusion_frag_supported(c, self.dtype)
+        return ok
 
     def chain_ok(self, c: int) -> bool:
         ok = self._chain_ok.get(c)
