@@ -267,7 +267,8 @@ typedef struct s2m2_chain_desc {
        fan_weight) -- and the launch runs the DIRECT form: a wave's weight fragments go from global memory straight into its MFMA operand
        registers, one whole stage ahead, no weight tile in LDS and no block barrier inside a stage.  For SHORT row counts (the 1/32 .. 1/8
        pyramid levels: a block lives for the latency of its weight stream, not for its arithmetic).  fp16, C = 128 / 256: ask
-       s2m2_mlp_chain_frag_supported.  Same arithmetic and rounding points as the row-major form. */
+       s2m2_mlp_chain_frag_supported.  Same arithmetic and rounding points as the row-major form.  With nstage = 0 and nfan = 1 .. 4 the
+       fan-out layers alone run in this form (any row count; without weight_frag nstage = 0 needs s2m2_mlp_fan_supported). */
     int weight_frag;
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);

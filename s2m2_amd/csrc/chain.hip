@@ -473,7 +473,9 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     ChainStream<CFG, T> ws;
     ws.init(p, tid);
     // the first D chunks of the weight stream and the row tile are requested together
-    if constexpr (CFG::DIRECT) ws.fetch_direct(static_cast<const T*>(p.w[0]), 0, 0);
+    // (NST == 0: fan-out only -- the stream starts with the first fan-out layer)
+    const T* wfirst = static_cast<const T*>(CFG::NST > 0 ? p.w[0] : p.fan_w);
+    if constexpr (CFG::DIRECT) ws.fetch_direct(wfirst, 0, 0);
     else ws.fetch(0, 0);
     raw16_t xr[CFG::X_IT];
 #pragma unroll
@@ -485,7 +487,7 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     }
 #pragma unroll
     for (int f = 1; f < D; ++f)
-        if constexpr (CFG::DIRECT) ws.fetch_direct(static_cast<const T*>(p.w[0]), f, f);     // (D = CPS: the whole first stage)
+        if constexpr (CFG::DIRECT) ws.fetch_direct(wfirst, f, f);     // (D = CPS: the whole first stage)
         else if (f < (CFG::NST + p.nfan) * CFG::CPS) ws.fetch(f, f);
     if constexpr (!CFG::DIRECT) ws.stash(W0, 0);
 #pragma unroll
@@ -495,11 +497,11 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     }
     __syncthreads();
 
-    ChainStage<CFG, T, 0>::run(p, ws, A0, A1, W0, W1, tid, m0);
+    if constexpr (CFG::NST > 0) ChainStage<CFG, T, 0>::run(p, ws, A0, A1, W0, W1, tid, m0);
     if constexpr (CFG::NST > 1) ChainStage<CFG, T, 1>::run(p, ws, A0, A1, W0, W1, tid, m0);
     if constexpr (CFG::NST > 2) ChainStage<CFG, T, 2>::run(p, ws, A0, A1, W0, W1, tid, m0);
     if (p.nfan > 0) {                                              // block-uniform
-        T* Afin = ((CFG::NST - 1) & 1) ? A1 : A0;                  // the last stage stages in place: its tile is its input buffer
+        T* Afin = (CFG::NST > 0 && ((CFG::NST - 1) & 1)) ? A1 : A0;   // the last stage stages in place: its tile is its input buffer (NST == 0: the x rows)
         chain_fan<CFG, T>(p, ws, Afin, Afin == A0 ? A1 : A0, W0, W1, tid, m0);
     }
 }
@@ -881,8 +883,27 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "mlp_chain: null descriptor");
     S2M2_REQUIRE(d->x, "mlp_chain: null x");
-    S2M2_REQUIRE(d->weight_frag == 0 || (d->weight_frag == 1 && d->nstage > 0 && s2m2_mlp_chain_frag_supported(d->C, d->dtype)),
-                 "mlp_chain: weight_frag=%d needs nstage >= 1, fp16 and C = 128 / 256", d->weight_frag);
+    S2M2_REQUIRE(d->weight_frag == 0 || (d->weight_frag == 1 && (d->nstage > 0 || d->nfan > 0) && s2m2_mlp_chain_frag_supported(d->C, d->dtype)),
+                 "mlp_chain: weight_frag=%d needs fp16 and C = 128 / 256", d->weight_frag);
+    if (d->nstage == 0 && d->weight_frag) {
+        // fan-out only, direct form: the nfan layers read the x rows, their fragments straight from global memory (any row count)
+        S2M2_REQUIRE(d->nfan >= 1 && d->nfan <= 4, "mlp_chain: nfan=%d (1..4)", d->nfan);
+        S2M2_REQUIRE(d->rows > 0 && d->rows < (1LL << 31) && d->x_stride >= d->C && d->x_stride % 8 == 0, "mlp_chain: bad rows / x_stride");
+        S2M2_REQUIRE(d->fan_weight && d->fan_out && d->fan_out_stride >= (long long)d->nfan * d->C && d->fan_out_stride % 8 == 0,
+                     "mlp_chain: fan-out stages need fan_weight, fan_out and a row stride of at least nfan * C (multiple of 8)");
+        S2M2_REQUIRE(!d->fan_ln_wsum || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
+        ChainArgs f{};
+        f.x = d->x; f.x_stride = d->x_stride; f.rows = d->rows; f.ln_eps = d->ln_eps; f.res_stage = -1;
+        f.fan_w = d->fan_weight; f.fan_b = d->fan_bias; f.fan_wsum = d->fan_ln_wsum; f.fan_out = d->fan_out; f.fan_out_stride = d->fan_out_stride;
+        f.nfan = d->nfan;
+        f.zero = zero_page();
+        S2M2_REQUIRE(f.zero, "mlp_chain: cannot allocate the zero page");
+        hipStream_t fst = static_cast<hipStream_t>(stream);
+        static const int force_bm0 = getenv("S2M2_CHAIN_DIRECT_BM") ? atoi(getenv("S2M2_CHAIN_DIRECT_BM")) : 0;
+        const bool tall0 = force_bm0 ? force_bm0 == 64 : d->rows > (d->C == 128 ? 24576 : 8192);
+        if (d->C == 128) return tall0 ? launch_chain<half_t, 128, 64, 0, 4, 0>(f, fst) : launch_chain<half_t, 128, 32, 0, 4, 0>(f, fst);
+        return tall0 ? launch_chain<half_t, 256, 64, 0, 8, 0>(f, fst) : launch_chain<half_t, 256, 32, 0, 8, 0>(f, fst);
+    }
     if (d->nstage == 0) {
         // fan-out only: the nfan layers read the x rows themselves (weights-stationary form: fp16, C = 128, nfan 1..3) -- ask
         // s2m2_mlp_fan_supported first

@@ -134,6 +134,7 @@ class Engine:
         self.chain_direct_qkv = os.environ.get("S2M2_CHAIN_DIRECT_QKV", "1") != "0"
         self._wfrag = {}
         self.pw_direct = os.environ.get("S2M2_PW_DIRECT", "1") != "0"
+        self.qkv_direct = os.environ.get("S2M2_QKV_DIRECT", "1") != "0"              # a block's first Q|K|V projection as a fan-out-only launch
         self.chain_direct_ln = os.environ.get("S2M2_CHAIN_DIRECT_LN", "1") != "0"    # the launch that also writes K1's normalised tokens
         # the same for K10 (hip.feature_fusion(frag=True)): S2M2_FUSION_DIRECT=0: off, S2M2_FUSION_DIRECT_MAX: largest row count
         self.fusion_direct = os.environ.get("S2M2_FUSION_DIRECT", "1") != "0"
@@ -369,6 +370,9 @@ class Engine:
         spec = self.qkv_spec(p)
         c = x.shape[-1]
         rows = x.numel() // c
+        if (self.qkv_direct and self.chain_direct and self.fuse_ln and spec[2] == 1 and spec[3] == 1 and spec[4] == 3 * c
+                and self.dtype == torch.float16 and rows <= self.chain_direct_max and self.chain_frag_ok(c)):
+            return hip.mlp_fan(x, self.wfrag(spec), spec[1], self.wsum(spec), frag=True)    # direct form: fragments straight into registers
         if (self.fan_ws and self.fuse_ln and spec[2] == 1 and spec[3] == 1 and spec[4] == 3 * c and rows >= 32768
                 and hip.mlp_fan_supported(c, 3, self.dtype)):
             return hip.mlp_fan(x, spec[0], spec[1], self.wsum(spec))       # one pass over the rows, the stacked weight resident in LDS

@@ -454,9 +454,11 @@ def mlp_fan_supported(C: int, nfan: int, dtype: torch.dtype) -> bool:
     return bool(load().s2m2_mlp_fan_supported(C, nfan, _DT[dtype]))
 
 
-def mlp_fan(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ln_wsum: Optional[torch.Tensor], ln_eps: float = 1e-5) -> torch.Tensor:
+def mlp_fan(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ln_wsum: Optional[torch.Tensor], ln_eps: float = 1e-5,
+            frag: bool = False) -> torch.Tensor:
     """n stacked C -> C layers on the rows of x (..., C) -> (..., n*C) in one pass over the rows (s2m2_mlp_chain with nstage = 0: the
-    weights-stationary fan-out form; pre-LayerNorm folded in when ln_wsum is given).  weight packed (n*C, C)."""
+    weights-stationary fan-out form; pre-LayerNorm folded in when ln_wsum is given).  weight packed (n*C, C).  frag: the weight is in
+    MFMA-fragment order (pack.chain_frag) -> the direct form (mlp_chain_frag_supported; any row count, n <= 4)."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_fan")
     n = weight.shape[0] // C
@@ -469,6 +471,7 @@ def mlp_fan(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
     d = ChainDesc()
     d.x, d.x_stride, d.rows, d.C, d.nstage, d.dtype, d.ln_eps = x.data_ptr(), xs, rows, C, 0, _DT[x.dtype], ln_eps
     d.res_stage = -1
+    d.weight_frag = int(bool(frag))
     d.fan_weight, d.fan_out, d.fan_out_stride, d.nfan = weight.data_ptr(), out.data_ptr(), n * C, n
     d.fan_bias = bias.data_ptr() if bias is not None else None
     d.fan_ln_wsum = ln_wsum.data_ptr() if ln_wsum is not None else None

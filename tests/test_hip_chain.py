@@ -308,3 +308,29 @@ def test_chain_direct_form_rejects_unsupported(hip):
     w = torch.randn(384, 384, device="cuda").half()
     with pytest.raises(RuntimeError, match="weight_frag"):
         hip.mlp_chain(x, [(w, None, 0, None)], frag=True)
+
+
+@pytest.mark.parametrize("C,shp,nfan,ln", [(256, (2, 32, 38), 3, True), (256, (2, 64, 76), 3, True), (128, (2, 128, 152), 3, True),
+                                           (128, (1, 256, 304), 3, True), (128, (1, 7, 9), 1, False), (256, (1, 5, 3), 4, False)])
+def test_fan_only_direct_form(hip, C, shp, nfan, ln):
+    """nstage = 0 with weight_frag: the fan-out layers alone (a block's first Q | K | V projection) in the direct form == the K5 launch with the
+    folded pre-LayerNorm within fp16 rounding and, where it exists, the weights-stationary form bit for bit (same operands, k16 order and epilogue)."""
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(C + nfan)
+    wide = (torch.randn(*shp, C + 8, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
+    x = wide[..., :C]                                               # strided rows
+    wq = (torch.randn(nfan * C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+    wp = pack.pack_conv(wq, dtype)
+    bp = pack.pack_bias(torch.randn(nfan * C, device="cuda", generator=g) * 0.3, nfan * C)
+    ws = wp.float().sum(1).contiguous() if ln else None
+    wf = pack.chain_frag(wp)
+    ref = hip.conv2d([x.contiguous()], wp, bp, 1, 1, nfan * C, **({"ln_wsum": ws} if ln else {}))
+    for _ in range(4):
+        y = hip.mlp_fan(x, wf, bp, ws, frag=True)
+        assert y.shape == ref.shape
+        assert float((y.float() - ref.float()).abs().max()) < 1.5e-2
+    if hip.mlp_fan_supported(C, nfan, dtype):
+        assert torch.equal(y, hip.mlp_fan(x, wp, bp, ws))
+    t = F.layer_norm(x.float(), (C,)) if ln else x.float()
+    full = F.linear(t, wq.float().reshape(nfan * C, C), bp[:nfan * C])
+    assert float((y.float() - full).abs().max()) < 2e-2
