@@ -270,6 +270,11 @@ typedef struct s2m2_chain_desc {
        s2m2_mlp_chain_frag_supported.  Same arithmetic and rounding points as the row-major form.  With nstage = 0 and nfan = 1 .. 4 the
        fan-out layers alone run in this form (any row count; without weight_frag nstage = 0 needs s2m2_mlp_fan_supported). */
     int weight_frag;
+    /* > 0 (with weight_frag): x is an image tensor (N, pool_h, pool_w, C) with pixel stride x_stride, and row m = (n, yo, xo) of the
+       (pool_h/2, pool_w/2) grid is the mean of its four pixels (2yo, 2xo) .. (2yo+1, 2xo+1): nn.AvgPool2d(2) in front of the 1x1 layer(s)
+       (the down_conv of Unet / MRT, reference unet.py:24-29, stacked_MRT.py:21-26) folded into the tile load, rounded to fp16 like the
+       stand-alone pooling launch; rows = N * (pool_h/2) * (pool_w/2).  A residual (res) is not combined with it. */
+    int pool_h, pool_w;
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);
 int s2m2_mlp_chain_frag_supported(int C, int dtype);

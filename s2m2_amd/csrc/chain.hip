@@ -57,6 +57,8 @@ struct ChainArgs {
     // every image -- xcd_tiles consecutive tiles per image and XCD.  The consumer K1 places image row y on XCD y / (h / 8): it then finds the
     // normalised tokens in the L2 of the XCD that wrote them.
     int xcd_tiles;
+    int pool_h, pool_w;                 // > 0: x is an (N, pool_h, pool_w, C) image tensor and row m = (n, yo, xo) of the (pool_h/2, pool_w/2) grid is the
+                                        //      mean of its pixels (2yo, 2xo) .. (2yo+1, 2xo+1) -- nn.AvgPool2d(2) folded into the tile load
 };
 
 template <typename T, int C_, int BM_, int NST_, int NW_, int WP_ = 4>
@@ -482,8 +484,29 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
     for (int it = 0; it < CFG::X_IT; ++it) {
         const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
         const long long m = m0 + row;
-        const T* src = m < p.rows ? static_cast<const T*>(p.x) + m * p.x_stride + pcx * VEC : static_cast<const T*>(p.zero);
-        xr[it] = global_load16(src);
+        if (p.pool_w == 0) {                                       // block-uniform
+            const T* src = m < p.rows ? static_cast<const T*>(p.x) + m * p.x_stride + pcx * VEC : static_cast<const T*>(p.zero);
+            xr[it] = global_load16(src);
+        } else {
+            // AvgPool2d(2) in front of the chain (the down_conv of Unet / MRT, unet.py:24-29): the mean of four pixels, formed and rounded
+            // exactly as K7's pooling kernel and K5's pool2 operand load do ((a + b + c + d) * 0.25 in fp32, one rounding)
+            const int Wo = p.pool_w >> 1, Ho = p.pool_h >> 1;
+            const bool ok = m < p.rows;
+            const long long mm = ok ? m : 0;
+            const int xo = (int)(mm % Wo);
+            const long long t = mm / Wo;
+            const int yo = (int)(t % Ho);
+            const long long n = t / Ho;
+            const T* q = static_cast<const T*>(p.x) + ((n * p.pool_h + 2 * yo) * p.pool_w + 2 * xo) * p.x_stride + pcx * VEC;
+            const long long dx = p.x_stride, dy = (long long)p.pool_w * p.x_stride;
+            const Vec16<T> a = __builtin_bit_cast(Vec16<T>, global_load16(q)), b = __builtin_bit_cast(Vec16<T>, global_load16(q + dx));
+            const Vec16<T> c = __builtin_bit_cast(Vec16<T>, global_load16(q + dy)), d = __builtin_bit_cast(Vec16<T>, global_load16(q + dy + dx));
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e)
+                o.v[e] = ok ? from_f32<T>((to_f32(a.v[e]) + to_f32(b.v[e]) + to_f32(c.v[e]) + to_f32(d.v[e])) * 0.25f) : from_f32<T>(0.f);
+            xr[it] = __builtin_bit_cast(raw16_t, o);
+        }
     }
 #pragma unroll
     for (int f = 1; f < D; ++f)
@@ -885,6 +908,9 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     S2M2_REQUIRE(d->x, "mlp_chain: null x");
     S2M2_REQUIRE(d->weight_frag == 0 || (d->weight_frag == 1 && (d->nstage > 0 || d->nfan > 0) && s2m2_mlp_chain_frag_supported(d->C, d->dtype)),
                  "mlp_chain: weight_frag=%d needs fp16 and C = 128 / 256", d->weight_frag);
+    S2M2_REQUIRE((d->pool_h == 0 && d->pool_w == 0) ||
+                 (d->weight_frag && d->pool_h >= 2 && d->pool_w >= 2 && d->rows % ((long long)(d->pool_h / 2) * (d->pool_w / 2)) == 0),
+                 "mlp_chain: pool_h / pool_w need weight_frag, an input of at least 2x2 pixels and rows = N * (pool_h/2) * (pool_w/2)");
     if (d->nstage == 0 && d->weight_frag) {
         // fan-out only, direct form: the nfan layers read the x rows, their fragments straight from global memory (any row count)
         S2M2_REQUIRE(d->nfan >= 1 && d->nfan <= 4, "mlp_chain: nfan=%d (1..4)", d->nfan);
@@ -896,6 +922,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
         f.x = d->x; f.x_stride = d->x_stride; f.rows = d->rows; f.ln_eps = d->ln_eps; f.res_stage = -1;
         f.fan_w = d->fan_weight; f.fan_b = d->fan_bias; f.fan_wsum = d->fan_ln_wsum; f.fan_out = d->fan_out; f.fan_out_stride = d->fan_out_stride;
         f.nfan = d->nfan;
+        f.pool_h = d->pool_h; f.pool_w = d->pool_w;
         f.zero = zero_page();
         S2M2_REQUIRE(f.zero, "mlp_chain: cannot allocate the zero page");
         hipStream_t fst = static_cast<hipStream_t>(stream);
@@ -952,6 +979,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     a.ln_out = d->ln_out; a.ln_out_stride = d->ln_out_stride; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out_eps = d->ln_out_eps;
     a.ln_tile_w = d->ln_out_tile_w;
     a.ln_tile_rows = d->ln_out_tile_rows; a.ln_out_rows = d->ln_out_rows;
+    a.pool_h = d->pool_h; a.pool_w = d->pool_w;
     S2M2_REQUIRE(d->ln_out_tile_rows == 0 || (d->ln_out_tile_w > 0 && d->ln_out_rows && d->ln_out_tile_rows % d->ln_out_tile_w == 0 && d->ln_out_tile_rows < d->rows),
                  "mlp_chain: ln_out_tile_rows needs ln_out_tile_w, ln_out_rows and a whole number of image rows below `rows`");
     a.fan_w = d->fan_weight; a.fan_b = d->fan_bias; a.fan_wsum = d->fan_ln_wsum; a.fan_out = d->fan_out; a.fan_out_stride = d->fan_out_stride;

@@ -134,6 +134,7 @@ class Engine:
         self.chain_direct_qkv = os.environ.get("S2M2_CHAIN_DIRECT_QKV", "1") != "0"
         self._wfrag = {}
         self.pw_direct = os.environ.get("S2M2_PW_DIRECT", "1") != "0"
+        self.pool_direct = os.environ.get("S2M2_POOL_DIRECT", "1") != "0"            # down_convs (AvgPool2d(2) + 1x1) on the direct K9 form
         self.qkv_direct = os.environ.get("S2M2_QKV_DIRECT", "1") != "0"              # a block's first Q|K|V projection as a fan-out-only launch
         self.chain_direct_ln = os.environ.get("S2M2_CHAIN_DIRECT_LN", "1") != "0"    # the launch that also writes K1's normalised tokens
         # the same for K10 (hip.feature_fusion(frag=True)): S2M2_FUSION_DIRECT=0: off, S2M2_FUSION_DIRECT_MAX: largest row count
@@ -270,6 +271,12 @@ class Engine:
         """nn.AvgPool2d(2) -> Conv2d 1x1 (unet.py:24-29, stacked_MRT.py:21-26): the pooling is folded into the GEMM's operand load (same
         mean, rounded to the activation dtype like the stand-alone K7 launch it replaces)."""
         spec = self.std(p + ".1")
+        c = x.shape[-1]
+        if (self.pool_direct and self.chain_direct and self.fuse_pool and self.dtype == torch.float16 and spec[2] == 1 and spec[3] == 1
+                and x.dim() == 4 and x.shape[1] >= 2 and x.shape[2] >= 2 and tuple(spec[0].shape) in ((c, c), (2 * c, c)) and spec[4] == spec[0].shape[0]
+                and not getattr(spec, "korder", 0) and self.chain_frag_ok(c)):
+            # pooled 1x1 C -> C / C -> 2C: a fan-out-only launch of the direct K9 form, the 2x2 mean formed while the row tile is loaded
+            return hip.mlp_fan(x, self.wfrag(spec), spec[1], None, frag=True, pool2=True)
         if self.fuse_pool and spec[2] == 1 and spec[3] == 1 and x.shape[1] >= 2 and x.shape[2] >= 2:
             return self.cconv(spec, [x], pool2=True)
         return self.cconv(spec, [hip.resample2x(x, 0)])

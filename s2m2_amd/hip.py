@@ -42,7 +42,7 @@ class ChainDesc(ctypes.Structure):
                 ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
                 ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float),
                 ("ln_out_tile_w", _i), ("ln_out_tile_rows", _ll), ("ln_out_rows", _vp), ("fan_weight", _vp), ("fan_bias", _vp), ("fan_ln_wsum", _vp), ("fan_out", _vp), ("fan_out_stride", _ll),
-                ("nfan", _i), ("xcd_group_rows", _ll), ("weight_frag", _i)]
+                ("nfan", _i), ("xcd_group_rows", _ll), ("weight_frag", _i), ("pool_h", _i), ("pool_w", _i)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -455,23 +455,32 @@ def mlp_fan_supported(C: int, nfan: int, dtype: torch.dtype) -> bool:
 
 
 def mlp_fan(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ln_wsum: Optional[torch.Tensor], ln_eps: float = 1e-5,
-            frag: bool = False) -> torch.Tensor:
+            frag: bool = False, pool2: bool = False) -> torch.Tensor:
     """n stacked C -> C layers on the rows of x (..., C) -> (..., n*C) in one pass over the rows (s2m2_mlp_chain with nstage = 0: the
     weights-stationary fan-out form; pre-LayerNorm folded in when ln_wsum is given).  weight packed (n*C, C).  frag: the weight is in
-    MFMA-fragment order (pack.chain_frag) -> the direct form (mlp_chain_frag_supported; any row count, n <= 4)."""
+    MFMA-fragment order (pack.chain_frag) -> the direct form (mlp_chain_frag_supported; any row count, n <= 4).  pool2 (with frag; x
+    (N,H,W,C)): nn.AvgPool2d(2) in front of the layers, folded into the tile load -> (N, H//2, W//2, n*C)."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_fan")
     n = weight.shape[0] // C
+    oshape = tuple(x.shape[:-1])
+    if pool2:
+        if not frag or x.dim() != 4 or x.shape[1] < 2 or x.shape[2] < 2:
+            raise ValueError("mlp_fan: pool2 needs frag and an (N,H,W,C) tensor of at least 2x2 pixels")
+        oshape = (x.shape[0], x.shape[1] // 2, x.shape[2] // 2)
+        rows = oshape[0] * oshape[1] * oshape[2]
     if weight.dtype != x.dtype or tuple(weight.shape) != (n * C, C) or not weight.is_contiguous() or not weight.is_cuda or not x.is_cuda:
         raise ValueError(f"mlp_fan: weight must be a packed (n*{C}, {C}) {x.dtype} device matrix")
     for name, t in (("bias", bias), ("ln_wsum", ln_wsum)):
         if t is not None and (t.dtype != torch.float32 or t.numel() != n * C or not t.is_contiguous() or not t.is_cuda):
             raise ValueError(f"mlp_fan: {name} must be fp32 ({n * C}) on the device")
-    out = torch.empty(tuple(x.shape[:-1]) + (n * C,), device=x.device, dtype=x.dtype)
+    out = torch.empty(oshape + (n * C,), device=x.device, dtype=x.dtype)
     d = ChainDesc()
     d.x, d.x_stride, d.rows, d.C, d.nstage, d.dtype, d.ln_eps = x.data_ptr(), xs, rows, C, 0, _DT[x.dtype], ln_eps
     d.res_stage = -1
     d.weight_frag = int(bool(frag))
+    if pool2:
+        d.pool_h, d.pool_w = x.shape[1], x.shape[2]
     d.fan_weight, d.fan_out, d.fan_out_stride, d.nfan = weight.data_ptr(), out.data_ptr(), n * C, n
     d.fan_bias = bias.data_ptr() if bias is not None else None
     d.fan_ln_wsum = ln_wsum.data_ptr() if ln_wsum is not None else None

@@ -334,3 +334,26 @@ def test_fan_only_direct_form(hip, C, shp, nfan, ln):
     t = F.layer_norm(x.float(), (C,)) if ln else x.float()
     full = F.linear(t, wq.float().reshape(nfan * C, C), bp[:nfan * C])
     assert float((y.float() - full).abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("C,shp,n", [(128, (2, 256, 304), 1), (128, (1, 128, 152), 2), (256, (2, 64, 76), 1), (128, (1, 9, 7), 2), (256, (1, 2, 2), 1)])
+def test_fan_only_direct_form_with_avgpool(hip, C, shp, n):
+    """pool2: nn.AvgPool2d(2) (floor) folded into the tile load of the fan-out-only direct form == the K5 pool2 launch bit for bit (same mean, same rounding
+    of the mean, same k16 order and epilogue), and == F.linear(F.avg_pool2d(x)) on the rounded mean; odd sizes drop the last row / column."""
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(C + shp[1])
+    N, H, W = shp
+    wide = (torch.randn(N, H, W, C + 8, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
+    x = wide[..., :C]                                               # strided pixels
+    wq = (torch.randn(n * C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+    wp = pack.pack_conv(wq, dtype)
+    bp = pack.pack_bias(torch.randn(n * C, device="cuda", generator=g) * 0.3, n * C)
+    y = hip.mlp_fan(x, pack.chain_frag(wp), bp, None, frag=True, pool2=True)
+    assert tuple(y.shape) == (N, H // 2, W // 2, n * C)
+    ref = hip.conv2d([x.contiguous()], wp, bp, 1, 1, n * C, pool2=True)
+    assert ref.shape == y.shape and torch.equal(y, ref)            # same mean, same k16 order, same epilogue: bit for bit (tools/pool_direct_biteq.py)
+    xc = x[:, :H // 2 * 2, :W // 2 * 2].float().reshape(N, H // 2, 2, W // 2, 2, C)
+    mean = ((xc[:, :, 0, :, 0] + xc[:, :, 0, :, 1] + xc[:, :, 1, :, 0] + xc[:, :, 1, :, 1]) * 0.25).to(dtype)
+    assert torch.equal(y, hip.mlp_fan(mean, pack.chain_frag(wp), bp, None, frag=True))     # the pooled tile == the explicit mean, bit for bit
+    full = F.linear(mean.float(), wq.float().reshape(n * C, C), bp[:n * C])
+    assert float((y.float() - full).abs().max()) < 2e-2
