@@ -74,6 +74,20 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     c.C, c.carry, c.res_stage = 128, 1, -1
     c.weight[0] = c.weight[1] = 4096
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"carry" in lib.s2m2_last_error()
+    # round 3: the direct form (weight_frag) exists for fp16 C = 128 / 256 only; the pooled tile load needs it and whole pooled images
+    c = hip.ChainDesc()
+    c.x, c.out, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.out_stride, c.res_stage = 4096, 4096, 384, 1, hip.F16, 8, 384, 384, -1
+    c.weight[0], c.weight_frag = 4096, 1
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"weight_frag" in lib.s2m2_last_error()
+    c.C, c.x_stride, c.out_stride, c.dtype = 128, 128, 128, hip.F32
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"weight_frag" in lib.s2m2_last_error()
+    c.dtype, c.weight_frag, c.pool_h, c.pool_w = hip.F16, 0, 4, 4
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"pool_h" in lib.s2m2_last_error()
+    c.weight_frag, c.rows = 1, 7                                    # 7 rows are not N * 2 * 2 pooled pixels
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"pool_h" in lib.s2m2_last_error()
+    c = hip.ChainDesc()                                            # fan-out only, direct form: nfan 1..4
+    c.x, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.res_stage, c.weight_frag, c.nfan = 4096, 256, 0, hip.F16, 8, 256, -1, 1, 5
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"nfan" in lib.s2m2_last_error()
 
     assert lib.s2m2_feature_fusion_supported(128, hip.F16) == 1 and lib.s2m2_feature_fusion_supported(384, hip.F16) == 0
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 64, 192, 4096, 4096, 4096, 4096, 4096, 0, 0, hip.F16, None) != 0
