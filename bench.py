@@ -21,8 +21,9 @@ The JSON line carries, next to the contract's fields:
                           around every K4 launch, analytic FLOPs 4*N^2*d*heads*batch -> fraction of the dense
                           fp16 MFMA peak (north_star: "MFMA utilisation on the attention GEMMs");
 * ``forward``             multiply-accumulate work of one forward as executed (counted per launch) / time per pair;
-* ``cpu_baseline``        the CPU oracle (port of the reference forward) on this box's host cores: thread-count sweep, 1 warm-up
-                          + 3 timed runs at the best count.
+* ``cpu_baseline``        the reference's own CPU forward (oracle/_ref = the unmodified reference model byte-compiled by
+                          oracle/make_ref.py; kind "reference") on this box's host cores: thread-count sweep, 1 warm-up + 3 timed
+                          runs at the best count.
 
 ``--dry`` (CPU, gloo, no model): exercises launcher, rendezvous, gather and max-over-ranks timing without a GPU (tests).
 """
@@ -85,14 +86,18 @@ def launch_ranks(a) -> int:
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# CPU baseline: the oracle (port of the reference forward), thread sweep
+# CPU baseline: the reference's own CPU forward (oracle/_ref), thread sweep
 # ---------------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(model_type, H, W, refine_iter):
-    """Oracle (CPU restatement of the reference forward, fp32) on this box's host cores, one pair of the benchmark workload per run:
-    1 warm-up, one timed run per thread count in the sweep, 2 more at the best count (value = median of its 3).  Default intra-op
-    thread counts (128 on the GPU box) oversubscribe the oneDNN/ATen kernels: measured 35.7 s per pair at 128 threads in round 1."""
+    """north_star: "next to the reference's own CPU forward timed on the host cores of the same box in the same run".  The UNMODIFIED
+    reference module (oracle/_ref: its model files byte-compiled by oracle/make_ref.py in the build container, shipped with the
+    snapshot; s2m2.py:136-197 under torch.no_grad(), eval, fp32 -- SURVEY.md 8d) on this box's host cores, one pair of the benchmark
+    workload per run, the same seeded weights and images as the GPU leg: 1 warm-up, one timed run per thread count in the sweep, 2 more
+    at the best count (value = median of its 3).  Default intra-op thread counts (128 on the GPU box) oversubscribe the oneDNN / ATen
+    kernels: measured 35.7 s per pair at 128 threads in round 1.  kind "reference"; only if oracle/_ref is missing (a checkout that was
+    never built where /root/reference exists) the repo's own restatement (oracle/s2m2_oracle.py) is timed instead and labelled "port"."""
     import torch
-    from oracle import s2m2_oracle as O
+    from oracle import ref_loader
     from s2m2_amd.spec import MODEL_CONFIGS
     from s2m2_amd.weights import noise_pair, seeded_state_dict
     C, ntr = MODEL_CONFIGS[model_type]
@@ -101,10 +106,26 @@ def cpu_baseline(model_type, H, W, refine_iter):
     default_threads = torch.get_num_threads()
     sweep = sorted({t for t in (8, 16, 32) if t <= ncpu} or {ncpu})
     l, r = noise_pair(H, W, 1, 0)
+    why = ref_loader.why_not()
+    if why is None:
+        kind = "reference"
+        ref = ref_loader.reference_model(sd, C, ntr, True, refine_iter)
+        what = "the unmodified reference S2M2.forward (oracle/_ref, byte-compiled from /root/reference/src/s2m2/core/model by oracle/make_ref.py)"
+
+        def fwd():
+            with torch.no_grad():
+                return ref(l, r)
+    else:
+        kind = "port"
+        from oracle import s2m2_oracle as O
+        what = f"oracle/s2m2_oracle.py (torch CPU restatement; the reference itself is not on this box: {why})"
+
+        def fwd():
+            return O.forward(sd, l, r, True, refine_iter)
 
     def one():
         t0 = time.perf_counter()
-        O.forward(sd, l, r, True, refine_iter)
+        fwd()
         return time.perf_counter() - t0
 
     torch.set_num_threads(sweep[len(sweep) // 2])
@@ -118,11 +139,9 @@ def cpu_baseline(model_type, H, W, refine_iter):
     times[best] += [one(), one()]
     dt = sorted(times[best])[1]
     torch.set_num_threads(default_threads)
-    return {"value": 1.0 / dt, "unit": "pairs/s", "seconds_per_pair": dt, "cores": best, "host_cpus": ncpu, "kind": "port",
+    return {"value": 1.0 / dt, "unit": "pairs/s", "seconds_per_pair": dt, "cores": best, "host_cpus": ncpu, "kind": kind,
             "thread_sweep_seconds": {str(t): [round(x, 3) for x in v] for t, v in times.items()},
-            "port_vs_reference": "oracle 2.1 s vs unmodified reference 3.2 s per 640x480 r=1 pair on the 8 cores of the build container "
-                                 "(same ATen CPU kernels; the oracle skips nn.Module dispatch and the (N,N,32) PE gather)",
-            "sample": f"1 pair {W}x{H} {model_type}-model fp32 refine_iter={refine_iter} per run, oracle/s2m2_oracle.py (torch CPU ops): "
+            "sample": f"1 pair {W}x{H} {model_type}-model fp32 refine_iter={refine_iter} use_positivity=True per run, {what}: "
                       f"1 warm-up, 1 run per thread count, median of 3 at the best count"}
 
 

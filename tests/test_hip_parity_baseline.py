@@ -151,21 +151,7 @@ def test_fp16_640x480_pinned_to_autocast_emulation():
     assert s3["conf"]["p999"] <= 5e-3 and s3["occ"]["p999"] <= 5e-3, s3
 
 
-def _sharp_tokens(C, h, w, shifts, seed, noise=0.05):
-    """Synthetic transformer output (2,C,h,w) with ONE unambiguous match per left pixel: left tokens iid N(0,1) per
-    channel, right token j = left token (j + d) mod w + noise, d = shifts[row band] -- after LayerNorm the matched score is ~C (128)
-    against N(0, sqrt C) for every other column, so neither fp16 rounding of the volume (ulp 0.125 at 128) nor summation order can
-    move an argmax.  Circular shift: every pixel has its match (run without the positivity mask, wrapped matches are negative
-    disparities)."""
-    g = torch.Generator().manual_seed(seed)
-    left = torch.randn(1, C, h, w, generator=g)
-    right = torch.empty_like(left)
-    band = (h + len(shifts) - 1) // len(shifts)
-    for k, d in enumerate(shifts):
-        rows = slice(k * band, min(h, (k + 1) * band))
-        right[:, :, rows] = torch.roll(left[:, :, rows], shifts=-d, dims=3)
-    right = right + noise * torch.randn(1, C, h, w, generator=g)
-    return torch.cat([left, right], 0)
+_sharp_tokens = PU.sharp_tokens
 
 
 def test_fp16_640x480_sharp_matches_free_running():
