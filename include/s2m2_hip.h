@@ -27,7 +27,12 @@ extern "C" {
 
 enum { S2M2_F32 = 0, S2M2_F16 = 1 };
 
-/* library version (major*10000 + minor*100 + patch) and last error text of the calling thread */
+/* ABI version of THIS header (major*10000 + minor*100 + patch).  s2m2_version() returns the value the library was built with: a caller
+ * compares the two before its first call (s2m2_amd/hip.py: load() refuses a library whose major.minor differs from the binding's).
+ * History: 100 = rounds 1-2; 300 = round 3 changed signatures IN PLACE (cv_pitch inserted into s2m2_sinkhorn_regress / s2m2_cv_lookup,
+ * s2m2_conv_desc / s2m2_chain_desc grew epi_cout0, ln_out*, fan_*, weight_frag, pool_h / pool_w) -- a caller built against 100 must be
+ * rebuilt; 400 = round 4 (fused-level entry points added, no existing signature changed). */
+#define S2M2_ABI_VERSION 400
 int s2m2_version(void);
 const char* s2m2_last_error(void);
 /* test aid (not part of the path): fills the LDS of every CU with quiet-NaN patterns, so that a kernel launched next that reads an LDS word it

@@ -532,12 +532,13 @@ def _forward(sd: SD, img0: Tensor, img1: Tensor, use_positivity: bool, refine_it
     cap["feature_4x"] = f4
     py = unet(sd, "feat_pyramid", f4)
     cap["feature_py_4x"] = py[0]
-    z = py
-    for i in range(_count(sd, "transformer.uformer_list")):
-        z = mrt(sd, f"transformer.uformer_list.{i}", *z)
-    tr = z[0].contiguous()
-    if inject and "feature_tr_4x" in inject:
+    if inject and "feature_tr_4x" in inject:                  # (the transformers' output is replaced: they are not run)
         tr = _q(inject["feature_tr_4x"].float()).contiguous()
+    else:
+        z = py
+        for i in range(_count(sd, "transformer.uformer_list")):
+            z = mrt(sd, f"transformer.uformer_list.{i}", *z)
+        tr = z[0].contiguous()
     cap["feature_tr_4x"] = tr
     disp, conf, occ, cv, ind, P = disp_init(sd, tr, use_positivity)
     cap.update(cv=cv, argmax=ind, disp0=disp, conf0=conf, occ0=occ, prob=P)

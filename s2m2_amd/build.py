@@ -39,13 +39,13 @@ def _deps_mtime():
     return m
 
 
-def _compile(src: str, force: bool, hdr_mtime: float) -> str:
+def _compile(src: str, force: bool, hdr_mtime: float, extra=()) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     spath = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
             and os.path.getmtime(obj) > hdr_mtime):
         return obj
-    cmd = [HIPCC, *FLAGS, *DEFINES, "-c", spath, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *DEFINES, *extra, "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
@@ -54,13 +54,25 @@ def _compile(src: str, force: bool, hdr_mtime: float) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def config_key() -> str:
+    """what the objects under OBJ were compiled with: library suffix, extra defines, compiler version (keys the check_isa stamp)"""
+    import hashlib
+    try:
+        ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        ver = "?"
+    return hashlib.sha256((SUFFIX + "|" + " ".join(DEFINES) + "|" + ver).encode()).hexdigest()[:12]
+
+
+def build(force: bool = False, verbose: bool = True, extra_defines=()) -> str:
+    """extra_defines: appended to S2M2_BUILD_DEFINES for this call (forces a full rebuild when given)"""
+    force = force or bool(extra_defines)
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = sources()
     hdr = _deps_mtime()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, hdr, tuple(extra_defines)), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]

@@ -66,12 +66,18 @@ __device__ __forceinline__ raw16_t global_load16(const void* p) {
 //     be in flight: loads return in order) followed by settle() on its register;
 //   * every such load IS consumed that way (or drained with wait_vmcnt<0>() + settle()): a destination register whose value is
 //     never used is free for the allocator while the load is still in flight.
-template <bool ASYNC = true>
+// Build switch (-DS2M2_UNTRACKED_LOADS=0): every default use becomes a TRACKED load and the counted waits no-ops -- slower (the
+// compiler sinks the requests towards their uses) but independent of the scheduling assumptions tools/check_isa.py guards; what
+// __graft_entry__.build() falls back to under S2M2_ISA_FALLBACK=1 when a compiler fails that check.
+#ifndef S2M2_UNTRACKED_LOADS
+#define S2M2_UNTRACKED_LOADS 1
+#endif
+template <bool ASYNC = (S2M2_UNTRACKED_LOADS != 0)>
 __device__ __forceinline__ void global_load16_async(raw16_t& dst, const void* p) {
     if constexpr (ASYNC) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));   // no "memory" clobber: it would pin every LDS access around it
     else dst = global_load16(p);                                  // tracked: the counted waits become no-ops
 }
-template <int N, bool ASYNC = true> __device__ __forceinline__ void wait_vmcnt() {
+template <int N, bool ASYNC = (S2M2_UNTRACKED_LOADS != 0)> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (ASYNC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));   // ordered against the loads / settle() by volatility alone
 }
 __device__ __forceinline__ void settle(raw16_t& v) { asm volatile("" : "+v"(v)); }

@@ -93,5 +93,5 @@ extern "C" int s2m2_debug_poison_lds(void* stream) {
     return check_launch("debug_poison_lds");
 }
 
-extern "C" int s2m2_version(void) { return 100; }          // 0.1.0
+extern "C" int s2m2_version(void) { return S2M2_ABI_VERSION; }   // include/s2m2_hip.h
 extern "C" const char* s2m2_last_error(void) { return s2m2::g_err; }

@@ -52,10 +52,12 @@ MAX_PIXELS = 1 << 24            # K5 addresses N*H*W pixels of one tensor with 2
 LDS_BYTES = 160 * 1024
 
 
-def check_limits(H: int, W: int, C: int, B: int = 1, dtype: Optional[torch.dtype] = None) -> None:
+def check_limits(H: int, W: int, C: int, B: int = 1, dtype: Optional[torch.dtype] = None, use_pe: bool = True) -> None:
     """Geometry limits of the kernel library, validated before the first launch (they raise inside the C ABI otherwise).  With a
-    dtype the positional-encoding attention of the feature pyramid (2B images, 8 heads of C/4 channels on the 1/32 token grid:
-    marginal-bin tiles + sinc tables next to the K/V stages in 160 KB of LDS) is planned by the library itself."""
+    dtype the attention of the feature pyramid at 1/32 (2B images, 8 heads of C/4 channels) is planned by the library itself: with
+    ``use_pe`` (the checkpoint has ``enc3s.*.pe_proj``: positional-encoding variant, marginal-bin tiles + sinc tables next to the K/V
+    stages in 160 KB of LDS, token grids up to 96 x 96), without it the plain key-split form, which has no grid limit.  Call it with the
+    tensors' device current (the planner asks that device's LDS grant)."""
     if C not in (64, 128, 192, 256, 384):
         raise ValueError(f"feature_channels={C}: K1 is instantiated for 64, 128, 192, 256 and 384 channels")
     if 2 * H * W >= MAX_PIXELS:
@@ -65,9 +67,10 @@ def check_limits(H: int, W: int, C: int, B: int = 1, dtype: Optional[torch.dtype
         raise ValueError(f"image width {W}: K2 keeps a cost-volume row's potentials in LDS, at most {4 * (LDS_BYTES // 136 - 1)} px wide")
     if dtype is not None:
         gh, gw = H // 32, W // 32
-        ok, why = hip.attention_supported(2 * min(B, max_batch(H, W)), 8, gh * gw, C // 4, dtype, grid=(gw, gh))
+        ok, why = hip.attention_supported(2 * min(B, max_batch(H, W)), 8, gh * gw, C // 4, dtype, grid=(gw, gh) if use_pe else None)
         if not ok:
-            raise ValueError(f"{W}x{H}: the positional-encoding attention at 1/32 resolution does not take a {gw}x{gh} token grid ({why})")
+            what = "positional-encoding attention" if use_pe else "attention"
+            raise ValueError(f"{W}x{H}: the {what} at 1/32 resolution does not take a {gw}x{gh} token grid ({why})")
 
 
 def max_batch(H: int, W: int) -> int:
@@ -726,9 +729,27 @@ class Engine:
         normed = self._tokens_normed
         if cap is not None and "feature_tr_4x" in (cap.get("inject") or {}):           # parity tests only, see finish()
             tr = cap["inject"]["feature_tr_4x"].to(tr.device, tr.dtype).permute(0, 2, 3, 1).contiguous()
-            normed = None                                         # injected tokens: K1 normalises them itself
+            normed = self._normed_like_the_forward(tr) if normed is not None else None
         cv = self.cost_volume(tr, banded=cap is None, normed=normed)   # captured runs hand out the full volume, like the reference
         return self.finish(tr, py0, f2_left, x8, cv, cap)
+
+    def _normed_like_the_forward(self, tr: Tensor):
+        """Parity tests only (injected ``feature_tr_4x``).  In a free-running forward DispInit's LayerNorm is the second output of the K9
+        launch that writes the tokens (attn_ffn) and K1 is the correlation alone (s2m2_corr) -- the kernel bench.py's roofline line
+        measures.  So that injected runs exercise THAT pair and not K1's own-LayerNorm form, the injected tokens go through the same
+        launch form: a one-stage K9 chain with an identity weight (x * 1 summed with zeros in fp32 is exact in both modes) whose
+        LayerNorm output feeds hip.corr.  Row-major outputs only (the opt-in fragment-ordered K1 forms keep K1's own LayerNorm)."""
+        if not isinstance(self._tokens_normed, Tensor):
+            return None
+        n, h, w, c = tr.shape
+        eye = self._packed.get("identity|k9")
+        if eye is None:
+            eye = self._packed["identity|k9"] = Spec((torch.eye(c, device=tr.device, dtype=tr.dtype).contiguous(), None, 1, 1, c))
+        grp = (h // 8) * w if h % 8 == 0 else 0
+        ln_out = (self.ln_w, self.ln_b, 1e-5)
+        if self.chain_direct and self.chain_direct_ln and self.fuse_ln and self.chain_frag_ok(c, self.dtype):
+            return hip.mlp_chain(tr, [(self.wfrag(eye), None, hip.ACT_NONE, None)], ln_out=ln_out, xcd_group_rows=grp, frag=True)[1]
+        return hip.mlp_chain(tr, [(eye[0], None, hip.ACT_NONE, None)], ln_out=ln_out, xcd_group_rows=grp)[1]
 
     def _conv0(self) -> Spec:
         """cnn_backbone.conv0.0 (1x1, 3 -> 16) reading the RGB planes from channels 1..3 of the 8-channel input tensor."""

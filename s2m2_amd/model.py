@@ -142,7 +142,9 @@ class S2M2(nn.Module):
         if img0.shape[-1] % 32 or img0.shape[-2] % 32:
             raise ValueError("image height and width must be multiples of 32 (pad with image_pad first)")
         from .engine import GraphRunner, check_limits, max_batch
-        check_limits(img0.shape[2], img0.shape[3], self.feature_channels, img0.shape[0], dtype)
+        with self._lock, torch.cuda.device(img0.device):         # the planner queries the images' device
+            check_limits(img0.shape[2], img0.shape[3], self.feature_channels, img0.shape[0], dtype,
+                         use_pe="feat_pyramid.enc3s.0.self_attn.attn.pe_proj.weight" in self._table)
         nb = max_batch(img0.shape[2], img0.shape[3])
         if img0.shape[0] > nb:                                   # K5 indexes pixels with 24 bits: large batches run in slices
             if capture is not None:

@@ -54,23 +54,37 @@ def gather_outputs(out: Sequence[torch.Tensor], dist, dst: int = 0, group=None) 
     return gather_outputs_async(out, dist, dst, group).wait()
 
 
+def padded_shard(n_pairs: int, rank: int, world: int) -> Tuple[List[int], int]:
+    """This rank's pair indices padded to the common shard size ceil(n / world) -> (indices, number that are real).  Ranks whose share is
+    one short (n % world != 0) repeat their last pair -- or pair 0 if they have none -- so that every rank runs the same launch sequence
+    and the gather stays ONE fixed-size collective; the padding results are dropped by the receiver."""
+    idx = shard_indices(n_pairs, rank, world)
+    real = len(idx)
+    per = -(-n_pairs // world)
+    return idx + [idx[-1] if idx else 0] * (per - real), real
+
+
 def run_sharded(forward: Callable[[torch.Tensor, torch.Tensor], Sequence[torch.Tensor]], left: torch.Tensor,
                 right: torch.Tensor, dist, dst: int = 0, group=None):
     """Every rank holds (or can index) the full batch of pairs; it processes its shard and rank ``dst`` receives all
-    outputs in the original pair order.  Requires n_pairs % world == 0 (equal shards -> one fixed-size gather)."""
+    outputs in the original pair order.  Any n_pairs >= 1: shards are padded to ceil(n / world) pairs (``padded_shard``: pad and drop),
+    so the exchange is one fixed-size gather whatever n is."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = left.shape[0]
-    if n % world:
-        raise ValueError(f"{n} pairs do not shard evenly over {world} ranks")
-    idx = shard_indices(n, rank, world)
+    if n < 1:
+        raise ValueError("run_sharded: no pairs")
+    idx, _ = padded_shard(n, rank, world)
     out = forward(left[idx], right[idx])
     g = gather_outputs(out, dist, dst, group)
     if g is None:
         return None
-    per = n // world
-    order = torch.tensor([p for r in range(world) for p in shard_indices(n, r, world)])
-    inv = torch.empty_like(order)
-    inv[order] = torch.arange(n)
-    assert per * world == n
-    return tuple(t[inv.to(t.device)] for t in g)
+    per = -(-n // world)
+    res = [torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in g]
+    for r in range(world):                                  # rank-major blocks of `per` entries; the first `real` of each are pairs
+        real_idx = shard_indices(n, r, world)
+        if real_idx:
+            sel = torch.tensor(real_idx, device=g[0].device)
+            for dst_t, src_t in zip(res, g):
+                dst_t[sel] = src_t[r * per:r * per + len(real_idx)]
+    return tuple(res)

@@ -105,7 +105,7 @@ def compute_confidence_scores(model: S2M2, lefts: torch.Tensor, rights: torch.Te
 
     With ``dist`` (an initialised ``torch.distributed`` module, one rank per GPU) the pairs are sharded round-robin over the ranks
     of ``group`` -- every rank passes the full population -- and every rank receives all N scores: the only collective is one
-    all-gather of N/world floats per rank.  Returns a float32 CPU tensor (N,)."""
+    all-gather of ceil(N/world) floats per rank (N need not divide: short shards are padded and the padding dropped).  Returns a float32 CPU tensor (N,)."""
     N = lefts.shape[0]
     if rights.shape != lefts.shape or lefts.dim() != 4:
         raise ValueError(f"expected two (N,3,H,W) batches, got {tuple(lefts.shape)} and {tuple(rights.shape)}")
@@ -115,11 +115,9 @@ def compute_confidence_scores(model: S2M2, lefts: torch.Tensor, rights: torch.Te
     idx = list(range(N))
     world = rank = 1
     if dist is not None:
-        from .shard import shard_indices
+        from .shard import padded_shard, shard_indices
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        if N % world:
-            raise ValueError(f"{N} pairs do not shard evenly over {world} ranks")
-        idx = shard_indices(N, rank, world)
+        idx, _ = padded_shard(N, rank, world)                # N % world != 0: pad and drop, the all-gather stays fixed-size
     step = batch or max(1, len(idx))
     scores = []
     for s0 in range(0, len(idx), step):
@@ -137,5 +135,6 @@ def compute_confidence_scores(model: S2M2, lefts: torch.Tensor, rights: torch.Te
     dist.all_gather(parts, mine, group=group)
     out = torch.empty(N, dtype=torch.float32)
     for r in range(world):
-        out[shard_indices(N, r, world)] = parts[r].float().cpu()
+        real = shard_indices(N, r, world)
+        out[real] = parts[r][:len(real)].float().cpu()
     return out

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Build-time guard of the scheduling assumptions behind K5 v5 (conv_frag_kernel, s2m2_amd/csrc/conv.hip) and the direct form of K10
-(feature_fusion_direct_kernel, s2m2_amd/csrc/fusion.hip).
+"""Build-time guard of the scheduling assumptions behind K5 v5 (conv_frag_kernel, s2m2_amd/csrc/conv.hip), the direct form of K10
+(feature_fusion_direct_kernel, s2m2_amd/csrc/fusion.hip) and the shipped K1 (ln_corr_kernel<PRENORM>, s2m2_amd/csrc/ln_corr.hip: s2m2_corr).
 
 The kernel prefetches its weight fragments with loads the compiler does NOT track (common.h: global_load16_async) and waits for them with
 hand-counted ``s_waitcnt vmcnt(N)``.  That is only correct while, inside the K loop,
@@ -18,6 +18,14 @@ feature_fusion_direct_kernel is one straight-line block (fully unrolled k16 step
 last fragment request -- while the ring is being refilled every ring register is either in flight or about to feed an MFMA -- and, besides
 the two properties above, every ``s_waitcnt vmcnt(N)`` in the region must carry the same N >= 8 (ring depth - 1: the prefetch distance the
 kernel was written for is what the generated code has).
+
+ln_corr_kernel<..., PRENORM = true> (the default K1 of the forward, and its hybrid left-fragment branch) requests all of its tokens with the
+same untracked loads and counted waits.  Checked over the whole kernel with the in-order memory model the compiler itself uses on gfx9
+(vmcnt counts loads and stores in issue order; ``s_waitcnt vmcnt(N)`` retires all but the youngest N):
+  a. no instruction reads or overwrites the destination of a load that may still be in flight;
+  b. no load is in flight across a label or a branch (a register copy at a control-flow merge would read it early);
+  c. the token burst is really in flight together: the deepest queue reaches RIF * PPL (* 2 with EARLY_B) loads -- the optimiser has not
+     sunk the requests next to their LDS stores again (29 us instead of 22).
 """
 import os
 import re
@@ -123,6 +131,74 @@ def check_straight_line(name: str, lines):
     return problems, 1
 
 
+def check_inflight(name: str, lines, expect_depth: int):
+    """properties a-c of the module docstring for one ln_corr_kernel<PRENORM> instantiation"""
+    problems, queue, deepest = [], [], 0                             # queue: destination register sets of loads (empty set: a store)
+    for raw in lines:
+        ln = raw.strip()
+        if re.match(r"^\.LBB\S*:", ln) or ln.startswith(("s_cbranch", "s_branch", "s_barrier")):
+            if any(q for q in queue):
+                problems.append(f"{name}: {sum(1 for q in queue if q)} load(s) in flight across control flow at: {ln.split(';')[0].strip()}")
+            continue
+        l = ln.split(";")[0].strip()
+        if not l or l.startswith("."):
+            continue
+        m = re.search(r"s_waitcnt\b.*vmcnt\((\d+)\)", l)
+        if m:
+            n = int(m.group(1))
+            queue = queue[len(queue) - n:] if n < len(queue) else queue
+            if n == 0:
+                queue = []
+            continue
+        if l.startswith("s_waitcnt") or l.startswith("s_"):
+            continue
+        ops = [t.strip().rstrip(",") for t in l.split()[1:]]
+        if l.startswith(("global_load", "buffer_load")):
+            flying = set().union(*queue) if queue else set()
+            for t in ops[1:]:
+                if regs_of(t) & flying:
+                    problems.append(f"{name}: address of a load reads a register whose load may be in flight: {l}")
+            queue.append(regs_of(ops[0]))
+            deepest = max(deepest, sum(1 for q in queue if q))
+            continue
+        flying = set().union(*queue) if queue else set()
+        if l.startswith(("global_store", "buffer_store")):
+            for t in ops:
+                if regs_of(t) & flying:
+                    problems.append(f"{name}: store reads a register whose load may be in flight: {l}")
+            queue.append(set())
+            continue
+        if not flying:
+            continue
+        for t in ops:                                                 # sources and destinations alike: neither may touch a flying register
+            if regs_of(t) & flying:
+                problems.append(f"{name}: instruction touches a register whose load may be in flight: {l}")
+    if deepest < expect_depth:
+        problems.append(f"{name}: at most {deepest} loads in flight together, expected the whole token burst ({expect_depth})")
+    return problems, deepest
+
+
+def check_ln_corr(text):
+    """every ln_corr_kernel<LnCorrCfg<T, TO, C, NWCAP, RIF, EARLY_B, PIPE, TPW, PRENORM = true>> instantiation"""
+    bad, seen = [], 0
+    for name, lines in functions(text, "_ZN4s2m214ln_corr_kernel").items():
+        # (parsed from the mangled name: this c++filt does not know DF16_ = _Float16)
+        m = re.search(r"LnCorrCfgI(DF16_|f)(DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb([01])ELb([01])ELi(\d+)ELb([01])E", name)
+        if not m or m.group(9) != "1":
+            continue
+        seen += 1
+        a = ["fp16" if m.group(1) != "f" else "fp32", "fp16" if m.group(2) != "f" else "fp32"]
+        C, rif, early = int(m.group(3)), int(m.group(5)), m.group(6) == "1"
+        vec = 4 if m.group(1) == "f" else 8
+        expect = rif * (C // vec // 8) * (2 if early else 1)
+        problems, deepest = check_inflight(name, lines, expect)
+        print(f"check_isa: ln_corr_kernel<{a[0]} -> {a[1]}, C={C}, PRENORM>: {deepest} loads in flight (expected {expect}), {len(problems)} problem(s)")
+        bad += problems
+    if seen == 0:
+        bad.append("ln_corr.hip: no PRENORM instantiation of ln_corr_kernel found in the assembly")
+    return bad
+
+
 def compile_asm(src: str, asm: str):
     defines = os.environ.get("S2M2_BUILD_DEFINES", "").split()
     r = subprocess.run([HIPCC, *FLAGS, *defines, src, "-o", asm], capture_output=True, text=True)
@@ -153,9 +229,10 @@ def main() -> int:
     with tempfile.TemporaryDirectory() as td:
         text = compile_asm(SRC, keep or os.path.join(td, "conv.s"))
         ftext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "fusion.hip"), os.path.join(td, "fusion.s"))
-        if text is None or ftext is None:
+        ktext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "ln_corr.hip"), os.path.join(td, "ln_corr.s"))
+        if text is None or ftext is None or ktext is None:
             return 2
-    bad = []
+    bad = check_ln_corr(ktext)
     ffuncs = functions(ftext, "_ZN4s2m228feature_fusion_direct_kernel")
     if not ffuncs:
         print("check_isa: no feature_fusion_direct_kernel instantiation found in the assembly")
