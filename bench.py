@@ -382,10 +382,9 @@ def main():
         k1_bytes = B * (2 * h * w * C * e + h * w * w * e)         # read both feature maps once + write cv once
         k1_variant = "full volume (B,h,w,w)"
         if eng._tokens_normed is not None:                         # DispInit's LayerNorm ran in the K9 launch that wrote the tokens (engine.features)
-            k1_variant += ", tokens normalised by the producing K9 launch (s2m2_corr), volume rows on 128-byte lines" if eng.cv_aligned else \
-                          ", tokens normalised by the producing K9 launch (s2m2_corr)"
-        if isinstance(eng._tokens_normed, hip.HybridTokens):
-            k1_variant += ", left tokens in MFMA-fragment order (s2m2_corr_hybrid)"
+            k1_variant += ", tokens normalised by the producing K9 launch (s2m2_corr), volume rows on 128-byte lines"
+        else:
+            k1_variant += ", LayerNorm inside K1 (s2m2_ln_corr)"
         if eng.cv_band >= 0:                                       # opt-in banded store (S2M2_CV_BAND=1): only j <= i + band must be written
             k1_bytes = B * (2 * h * w * C * e + h * e * sum(min(w, i + 1 + eng.cv_band) for i in range(w)))
             k1_variant = f"banded volume j <= i + {eng.cv_band}"

@@ -85,29 +85,11 @@ int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, 
  */
 int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
               void* stream, void* start_event, void* stop_event);
-/* measurement aid (not part of the path; tools/k1_store_path.py): K1's store pattern alone -- mode 0: one block per volume row, 32 rows per
- * wave in 128-byte segments exactly like the kernel's store loop, no loads / MFMA; 1: the same with non-temporal stores; 2 / 3: the same
- * bytes as one linear stream (3: non-temporal).  fp16 volume of `rows` rows of w x cv_pitch; events as s2m2_ln_corr_timed. */
-int s2m2_debug_store_pattern(void* cv, int rows, int w, int cv_pitch, int mode, void* stream, void* start_event, void* stop_event);
-/*
- * [A4] K1 in its streaming form: the correlation on fp16 tokens that are normalised AND stored in MFMA-fragment order by the launch that
- *   produced them (s2m2_chain_desc.ln_out_tile_w).  No LDS staging of tokens, no block barrier: a wave owns 32 left tokens in registers
- *   and streams the right row tile by tile with coalesced 1 KB fragment loads, so the loads of one wave run under the stores of another
- *   (the LDS form of s2m2_corr / s2m2_ln_corr loads, meets at a barrier, then stores: with one image row per CU the two phases add up).
- *   tokens_tiled: s2m2_corr_tiled_bytes(B, h, w, C) bytes; cv, cv_pitch, band, events: as s2m2_corr.  C = 64 / 128 / 256 (fp16 volume),
- *   128 (fp32 volume).
- */
-size_t s2m2_corr_tiled_bytes(int B, int h, int w, int C);
-int s2m2_corr_tiled(const void* tokens_tiled, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype, int band,
-                    void* stream, void* start_event, void* stop_event);
-/*
- * [A4] K1 on normalised tokens with the LEFT tokens in MFMA-fragment order (the tiled half written by s2m2_mlp_chain with
- *   ln_out_tile_rows = B*h*w) and the RIGHT tokens row-major ((B, h, w, C) fp16): the LDS form of s2m2_corr, except that a wave's 32 left
- *   tokens go from global memory straight into its MFMA operand registers (coalesced 1 KB fragment loads) instead of through an LDS bounce.
- *   left_tiled: s2m2_corr_tiled_bytes(B, h, w, C) / 2 bytes.  cv, cv_pitch, band, events as s2m2_corr; fp16 tokens.
- */
-int s2m2_corr_hybrid(const void* left_tiled, const void* right_rows, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype, int band,
-                     void* stream, void* start_event, void* stop_event);
+/* [A4] s2m2_ln_corr (LayerNorm inside K1) with every option of s2m2_corr: cv_pitch (0 = dense rows), band (-1 = full volume) and the
+ * start / stop events on the dispatch (may be NULL).  What the engine launches for widths whose producing K9 launch has no LayerNorm
+ * output (C = 192, 384) and under S2M2_FUSE_K1LN=0, on the same 128-byte-aligned volume as s2m2_corr. */
+int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
+                         int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event);
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);
@@ -245,14 +227,6 @@ typedef struct s2m2_chain_desc {
     const float* ln_gamma;
     const float* ln_beta;
     float ln_out_eps;
-    /* > 0 (fp16 only): ln_out is written in the MFMA-fragment order s2m2_corr_tiled reads -- the rows are image rows of ln_out_tile_w
-       tokens, cut into 32-token tiles; the 16-byte piece (token x of image row r, channels 8p .. 8p+7) goes to 16-byte slot
-       ((r * ceil(w/32) + x/32) * (C/16) + p/2) * 64 + (p%2) * 32 + x%32 of a buffer of s2m2_corr_tiled_bytes(); ln_out_stride is ignored. */
-    int ln_out_tile_w;
-    /* > 0 (with ln_out_tile_w): only rows [0, ln_out_tile_rows) -- the LEFT images of a stereo batch -- go to the tiled buffer `ln_out`; the rows
-       from ln_out_tile_rows on are written row-major to ln_out_rows + (row - ln_out_tile_rows) * ln_out_stride (consumed by s2m2_corr_hybrid). */
-    long long ln_out_tile_rows;
-    void* ln_out_rows;
     /* fan-out stages, nfan = 0: none.  nfan further C -> C layers that ALL read the chain's `out` rows (while they are still in LDS) and
        write fan_out[:, f*C:(f+1)*C] = W_f . (fan_ln_wsum ? LayerNorm(out rows) : out rows) + b_f  -- the Q | K | V projection of the attention
        block that follows (reference attentions.py:24-28,71-74 behind the pre-norm of :117,148), fused into the launch that produces its
@@ -273,7 +247,7 @@ typedef struct s2m2_chain_desc {
        registers, one whole stage ahead, no weight tile in LDS and no block barrier inside a stage.  For SHORT row counts (the 1/32 .. 1/8
        pyramid levels: a block lives for the latency of its weight stream, not for its arithmetic).  fp16, C = 128 / 256: ask
        s2m2_mlp_chain_frag_supported.  Same arithmetic and rounding points as the row-major form.  With nstage = 0 and nfan = 1 .. 4 the
-       fan-out layers alone run in this form (any row count; without weight_frag nstage = 0 needs s2m2_mlp_fan_supported). */
+       fan-out layers alone run in this form (any row count; nstage = 0 exists in this form only: ask s2m2_mlp_fan_supported). */
     int weight_frag;
     /* > 0 (with weight_frag): x is an image tensor (N, pool_h, pool_w, C) with pixel stride x_stride, and row m = (n, yo, xo) of the
        (pool_h/2, pool_w/2) grid is the mean of its four pixels (2yo, 2xo) .. (2yo+1, 2xo+1): nn.AvgPool2d(2) in front of the 1x1 layer(s)
@@ -283,8 +257,8 @@ typedef struct s2m2_chain_desc {
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);
 int s2m2_mlp_chain_frag_supported(int C, int dtype);
-/* nstage = 0 with nfan > 0 ("fan-out only": the nfan layers read the x rows themselves -- a Q | K | V projection as ONE pass over the rows,
- * the stacked weight resident in LDS): 1 where the library has that form (fp16, C = 128, nfan 1..3), else 0 */
+/* nstage = 0 with nfan > 0 ("fan-out only": the nfan layers read the x rows themselves -- a Q | K | V projection, or a pooled down_conv, as
+ * ONE pass over the rows): 1 where the library has that form (the direct form, weight_frag = 1: fp16, C = 128 / 256, nfan 1..4), else 0 */
 int s2m2_mlp_fan_supported(int C, int nfan, int dtype);
 int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
 

@@ -50,9 +50,6 @@ struct ChainArgs {
     void* fan_out;
     long long fan_out_stride;
     int nfan;
-    int ln_tile_w;                      // > 0: ln_out in the MFMA-fragment order of s2m2_corr_tiled, the rows being image rows of ln_tile_w tokens
-    long long ln_tile_rows;             // > 0 (with ln_tile_w): only rows below this index go to the tiled buffer `ln_out`; rows at or above it are
-    void* ln_out_rows;                  //   written row-major to ln_out_rows + (m - ln_tile_rows) * ln_out_stride  (s2m2_corr_hybrid: left images tiled)
     // > 0: row tiles are handed to blocks so that the XCD a block runs on (hardware: block b on XCD b % 8) owns the tiles of ONE eighth of
     // every image -- xcd_tiles consecutive tiles per image and XCD.  The consumer K1 places image row y on XCD y / (h / 8): it then finds the
     // normalised tokens in the L2 of the XCD that wrote them.
@@ -328,18 +325,7 @@ struct ChainStage {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
                     if (m < p.rows) {
-                        if (sizeof(T) == 2 && p.ln_tile_w > 0 && p.ln_tile_rows > 0 && m >= p.ln_tile_rows) {
-                            *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out_rows) + (m - p.ln_tile_rows) * p.ln_out_stride + pcx * VEC) = o;
-                        } else if (sizeof(T) == 2 && p.ln_tile_w > 0) {
-                            // fragment order: 32-token tile t of image row rid, k16 step kk = pcx / 2, half hh = pcx % 2 -> 16-byte slot
-                            // ((rid * NT + t) * KS + kk) * 64 + hh * 32 + token % 32   (what a lane of K1 loads for its MFMA operand)
-                            const long long rid = m / p.ln_tile_w;
-                            const int x = (int)(m - rid * p.ln_tile_w);
-                            const long long slot = ((rid * ((p.ln_tile_w + 31) >> 5) + (x >> 5)) * (C / 16) + (pcx >> 1)) * 64 + (pcx & 1) * 32 + (x & 31);
-                            reinterpret_cast<Vec16<T>*>(p.ln_out)[slot] = o;
-                        } else {
-                            *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
-                        }
+                        *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
                     }
                 }
             }
@@ -530,349 +516,6 @@ __global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// K9, weights-stationary form (fp16, C = 128; long row counts).  The streaming kernel above re-reads the chain's weights (96 KB for three
-// stages) per 64-row tile and meets at a block barrier per 64-byte chunk of K -- 4 MFMAs per wave between barriers: at 1/4 resolution a
-// block lives ~8 us for 0.7 us of MFMA work (profiles/r03/layer_trace_eager.txt: 230-280 TF/s).  Here a PERSISTENT block copies every
-// weight of the chain into LDS once (XOR-swizzled 16-byte pieces: conflict-free ds_read_b128 without padding) and walks over row tiles:
-//   * 8 waves = 2 groups x 4; a group owns one 32-row tile per step, a wave 32 rows x 32 couts, the whole K = 128 of a stage without a
-//     barrier (A tile and weights are both resident);
-//   * ONE block barrier per stage (the output tile of a stage is the A operand of the next), two buffers per group;
-//   * the next tile's input and residual rows are requested before the first stage of the current one and land under its three stages.
-// Same arithmetic and rounding points as the streaming kernel (tests/test_hip_chain.py runs both against the same references).
-// ---------------------------------------------------------------------------------------------------------------
-template <int NST_>
-struct ChainWsCfg {
-    static constexpr int C = 128, BM = 32, NST = NST_, NG = 2, NWG = 4, NT = 64 * NG * NWG, GT = 64 * NWG;
-    static constexpr int VEC = 8, ARS = C + VEC, CRS = ARS, KSTEPS = C / 16, PPR = C / VEC;
-    static constexpr int WM = BM, MT = 1, WN = 32, NTL = 1;
-    static constexpr int X_IT = BM * PPR / GT;                   // 16-byte pieces per thread and tile
-    static constexpr size_t W_BYTES = (size_t)NST * C * C * sizeof(half_t);
-    static constexpr size_t A_BYTES = (size_t)BM * ARS * sizeof(half_t);
-    static constexpr size_t CV_BYTES = (size_t)NST * 2 * C * sizeof(float);          // bias and rowsum(W) of every stage
-    static constexpr size_t LDS_BYTES = W_BYTES + (size_t)NG * 2 * A_BYTES + CV_BYTES;
-    static_assert(X_IT * GT == BM * PPR && LDS_BYTES <= 160 * 1024, "weights-stationary chain tile");
-};
-
-template <int NST>
-__global__ __launch_bounds__(ChainWsCfg<NST>::NT) void mlp_chain_ws_kernel(ChainArgs p, int ntiles) {
-    using CFG = ChainWsCfg<NST>;
-    using T = half_t;
-    constexpr int C = CFG::C, VEC = CFG::VEC, ARS = CFG::ARS, PPR = CFG::PPR, GT = CFG::GT, X_IT = CFG::X_IT, BM = CFG::BM;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Wt = reinterpret_cast<T*>(smem);                           // [NST][C][C], piece pc of row r at slot pc ^ (r & 15)
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave / CFG::NWG, wn = wave - g * CFG::NWG;      // row-tile group, cout tile of this wave
-    const int gt = tid - g * GT;                                  // thread inside the group
-    T* A0 = reinterpret_cast<T*>(smem + CFG::W_BYTES + (size_t)(2 * g) * CFG::A_BYTES);
-    T* A1 = A0 + BM * ARS;
-    // per-cout fp32 vectors in LDS too: read per stage with ds_read -- as global loads they would be YOUNGER than the row prefetches, and
-    // waiting for them (loads return in order) would drain the prefetch at the first epilogue of every tile
-    float* Cv = reinterpret_cast<float*>(smem + CFG::W_BYTES + (size_t)CFG::NG * 2 * CFG::A_BYTES);      // [NST][2][C]
-    for (int q = tid; q < NST * 2 * C; q += CFG::NT) {
-        const int st = q / (2 * C), r = q - st * 2 * C;
-        const float* src = r < C ? p.b[st] : p.wsum[st];
-        Cv[q] = src ? src[r < C ? r : r - C] : 0.f;
-    }
-
-    // ---- every weight of the chain -> LDS, once per block
-#pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        const T* wsrc = static_cast<const T*>(p.w[st]);
-        for (int q = tid; q < C * PPR; q += CFG::NT) {
-            const int r = q / PPR, pc = q - r * PPR;
-            *reinterpret_cast<raw16_t*>(Wt + (size_t)st * C * C + (size_t)r * C + ((pc ^ (r & 15)) * VEC)) = global_load16(wsrc + (size_t)r * C + pc * VEC);
-        }
-    }
-    const int npair = (ntiles + 1) >> 1;
-    const int niter = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // uniform for the block (>= 1: grid <= npair)
-    auto fetch_rows = [&](long long m0, const void* src, long long stride, raw16_t (&r)[X_IT]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) {
-            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
-            const long long m = m0 + row;
-            const T* q = (src != nullptr && m < p.rows) ? static_cast<const T*>(src) + m * stride + pcx * VEC : static_cast<const T*>(p.zero);
-            r[it] = global_load16(q);
-        }
-    };
-    const bool res_any = p.res_stage >= 0;
-    // input and residual rows of the current tile and of the next TWO (one block per CU: the bytes in flight hide the memory latency,
-    // not co-resident blocks -- with one tile ahead a step took 5.5 us, the latency of its own loads)
-    raw16_t xr[X_IT], rr[X_IT], xn[X_IT], rn[X_IT], xn2[X_IT], rn2[X_IT];
-    const long long mstep = (long long)2 * gridDim.x * BM;
-    long long m0 = ((long long)2 * blockIdx.x + g) * BM;
-    fetch_rows(m0, p.x, p.x_stride, xr);
-    fetch_rows(m0, res_any ? p.res : nullptr, p.res_stride, rr);
-    fetch_rows(m0 + mstep, p.x, p.x_stride, xn);                  // (rows past the end read the zero page)
-    fetch_rows(m0 + mstep, res_any ? p.res : nullptr, p.res_stride, rn);
-
-    const bool ln2 = p.ln_out != nullptr;
-    float g2[VEC], b2[VEC];
-    if (ln2) {
-        const int pcx = gt % PPR;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) { g2[e] = p.ln_gamma[pcx * VEC + e]; b2[e] = p.ln_beta[pcx * VEC + e]; }
-    }
-    const int sw = l31 & 15;                                      // swizzle key of this lane's weight row (wn * 32 + l31)
-
-    for (int iter = 0; iter < niter; ++iter) {
-        __syncthreads();                                          // previous tile's store pass has read A0 / A1 (first pass: weights visible)
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) {
-            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
-            *reinterpret_cast<raw16_t*>(A0 + (size_t)row * ARS + pcx * VEC) = xr[it];
-        }
-        const long long mnext = m0 + mstep;
-        if (iter + 2 < niter) {                                   // in flight under this tile's and the next tile's stages
-            fetch_rows(mnext + mstep, p.x, p.x_stride, xn2);
-            fetch_rows(mnext + mstep, res_any ? p.res : nullptr, p.res_stride, rn2);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int st = 0; st < NST; ++st) {
-            const bool last = st == NST - 1;
-            T* Ain = (st & 1) ? A1 : A0;
-            T* Aoth = (st & 1) ? A0 : A1;
-            T* Aout = last ? Ain : Aoth;
-            const bool ln_on = p.wsum[st] != nullptr;
-            CoutRegs<CFG> bias, wsum;                              // per-cout vectors of the stage from LDS
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int co = wn * 32 + 8 * gq + 4 * hi;
-                bias.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + co);
-                wsum.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + C + co);
-            }
-            float16_t acc[1][1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-            float ln_s = 0.f, ln_q = 0.f;
-            const T* arow = Ain + (size_t)l31 * ARS + hi * 8;
-            const T* wrow = Wt + (size_t)st * C * C + (size_t)(wn * 32 + l31) * C;
-#pragma unroll
-            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-                Frag<T> xf, wf;
-                load_frag(xf, arow + kk * 16);
-                load_frag(wf, wrow + (((2 * kk + hi) ^ sw) * VEC));
-                if (ln_on) ln_accumulate(xf, ln_s, ln_q, 0.f);
-                mma32(acc[0][0], wf, xf);                          // D[cout][row]
-            }
-            if (last) __syncthreads();                             // staged in place: every wave is done reading Ain
-            if (ln_on) {
-                LnRow ln[1];
-                const float inv = 1.0f / (float)C;
-                const float sm = ln_s + __shfl_xor(ln_s, 32), q = ln_q + __shfl_xor(ln_q, 32);
-                const float mean = sm * inv;
-                ln[0].mean = mean;
-                ln[0].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
-                chain_stage_tile<CFG, T, true>(p.act[st], acc, Aout, bias, wn, lane, ln, &wsum);
-            } else {
-                chain_stage_tile<CFG, T, false>(p.act[st], acc, Aout, bias, wn, lane, nullptr, nullptr);
-            }
-            __syncthreads();
-            if (!last) {
-                if (p.res_stage == st) {                           // Aout += res (rounded like the separate launch: tile, then the sum)
-#pragma unroll
-                    for (int it = 0; it < X_IT; ++it) {
-                        const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
-                        Vec16<T>* q = reinterpret_cast<Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC);
-                        Vec16<T> v = *q;
-                        const Vec16<T> u = __builtin_bit_cast(Vec16<T>, rr[it]);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
-                        *q = v;
-                    }
-                    __syncthreads();
-                }
-            } else {                                               // coalesced store of the staged tile (+ carry, + res, LayerNorm output)
-                T* outp = static_cast<T*>(p.out);
-#pragma unroll
-                for (int it = 0; it < X_IT; ++it) {
-                    const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
-                    const long long m = m0 + row;
-                    Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC);
-                    if (p.carry) {
-                        const Vec16<T> u = *reinterpret_cast<const Vec16<T>*>(Aoth + (size_t)row * ARS + pcx * VEC);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
-                    }
-                    if (p.res_stage == st) {
-                        const Vec16<T> u = __builtin_bit_cast(Vec16<T>, rr[it]);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
-                    }
-                    if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + pcx * VEC) = v;
-                    if (ln2) {
-                        float x[VEC], sum = 0.f;
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) { x[e] = to_f32(v.v[e]); sum += x[e]; }
-#pragma unroll
-                        for (int o = 1; o < PPR; o <<= 1) sum += __shfl_xor(sum, o);
-                        const float mean = sum * (1.0f / (float)C);
-                        float sq = 0.f;
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) { x[e] -= mean; sq = __builtin_fmaf(x[e], x[e], sq); }
-#pragma unroll
-                        for (int o = 1; o < PPR; o <<= 1) sq += __shfl_xor(sq, o);
-                        const float rstd = rsqrtf(sq * (1.0f / (float)C) + p.ln_out_eps);
-                        Vec16<T> o;
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
-                        if (m < p.rows) {
-                            if (p.ln_tile_w > 0 && p.ln_tile_rows > 0 && m >= p.ln_tile_rows) {
-                                *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out_rows) + (m - p.ln_tile_rows) * p.ln_out_stride + pcx * VEC) = o;
-                            } else if (p.ln_tile_w > 0) {
-                                const long long rid = m / p.ln_tile_w;
-                                const int xq = (int)(m - rid * p.ln_tile_w);
-                                const long long slot = ((rid * ((p.ln_tile_w + 31) >> 5) + (xq >> 5)) * (C / 16) + (pcx >> 1)) * 64 + (pcx & 1) * 32 + (xq & 31);
-                                reinterpret_cast<Vec16<T>*>(p.ln_out)[slot] = o;
-                            } else {
-                                *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        m0 = mnext;
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) { xr[it] = xn[it]; rr[it] = rn[it]; xn[it] = xn2[it]; rn[it] = rn2[it]; }
-    }
-}
-
-
-// Fan-out only, weights-stationary (fp16, C = 128): NF C -> C layers that all read the SAME input rows -- the Q | K | V projection of an
-// attention at 1/4 and 1/8 resolution (reference attentions.py:24-28,71-74 behind the pre-norm of :117,148) as ONE pass over the rows:
-// the input tile is loaded once, the pre-LayerNorm statistics are taken once, the (NF*C, C) weight stays in LDS for the life of the block,
-// each layer's 32 x 128 output tile is staged and stored to its column block of the (rows, NF*C) output.  The K5 tile kernel it replaces
-// re-loads the input tile per 128-cout block and runs at 230 TF/s / 2.4 TB/s of its 160 MB (profiles/r03/layer_trace_eager.txt).
-template <int NF>
-__global__ __launch_bounds__(ChainWsCfg<NF>::NT) void mlp_fan_ws_kernel(ChainArgs p, int ntiles) {
-    using CFG = ChainWsCfg<NF>;
-    using T = half_t;
-    constexpr int C = CFG::C, VEC = CFG::VEC, ARS = CFG::ARS, PPR = CFG::PPR, GT = CFG::GT, X_IT = CFG::X_IT, BM = CFG::BM;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Wt = reinterpret_cast<T*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave / CFG::NWG, wn = wave - g * CFG::NWG;
-    const int gt = tid - g * GT;
-    T* A0 = reinterpret_cast<T*>(smem + CFG::W_BYTES + (size_t)(2 * g) * CFG::A_BYTES);
-    T* A1 = A0 + BM * ARS;
-    float* Cv = reinterpret_cast<float*>(smem + CFG::W_BYTES + (size_t)CFG::NG * 2 * CFG::A_BYTES);
-    for (int q = tid; q < NF * 2 * C; q += CFG::NT) {
-        const int st = q / (2 * C), r = q - st * 2 * C;
-        const float* src = r < C ? p.fan_b : p.fan_wsum;
-        Cv[q] = src ? src[st * C + (r < C ? r : r - C)] : 0.f;
-    }
-    const T* wsrc = static_cast<const T*>(p.fan_w);
-    for (int q = tid; q < NF * C * PPR; q += CFG::NT) {
-        const int r = q / PPR, pc = q - r * PPR;                   // r: row of the stacked (NF*C, C) weight
-        *reinterpret_cast<raw16_t*>(Wt + (size_t)r * C + ((pc ^ (r & 15)) * VEC)) = global_load16(wsrc + (size_t)r * C + pc * VEC);
-    }
-    const int npair = (ntiles + 1) >> 1;
-    const int niter = (npair - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    auto fetch_rows = [&](long long m0, raw16_t (&r)[X_IT]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) {
-            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
-            const long long m = m0 + row;
-            r[it] = global_load16(m < p.rows ? static_cast<const T*>(p.x) + m * p.x_stride + pcx * VEC : static_cast<const T*>(p.zero));
-        }
-    };
-    raw16_t xr[X_IT], xn[X_IT], xn2[X_IT];
-    const long long mstep = (long long)2 * gridDim.x * BM;
-    long long m0 = ((long long)2 * blockIdx.x + g) * BM;
-    fetch_rows(m0, xr);
-    fetch_rows(m0 + mstep, xn);
-    const bool ln_on = p.fan_wsum != nullptr;
-    const int sw = l31 & 15;
-    for (int iter = 0; iter < niter; ++iter) {
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) {
-            const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
-            *reinterpret_cast<raw16_t*>(A0 + (size_t)row * ARS + pcx * VEC) = xr[it];
-        }
-        if (iter + 2 < niter) fetch_rows(m0 + 2 * mstep, xn2);
-        __syncthreads();
-        LnRow ln[1];
-        ln[0].mean = 0.f; ln[0].rstd = 1.f;
-#pragma unroll
-        for (int st = 0; st < NF; ++st) {
-            CoutRegs<CFG> bias, wsum;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int co = wn * 32 + 8 * gq + 4 * hi;
-                bias.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + co);
-                wsum.v[0][gq] = *reinterpret_cast<const raw16_t*>(Cv + (size_t)st * 2 * C + C + co);
-            }
-            float16_t acc[1][1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
-            float ln_s = 0.f, ln_q = 0.f;
-            const T* arow = A0 + (size_t)l31 * ARS + hi * 8;
-            const T* wrow = Wt + (size_t)(st * C + wn * 32 + l31) * C;
-#pragma unroll
-            for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-                Frag<T> xf, wf;
-                load_frag(xf, arow + kk * 16);
-                load_frag(wf, wrow + (((2 * kk + hi) ^ sw) * VEC));
-                if (ln_on && st == 0) ln_accumulate(xf, ln_s, ln_q, 0.f);
-                mma32(acc[0][0], wf, xf);
-            }
-            if (ln_on && st == 0) {
-                const float inv = 1.0f / (float)C;
-                const float sm = ln_s + __shfl_xor(ln_s, 32), q = ln_q + __shfl_xor(ln_q, 32);
-                const float mean = sm * inv;
-                ln[0].mean = mean;
-                ln[0].rstd = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, q * inv), 0.f) + p.ln_eps);
-            }
-            if (st > 0) __syncthreads();                           // the previous layer's tile has left A1
-            if (ln_on) chain_stage_tile<CFG, T, true>(S2M2_ACT_NONE, acc, A1, bias, wn, lane, ln, &wsum);
-            else chain_stage_tile<CFG, T, false>(S2M2_ACT_NONE, acc, A1, bias, wn, lane, nullptr, nullptr);
-            __syncthreads();
-            T* outp = static_cast<T*>(p.fan_out) + (size_t)st * C;
-#pragma unroll
-            for (int it = 0; it < X_IT; ++it) {
-                const int idx = gt + GT * it, row = idx / PPR, pcx = idx - row * PPR;
-                const long long m = m0 + row;
-                const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(A1 + (size_t)row * ARS + pcx * VEC);
-                if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.fan_out_stride + pcx * VEC) = v;
-            }
-        }
-        m0 += mstep;
-#pragma unroll
-        for (int it = 0; it < X_IT; ++it) { xr[it] = xn[it]; xn[it] = xn2[it]; }
-    }
-}
-
-template <int NF>
-static int launch_fan_ws(const ChainArgs& a, hipStream_t st) {
-    using CFG = ChainWsCfg<NF>;
-    auto kern = mlp_fan_ws_kernel<NF>;
-    static size_t lds_granted[kMaxDevices] = {};
-    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "mlp_chain")) return 1;
-    const int ntiles = (int)((a.rows + CFG::BM - 1) / CFG::BM);
-    const int npair = (ntiles + 1) / 2;
-    const int grid = npair < 256 ? npair : 256;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::NT), CFG::LDS_BYTES, st, a, ntiles);
-    return check_launch("mlp_chain");
-}
-
-template <int NST>
-static int launch_chain_ws(const ChainArgs& a, hipStream_t st) {
-    using CFG = ChainWsCfg<NST>;
-    auto kern = mlp_chain_ws_kernel<NST>;
-    static size_t lds_granted[kMaxDevices] = {};
-    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "mlp_chain")) return 1;
-    const int ntiles = (int)((a.rows + CFG::BM - 1) / CFG::BM);
-    const int npair = (ntiles + 1) / 2;
-    const int grid = npair < 256 ? npair : 256;                   // one persistent block per CU (130 KB of LDS)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::NT), CFG::LDS_BYTES, st, a, ntiles);
-    return check_launch("mlp_chain");
-}
-
 template <typename T, int C, int BM, int NST, int NW, int WP = 4>
 static int launch_chain(const ChainArgs& a, hipStream_t st) {
     using CFG = ChainCfg<T, C, BM, NST, NW, WP>;
@@ -900,7 +543,7 @@ extern "C" int s2m2_mlp_chain_supported(int C, int dtype) {
 
 extern "C" int s2m2_mlp_chain_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 256); }
 
-extern "C" int s2m2_mlp_fan_supported(int C, int nfan, int dtype) { return dtype == S2M2_F16 && C == 128 && nfan >= 1 && nfan <= 3; }
+extern "C" int s2m2_mlp_fan_supported(int C, int nfan, int dtype) { return s2m2_mlp_chain_frag_supported(C, dtype) && nfan >= 1 && nfan <= 4; }
 
 extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     using namespace s2m2;
@@ -933,25 +576,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
         if (d->C == 128) return tall0 ? launch_chain<half_t, 128, 64, 0, 4, 0>(f, fst) : launch_chain<half_t, 128, 32, 0, 4, 0>(f, fst);
         return tall0 ? launch_chain<half_t, 256, 64, 0, 8, 0>(f, fst) : launch_chain<half_t, 256, 32, 0, 8, 0>(f, fst);
     }
-    if (d->nstage == 0) {
-        // fan-out only: the nfan layers read the x rows themselves (weights-stationary form: fp16, C = 128, nfan 1..3) -- ask
-        // s2m2_mlp_fan_supported first
-        S2M2_REQUIRE(s2m2_mlp_fan_supported(d->C, d->nfan, d->dtype), "mlp_chain: fan-out only (nstage = 0) needs fp16, C = 128, nfan 1..3");
-        S2M2_REQUIRE(d->rows > 0 && d->rows < (1LL << 31) && d->x_stride >= d->C && d->x_stride % 8 == 0, "mlp_chain: bad rows / x_stride");
-        S2M2_REQUIRE(d->fan_weight && d->fan_out && d->fan_out_stride >= (long long)d->nfan * d->C && d->fan_out_stride % 8 == 0,
-                     "mlp_chain: fan-out stages need fan_weight, fan_out and a row stride of at least nfan * C (multiple of 8)");
-        S2M2_REQUIRE(!d->fan_ln_wsum || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
-        ChainArgs f{};
-        f.x = d->x; f.x_stride = d->x_stride; f.rows = d->rows; f.ln_eps = d->ln_eps;
-        f.fan_w = d->fan_weight; f.fan_b = d->fan_bias; f.fan_wsum = d->fan_ln_wsum; f.fan_out = d->fan_out; f.fan_out_stride = d->fan_out_stride;
-        f.nfan = d->nfan;
-        f.zero = zero_page();
-        S2M2_REQUIRE(f.zero, "mlp_chain: cannot allocate the zero page");
-        hipStream_t fst = static_cast<hipStream_t>(stream);
-        if (d->nfan == 1) return launch_fan_ws<1>(f, fst);
-        if (d->nfan == 2) return launch_fan_ws<2>(f, fst);
-        return launch_fan_ws<3>(f, fst);
-    }
+    S2M2_REQUIRE(d->nstage != 0, "mlp_chain: fan-out only (nstage = 0) exists in the direct form: weight_frag = 1, fp16, C = 128 / 256");
     S2M2_REQUIRE(d->out, "mlp_chain: null out");
     S2M2_REQUIRE(d->nstage >= 1 && d->nstage <= 3, "mlp_chain: nstage=%d (0..3)", d->nstage);
     S2M2_REQUIRE(s2m2_mlp_chain_supported(d->C, d->dtype), "mlp_chain: C=%d dtype=%d is not supported (fp16: 128/256/384/512, fp32: 128/256)", d->C, d->dtype);
@@ -979,11 +604,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     S2M2_REQUIRE(!any_ln || d->ln_eps > 0.f, "mlp_chain: ln_eps must be positive");
     a.res_stage = d->res_stage; a.carry = d->carry; a.ln_eps = d->ln_eps;
     a.ln_out = d->ln_out; a.ln_out_stride = d->ln_out_stride; a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out_eps = d->ln_out_eps;
-    a.ln_tile_w = d->ln_out_tile_w;
-    a.ln_tile_rows = d->ln_out_tile_rows; a.ln_out_rows = d->ln_out_rows;
     a.pool_h = d->pool_h; a.pool_w = d->pool_w;
-    S2M2_REQUIRE(d->ln_out_tile_rows == 0 || (d->ln_out_tile_w > 0 && d->ln_out_rows && d->ln_out_tile_rows % d->ln_out_tile_w == 0 && d->ln_out_tile_rows < d->rows),
-                 "mlp_chain: ln_out_tile_rows needs ln_out_tile_w, ln_out_rows and a whole number of image rows below `rows`");
     a.fan_w = d->fan_weight; a.fan_b = d->fan_bias; a.fan_wsum = d->fan_ln_wsum; a.fan_out = d->fan_out; a.fan_out_stride = d->fan_out_stride;
     a.nfan = d->nfan;
     S2M2_REQUIRE(d->nfan >= 0 && d->nfan <= 4, "mlp_chain: nfan=%d (0..4)", d->nfan);
@@ -997,25 +618,16 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
         S2M2_REQUIRE(ppr == 16 || ppr == 32 || ppr == 64, "mlp_chain: ln_out needs a row of 16, 32 or 64 pieces (C=%d has %d)", d->C, ppr);
         S2M2_REQUIRE(d->ln_gamma && d->ln_beta && d->ln_out_eps > 0.f && d->ln_out_stride >= d->C && d->ln_out_stride % 8 == 0,
                      "mlp_chain: ln_out needs gamma, beta, a positive eps and a row stride that is a multiple of 8");
-        S2M2_REQUIRE(d->ln_out_tile_w >= 0 && (d->ln_out_tile_w == 0 || (d->dtype == S2M2_F16 && d->rows % d->ln_out_tile_w == 0)),
-                     "mlp_chain: ln_out_tile_w=%d needs fp16 rows that are whole image rows of that many tokens", d->ln_out_tile_w);
     }
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "mlp_chain: cannot allocate the zero page");
     a.xcd_tiles = 0;
     static const bool xcd_off = getenv("S2M2_K9_XCD") != nullptr && atoi(getenv("S2M2_K9_XCD")) == 0;    // A/B switch
     const int bm = (d->dtype == S2M2_F32 || d->rows <= 8192 || d->C >= 384) ? 32 : 64;   // (the tile heights picked below)
-    if (d->xcd_group_rows > 0 && !xcd_off && d->xcd_group_rows % bm == 0 && d->rows % (8LL * d->xcd_group_rows) == 0 && !(getenv("S2M2_CHAIN_CFG")))
+    if (d->xcd_group_rows > 0 && !xcd_off && d->xcd_group_rows % bm == 0 && d->rows % (8LL * d->xcd_group_rows) == 0)
         a.xcd_tiles = (int)(d->xcd_group_rows / bm);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const char* force = getenv("S2M2_CHAIN_CFG");          // tuning only: "s" (32-row tiles) / "m" (64-row tiles)
-    char cfg = d->rows <= 8192 ? 's' : 'm';                       // at most one 32-row tile per CU: short tiles, more CUs busy (measured: tools/chainbench.py)
-    if (force && *force) cfg = *force;
-    static const bool wide = getenv("S2M2_CHAIN_CHUNK128") != nullptr;   // A/B switch: 128-byte K chunks
-    // weights-stationary persistent form: fp16, C = 128, enough rows to give every CU several tiles (S2M2_CHAIN_WS=0: off, tuning knob
-    // S2M2_CHAIN_WS_MIN: smallest row count)
-    static const bool ws_off = getenv("S2M2_CHAIN_WS") != nullptr && atoi(getenv("S2M2_CHAIN_WS")) == 0;
-    static const long long ws_min = getenv("S2M2_CHAIN_WS_MIN") ? atoll(getenv("S2M2_CHAIN_WS_MIN")) : 32768;
+    const char cfg = d->rows <= 8192 ? 's' : 'm';                 // at most one 32-row tile per CU: short tiles, more CUs busy (measured: tools/chainbench.py)
     if (d->weight_frag) {                                         // direct form: 32-row tiles, one wave per 32 couts
         a.xcd_tiles = (d->xcd_group_rows > 0 && !xcd_off && d->xcd_group_rows % 32 == 0 && d->rows % (8LL * d->xcd_group_rows) == 0) ? (int)(d->xcd_group_rows / 32) : 0;
         // 32-row tiles while they fit the chip in one round (C = 256: one block per CU, C = 128: three), else 64-row tiles (half the weight
@@ -1028,19 +640,11 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
         }
         return d->C == 128 ? launch_chain_n<half_t, 128, 32, 4, 0>(a, d->nstage, st) : launch_chain_n<half_t, 256, 32, 8, 0>(a, d->nstage, st);
     }
-    if (d->dtype == S2M2_F16 && d->C == 128 && d->nfan == 0 && !ws_off && d->rows >= ws_min && !(force && *force)) {
-        a.xcd_tiles = 0;
-        if (d->nstage == 1) return launch_chain_ws<1>(a, st);
-        if (d->nstage == 2) return launch_chain_ws<2>(a, st);
-        return launch_chain_ws<3>(a, st);
-    }
     if (d->dtype == S2M2_F16) {
         switch (d->C) {
             case 128:
-                if (wide) return cfg == 's' ? launch_chain_n<half_t, 128, 32, 4, 8>(a, d->nstage, st) : launch_chain_n<half_t, 128, 64, 4, 8>(a, d->nstage, st);
                 return cfg == 's' ? launch_chain_n<half_t, 128, 32, 4>(a, d->nstage, st) : launch_chain_n<half_t, 128, 64, 4>(a, d->nstage, st);
             case 256:
-                if (wide) return cfg == 's' ? launch_chain_n<half_t, 256, 32, 8, 8>(a, d->nstage, st) : launch_chain_n<half_t, 256, 64, 8, 8>(a, d->nstage, st);
                 return cfg == 's' ? launch_chain_n<half_t, 256, 32, 8>(a, d->nstage, st) : launch_chain_n<half_t, 256, 64, 8>(a, d->nstage, st);
             case 384: return launch_chain_n<half_t, 384, 32, 4>(a, d->nstage, st);
             default: return launch_chain_n<half_t, 512, 32, 8>(a, d->nstage, st);

@@ -47,12 +47,11 @@ __device__ unsigned long long g_k1_trace[1024 * 16 * 16];
 
 namespace s2m2 {
 
-template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, bool PIPE_ = false, int TPW_ = 32, bool PRENORM_ = false>
+template <typename T, typename TO, int C_, int NWCAP_, int RIF_, bool EARLY_B_, int TPW_ = 32, bool PRENORM_ = false>
 struct LnCorrCfg {
     // PRENORM: the tokens arrive normalised (s2m2_corr: DispInit's LayerNorm was folded into the launch that produced them, the
     // second output of s2m2_mlp_chain) -- no statistics, no affine, the kernel is the batched R . L^T product and its stores
     static constexpr bool PRENORM = PRENORM_;
-    static constexpr bool PIPE = PIPE_;                 // right tokens normalised in 4 rounds, column tiles stored as soon as their tokens exist
     static constexpr int C = C_;
     static constexpr int RIF = RIF_;                    // token rounds (8 tokens per wave each) kept in flight in registers
     static constexpr bool EARLY_B = EARLY_B_;           // right tokens of chunk 0 are requested together with the left ones
@@ -80,7 +79,7 @@ struct LnCorrCfg {
     static constexpr int NWMAX = (NWLDS < NWCAP_ ? NWLDS : NWCAP_) / NWGRAN * NWGRAN;   // waves per block: LDS bound, register bound
     static_assert(PIECES % LPT == 0 && LPT == 8, "C must be a multiple of 8 pieces; group8_sum assumes 8 lanes per token");
     static_assert(NWMAX >= 1, "LDS budget");
-    static_assert((TPW == 32 || TPW == 16) && ROUNDS % RIF == 0 && (!PIPE || TPW == 32), "token rounds");
+    static_assert((TPW == 32 || TPW == 16) && ROUNDS % RIF == 0, "token rounds");
 };
 
 // LayerNorm (eps 1e-5, biased variance, affine) one token spread over 8 lanes (PPL 16-B pieces per lane) in fp32 and
@@ -188,20 +187,25 @@ template <> __device__ __forceinline__ void store_quad<float>(float* dst, float 
     *reinterpret_cast<float4_t*>(dst) = v;
 }
 
-// 16-byte store of a cost-volume piece; nt: non-temporal (streaming) -- the volume is written once and is larger than the L2 of the XCD that
-// writes it, so allocating its lines there only evicts them again (A/B switch S2M2_K1_NT, measured in profiles/r03/k1_store_path.txt)
+// 16-byte store of a cost-volume piece.  The volume is written once and is larger than the L2 of the XCD that writes it; ``mode`` picks the
+// cache policy of the store (S2M2_K1_NT, measured in profiles/r04/k1_store_modes.txt): 0 default (write-back L2: the dirty lines are flushed
+// when the kernel ends), 1 nt (streaming hint), 2 sc1, 3 sc0 sc1 (write-through to memory: nothing is left to flush at the end of the
+// kernel), 4 sc0 sc1 nt
 template <typename TO>
-__device__ __forceinline__ void store_cv(TO* dst, const Vec16<TO>& v, int nt) {
+__device__ __forceinline__ void store_cv(TO* dst, const Vec16<TO>& v, int mode) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 r = __builtin_bit_cast(f4, v);
-    if (nt) __builtin_nontemporal_store(r, reinterpret_cast<f4*>(dst));
-    else *reinterpret_cast<f4*>(dst) = r;
+    if (mode == 0) *reinterpret_cast<f4*>(dst) = r;
+    else if (mode == 1) __builtin_nontemporal_store(r, reinterpret_cast<f4*>(dst));
+    else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r) : "memory");
+    else if (mode == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(r) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(r) : "memory");
 }
 
 template <typename CFG, typename T, typename TO>
 __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __restrict__ feat, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, TO* __restrict__ cv,
-                                                                 int B, int h, int w, int nstrip, int band, int pitch, int flags, const raw16_t* __restrict__ left_tiled) {
+                                                                 int B, int h, int w, int nstrip, int band, int pitch, int flags) {
     constexpr int dbg = S2M2_LNCORR_DBG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* gb = reinterpret_cast<float*>(smem);
@@ -279,32 +283,6 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
             }
     };
     if constexpr (CFG::PRENORM) {
-        static_assert(!CFG::PIPE, "the pipelined variant has no normalised-input form");
-        bool hybrid = false;
-        if constexpr (sizeof(T) == 2) {
-        if (left_tiled != nullptr) {                               // block-uniform
-            hybrid = true;
-            // hybrid (s2m2_corr_hybrid): the left tokens arrive in MFMA-fragment order -- fragment kk of this wave's 32-token tile is one
-            // coalesced 1 KB read straight into the operand registers: no LDS bounce, no wave barriers.  The right tokens are requested
-            // FIRST (loads return in order: they are what the block barrier waits for), the fragments behind them.
-            raw16_t lf[CFG::KSTEPS];
-            const int NT = (w + 31) >> 5;
-            const raw16_t* lp = left_tiled + ((size_t)((size_t)(b * h + y) * NT + (i0 >> 5)) * CFG::KSTEPS) * 64 + lane;
-            if (CFG::EARLY_B) pre_issue(pre_b, right, wv * CFG::TPW);
-#pragma unroll
-            for (int kk = 0; kk < CFG::KSTEPS; ++kk) global_load16_async(lf[kk], lp + (wave_active ? kk : 0) * 64);
-            K1_T(2);
-            if (CFG::EARLY_B) {
-                wait_vmcnt<CFG::KSTEPS>();                         // the KSTEPS fragment requests may still be in flight
-                pre_stash(pre_b, 0);
-            }
-            K1_T(3);
-            wait_vmcnt<0>();
-#pragma unroll
-            for (int kk = 0; kk < CFG::KSTEPS; ++kk) { settle(lf[kk]); afrag[kk].v = __builtin_bit_cast(half8_t, lf[kk]); }
-        }
-        }
-        if (!hybrid) {
         pre_issue(pre_a, left, i0);
         if (CFG::EARLY_B) pre_issue(pre_b, right, wv * CFG::TPW);
         K1_T(2);
@@ -322,7 +300,6 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
             wait_vmcnt<0>();
             pre_stash(pre_b, 0);
         }
-        }
     } else {
         Vec16<T> rawA[CFG::RIF][CFG::PPL];
         // unconditional (token indices are clamped): a branch here lets the compiler hoist the first LayerNorm under it and push
@@ -332,7 +309,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
         if (CFG::EARLY_B) {
 #pragma unroll
             for (int r = 0; r < CFG::RIF; ++r)
-                load_token<CFG, T>(rawB[r], right, CFG::PIPE ? r * 8 * NW + wv * 8 + trow : wv * CFG::TPW + r * 8 + trow, w, sub);
+                load_token<CFG, T>(rawB[r], right, wv * CFG::TPW + r * 8 + trow, w, sub);
         }
         // keep every request above in front of the arithmetic below: without this the scheduler sinks the right-token loads under
         // the LayerNorm of the left tokens (one full memory latency lost)
@@ -353,75 +330,6 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                 normalize_store<CFG, T>(rawA[r], Wb + (size_t)(((r0 + r) * 8 + trow) % CFG::TPW) * CFG::RS, gb, sub, dbg);
             if ((r0 + CFG::RIF) % CFG::ROUNDS == 0) pickup((r0 + CFG::RIF) / CFG::ROUNDS - 1);
         }
-    }
-
-    if constexpr (CFG::PIPE) {
-        // ---- pipelined single-chunk path (w <= 32*NW, whole rows): the four 8-token rounds of every wave form four 8*NW-token
-        // slabs of the right row, ordered slab-major in memory request order.  After slab r is normalised, every column tile whose
-        // 32 tokens lie below 8*NW*(r+1) is multiplied and stored while the later slabs are still arriving from HBM, so the
-        // store phase of a row overlaps its own load phase inside the CU.  Barriers are plain s_barrier + lgkmcnt(0): a fenced
-        // __syncthreads() would wait for the loads still in flight.
-        auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-        lds_barrier();                                            // all A-operand scratch reads done before right tokens land there
-        const int ntile_all = (w + 31) / 32;
-        float16_t acc0, acc1;
-        auto mma_pair = [&](int ct0, bool two) {
-            const T* bp0 = Bs + (size_t)(ct0 * 32 + (lane & 31)) * CFG::RS + (lane >> 5) * 8;
-            const T* bp1 = two ? bp0 + 32 * CFG::RS : bp0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-            if (!(dbg & 2)) {
-#pragma unroll
-                for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
-                    Frag<T> b0, b1;
-                    load_frag(b0, bp0 + kk * 16);
-                    load_frag(b1, bp1 + kk * 16);
-                    mma32(acc0, b0, afrag[kk]);                   // D[j][i]: lane = left pixel i, registers = right pixels j
-                    mma32(acc1, b1, afrag[kk]);
-                }
-            }
-        };
-        int done = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int jtok = r * 8 * NW + wv * 8 + trow;
-            normalize_store<CFG, T>(rawB[r], Bs + (size_t)jtok * CFG::RS, gb, sub, dbg);
-            lds_barrier();
-            int ready = r == 3 ? ntile_all : (8 * NW * (r + 1)) / 32;
-            ready = ready < ntile_all ? ready : ntile_all;
-            if (wave_active && !(dbg & 8) && ready > done) {
-                const int npair = (ready - done + 1) >> 1;
-                auto pair_ct = [&](int pp) { int pr = pp + wv; pr = pr % npair; return done + 2 * pr; };
-                mma_pair(pair_ct(0), pair_ct(0) + 1 < ready);
-                for (int pp = 0; pp < npair; ++pp) {
-                    const int ct0 = pair_ct(pp);
-                    TO* wrow = Wc + (size_t)(lane & 31) * CFG::CRS + 4 * (lane >> 5);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        store_quad<TO>(wrow + 8 * g, acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
-                        store_quad<TO>(wrow + 32 + 8 * g, acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (pp + 1 < npair) mma_pair(pair_ct(pp + 1), pair_ct(pp + 1) + 1 < ready);
-                    constexpr int PPR = 64 / CFG::VECO;           // 16-B pieces per staged row (64 columns)
-                    constexpr int ITERS = 32 * PPR / 64;
-                    const int j0 = ct0 * 32;
-                    const int jlim = (ct0 + 1 < ready ? ct0 + 2 : ct0 + 1) * 32;      // a lone tile stores 32 columns only
-#pragma unroll
-                    for (int it = 0; it < ITERS; ++it) {
-                        const int q = it * 64 + lane;
-                        const int rr = q / PPR, pc = q - rr * PPR;
-                        const int i = i0 + rr;
-                        const int j = j0 + pc * CFG::VECO;
-                        const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                        if (i < w && j < w && j < jlim && !(dbg & 1)) store_cv(cvrow + (size_t)i * pitch + j, v, flags & 1);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            done = ready;
-        }
-        return;
     }
 
     for (int c = 0; c < nchunks; ++c) {
@@ -517,7 +425,7 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
                     const int i = i0 + rr;
                     const int j = j0 + pc * CFG::VECO;
                     const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CFG::CRS + pc * CFG::VECO);
-                    if (i < w && j < w && !(dbg & 1)) store_cv(cvrow + (size_t)i * pitch + j, v, flags & 1);
+                    if (i < w && j < w && !(dbg & 1)) store_cv(cvrow + (size_t)i * pitch + j, v, flags);
                 }
                 __builtin_amdgcn_wave_barrier();
                 K1_T(6 + (pp < 8 ? pp : 8));
@@ -530,93 +438,6 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1, streaming form (s2m2_corr_tiled; fp16 tokens, normalised by their producer and stored IN MFMA FRAGMENT ORDER):
-//
-// The LDS form above is phase-serial: every wave of a row loads (5 us at c3), the block meets at a barrier, then every wave stores
-// (11 us) -- and with one image row per CU (B = 1: 256 rows, 256 CUs) nothing else runs on the CU while either phase waits on the memory
-// system.  The store loop ALONE takes 8.5 us, loads alone ~5 (profiles/r03/k1_store_path.txt): the kernel's 18.4 us is their sum plus
-// launch, not their maximum.  Here a wave shares NOTHING with its neighbours: it owns 32 left tokens (8 fragment registers for C = 128)
-// and walks the right row pair by pair of 32-token tiles, reading each tile's fragments with perfectly coalesced 1 KB loads
-// (fragment f of tile t at ((row * NT + t) * KS + f) * 1 KB + lane * 16 B -- the layout the producing s2m2_mlp_chain launch writes:
-// s2m2_chain_desc.ln_out_tile_w), multiplying, staging, storing.  No LDS for tokens, no block barrier; the ten waves of a row are at
-// different points of that loop, so one wave's tile loads run under another wave's stores.  The right row is read ten times per row
-// from L1 / L2 (78 KB x 10 per CU at 64 B/clk = 6 us, under the stores) instead of once into LDS.
-// ------------------------------------------------------------------------------------------------
-template <int C, typename TO>
-__global__ __launch_bounds__(1024) void corr_stream_kernel(const raw16_t* __restrict__ frag, TO* __restrict__ cv, int B, int h, int w,
-                                                            int NT, int nsplit, int band, int pitch, int flags) {
-    constexpr int KS = C / 16;
-    constexpr int VECO = 16 / sizeof(TO), CRS = 64 + VECO;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int NWB = blockDim.x >> 6;
-    TO* Wc = reinterpret_cast<TO*>(smem) + (size_t)wv * 32 * CRS;            // this wave's 32 x 64 staging tile
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int row = bid / nsplit;                        // (b, y)
-    const int part = bid - row * nsplit;
-    const int b = row / h, y = row - b * h;
-    const int lt = part * NWB + wv;                      // left tile of this wave
-    if (lt >= NT) return;
-    const int i0 = lt * 32;
-    const raw16_t* L = frag + ((size_t)((size_t)(b * h + y) * NT + lt) * KS) * 64 + lane;
-    const raw16_t* R = frag + ((size_t)((size_t)((B + b) * h + y) * NT) * KS) * 64 + lane;
-    TO* cvrow = cv + (size_t)row * w * pitch;
-    Frag<half_t> af[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) af[kk].v = __builtin_bit_cast(half8_t, L[kk * 64]);
-    int npair = (NT + 1) >> 1;
-    if (band >= 0) {                                     // banded volume: this wave's rows need columns up to i0 + 31 + band only
-        const int need = (i0 + 31 + band) / 64 + 1;
-        npair = npair < need ? npair : need;
-    }
-    const int stagger = (flags & 2) ? lt : 0;            // A/B: every wave starts at its own pair (spreads the stores, costs L1 reuse)
-    for (int pp = 0; pp < npair; ++pp) {
-        int pr = pp + stagger;
-        pr = pr >= npair ? pr % npair : pr;
-        const int ct0 = 2 * pr;
-        const bool two = ct0 + 1 < NT;
-        const raw16_t* r0 = R + (size_t)ct0 * KS * 64;
-        const raw16_t* r1 = two ? r0 + KS * 64 : r0;
-        raw16_t q0[KS], q1[KS];
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) { q0[kk] = global_load16(r0 + kk * 64); q1[kk] = global_load16(r1 + kk * 64); }
-        float16_t acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            Frag<half_t> b0, b1;
-            b0.v = __builtin_bit_cast(half8_t, q0[kk]);
-            b1.v = __builtin_bit_cast(half8_t, q1[kk]);
-            mma32(acc0, b0, af[kk]);                      // D[j][i]: lane = left pixel i, registers = right pixels j
-            mma32(acc1, b1, af[kk]);
-        }
-        TO* wrow = Wc + (size_t)(lane & 31) * CRS + 4 * (lane >> 5);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            store_quad<TO>(wrow + 8 * g, acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]);
-            store_quad<TO>(wrow + 32 + 8 * g, acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        constexpr int PPR = 64 / VECO;                    // 16-B pieces per staged row (64 columns)
-        constexpr int ITERS = 32 * PPR / 64;
-        const int j0 = ct0 * 32;
-        const int jlim = two ? j0 + 64 : j0 + 32;
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int q = it * 64 + lane;
-            const int rr = q / PPR, pc = q - rr * PPR;
-            const int i = i0 + rr;
-            const int j = j0 + pc * VECO;
-            const Vec16<TO> v = *reinterpret_cast<const Vec16<TO>*>(Wc + rr * CRS + pc * VECO);
-            if (i < w && j < w && j < jlim) store_cv(cvrow + (size_t)i * pitch + j, v, flags & 1);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
 // s2m2_ln_corr_timed: events attached to the next launch of the calling thread (hipExtLaunchKernel records them at the start and
@@ -624,20 +445,14 @@ __global__ __launch_bounds__(1024) void corr_stream_kernel(const raw16_t* __rest
 static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static thread_local int g_band = -1;                 // s2m2_ln_corr_banded: columns right of the diagonal that must be valid (-1: all)
 static thread_local int g_pitch = 0;                 // s2m2_corr: elements between volume rows (0: w)
-static thread_local const void* g_left_tiled = nullptr;   // s2m2_corr_hybrid: left tokens in fragment order
 
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st);
 
 // normalised-input variant of a configuration (same tiling)
 template <typename CFG> struct PrenormOf;
-template <typename T, typename TO, int C, int NWCAP, int RIF, bool EB, bool PIPE, int TPW>
-struct PrenormOf<LnCorrCfg<T, TO, C, NWCAP, RIF, EB, PIPE, TPW, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, RIF, EB, PIPE, TPW, true>; };
-
-// pipelined variant of a configuration (same tiling, PIPE = true) where it exists: all four token rounds resident in registers
-template <typename CFG> struct PipeOf { using type = void; };
-template <typename T, typename TO, int C, int NWCAP>
-struct PipeOf<LnCorrCfg<T, TO, C, NWCAP, 4, true, false, 32>> { using type = LnCorrCfg<T, TO, C, NWCAP, 4, true, true, 32>; };
+template <typename T, typename TO, int C, int NWCAP, int RIF, bool EB, int TPW>
+struct PrenormOf<LnCorrCfg<T, TO, C, NWCAP, RIF, EB, TPW, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, RIF, EB, TPW, true>; };
 
 template <typename CFG, typename T, typename TO>
 static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st) {
@@ -648,27 +463,17 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     int nstrip = (tiles + CFG::NWMAX - 1) / CFG::NWMAX;
     // small problems: split rows into strips until the grid covers the chip (each strip re-normalises the right row)
     while (B * h * nstrip < 200 && nstrip < tiles && (tiles + nstrip) / (nstrip + 1) >= 2) ++nstrip;
-    static const int force_nstrip = getenv("S2M2_LNCORR_NSTRIP") ? atoi(getenv("S2M2_LNCORR_NSTRIP")) : 0;   // tuning knob
-    if (force_nstrip > 0 && ((tiles + force_nstrip - 1) / force_nstrip + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN <= CFG::NWMAX)
-        nstrip = force_nstrip;
     int nw = (tiles + nstrip - 1) / nstrip;
     nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;
     const int pitch = g_pitch > 0 ? g_pitch : w;
-    static const int k1_flags = getenv("S2M2_K1_NT") ? (atoi(getenv("S2M2_K1_NT")) != 0 ? 1 : 0) : 0;      // A/B switch: non-temporal stores
-    if constexpr (!CFG::PIPE && !std::is_void<typename PipeOf<CFG>::type>::value) {
-        // measured (tools/k1_ab.py, c3 fp16): 24.2 us pipelined vs 21.3 us plain -- the extra barriers and the smaller store bursts cost
-        // more than the overlap returns, so the pipelined variant stays an opt-in experiment
-        static const bool pipe = getenv("S2M2_LNCORR_PIPE") != nullptr;
-        if (nstrip == 1 && pipe)                                  // whole rows per block: overlap the row's stores with its own loads
-            return launch_ln_corr<typename PipeOf<CFG>::type, T, TO>(feat, g, bta, cv, B, h, w, st);
-    }
+    static const int k1_flags = getenv("S2M2_K1_NT") ? atoi(getenv("S2M2_K1_NT")) : 0;      // A/B switch: cache policy of the volume stores (store_cv)
     if (g_ev_start || g_ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
-                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags, static_cast<const raw16_t*>(g_left_tiled));
+                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
-                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags, static_cast<const raw16_t*>(g_left_tiled));
+                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
     return check_launch("ln_corr");
 }
 
@@ -677,9 +482,9 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
 template <typename T, int C> struct LnCorrPick;
 template <> struct LnCorrPick<half_t, 64>  { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 64, 12, 4, true>; };
 template <> struct LnCorrPick<half_t, 128> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 128, 11, 4, true>; };
-template <> struct LnCorrPick<half_t, 192> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 192, 10, 2, true, false, 16>; };
-template <> struct LnCorrPick<half_t, 256> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 256, 10, 2, true, false, 16>; };
-template <> struct LnCorrPick<half_t, 384> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 384, 8, 2, true, false, 16>; };
+template <> struct LnCorrPick<half_t, 192> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 192, 10, 2, true, 16>; };
+template <> struct LnCorrPick<half_t, 256> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 256, 10, 2, true, 16>; };
+template <> struct LnCorrPick<half_t, 384> { template <typename TO> using cfg = LnCorrCfg<half_t, TO, 384, 8, 2, true, 16>; };
 template <> struct LnCorrPick<float, 64>   { template <typename TO> using cfg = LnCorrCfg<float, TO, 64, 12, 4, true>; };
 template <> struct LnCorrPick<float, 128>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 128, 8, 4, false>; };
 template <> struct LnCorrPick<float, 192>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 192, 8, 2, false>; };
@@ -734,76 +539,16 @@ extern "C" int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const fl
     return rc;
 }
 
-template <int C, typename TO>
-static int launch_corr_stream(const void* frag, void* cv, int B, int h, int w, int pitch, int band, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
-    using namespace s2m2;
-    auto kern = corr_stream_kernel<C, TO>;
-    const int NT = (w + 31) / 32;
-    // waves per block: a whole row when it fits 12 resident waves per CU (<= 170 registers), else the row in equal parts
-    int nsplit = (NT + 11) / 12;
-    static const int force_split = getenv("S2M2_K1_SPLIT") ? atoi(getenv("S2M2_K1_SPLIT")) : 0;       // tuning knob: blocks per image row
-    if (force_split > 0 && force_split <= NT) nsplit = force_split;
-    const int nwb = (NT + nsplit - 1) / nsplit;
-    const size_t lds = (size_t)nwb * 32 * (64 + 16 / sizeof(TO)) * sizeof(TO);
-    static size_t lds_granted[kMaxDevices] = {};
-    if (reserve_lds(reinterpret_cast<const void*>(kern), lds, lds_granted, "corr_tiled")) return 1;
-    static const int k1_flags = (getenv("S2M2_K1_NT") && atoi(getenv("S2M2_K1_NT")) != 0 ? 1 : 0) |
-                                (getenv("S2M2_K1_STAGGER") && atoi(getenv("S2M2_K1_STAGGER")) != 0 ? 2 : 0);      // A/B switches
-    hipExtLaunchKernelGGL(kern, dim3(B * h * nsplit), dim3(nwb * 64), lds, st, e0, e1, 0, static_cast<const raw16_t*>(frag),
-                          static_cast<TO*>(cv), B, h, w, NT, nsplit, band, pitch, k1_flags);
-    return check_launch("corr_tiled");
-}
-
-extern "C" int s2m2_corr_hybrid(const void* left_tiled, const void* right_rows, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype,
-                                int band, void* stream, void* start_event, void* stop_event) {
-    using namespace s2m2;
-    S2M2_REQUIRE(left_tiled && right_rows && cv, "corr_hybrid: null pointer");
-    S2M2_REQUIRE(B > 0 && h > 0 && w > 0 && w % 8 == 0, "corr_hybrid: bad shape B=%d h=%d w=%d (w a multiple of 8)", B, h, w);
-    S2M2_REQUIRE(C == 64 || C == 128, "corr_hybrid: C=%d (64 or 128: one chunk of right tokens per 32-token left tile)", C);
+extern "C" int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
+                                    int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
     if (cv_pitch == 0) cv_pitch = w;
-    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "corr_hybrid: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    g_ev_start = static_cast<hipEvent_t>(start_event);
-    g_ev_stop = static_cast<hipEvent_t>(stop_event);
-    g_band = band >= 0 ? band : -1;
-    g_pitch = cv_pitch;
-    g_left_tiled = left_tiled;
-    // the kernel indexes the right images as batch entries [B, 2B) of one (2B, h, w, C) tensor: hand it a base B images before right_rows
-    const half_t* base = static_cast<const half_t*>(right_rows) - (size_t)B * h * w * C;
-    int rc;
-    if (cv_dtype == S2M2_F16) rc = dispatch_c<half_t, half_t, true>(base, nullptr, nullptr, cv, B, h, w, C, st);
-    else if (cv_dtype == S2M2_F32) rc = dispatch_c<half_t, float, true>(base, nullptr, nullptr, cv, B, h, w, C, st);
-    else rc = set_error("corr_hybrid: unsupported cv dtype %d", cv_dtype);
-    g_ev_start = g_ev_stop = nullptr;
-    g_band = -1;
-    g_pitch = 0;
-    g_left_tiled = nullptr;
+    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "ln_corr_pitched: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
+    s2m2::g_pitch = cv_pitch;
+    s2m2::g_band = band >= 0 ? band : -1;
+    const int rc = s2m2_ln_corr_timed(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream, start_event, stop_event);
+    s2m2::g_band = -1;
+    s2m2::g_pitch = 0;
     return rc;
-}
-
-extern "C" size_t s2m2_corr_tiled_bytes(int B, int h, int w, int C) {
-    if (B <= 0 || h <= 0 || w <= 0 || C <= 0) return 0;
-    return (size_t)2 * B * h * ((w + 31) / 32) * 32 * C * 2;          // fp16, rows padded to whole 32-token tiles
-}
-
-extern "C" int s2m2_corr_tiled(const void* tokens_tiled, void* cv, int B, int h, int w, int C, int cv_pitch, int cv_dtype, int band,
-                               void* stream, void* start_event, void* stop_event) {
-    using namespace s2m2;
-    S2M2_REQUIRE(tokens_tiled && cv, "corr_tiled: null pointer");
-    S2M2_REQUIRE(B > 0 && h > 0 && w > 0 && w % 8 == 0, "corr_tiled: bad shape B=%d h=%d w=%d (w a multiple of 8)", B, h, w);
-    if (cv_pitch == 0) cv_pitch = w;
-    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "corr_tiled: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipEvent_t e0 = static_cast<hipEvent_t>(start_event), e1 = static_cast<hipEvent_t>(stop_event);
-    const int bnd = band >= 0 ? band : -1;
-    if (cv_dtype == S2M2_F16) {
-        if (C == 64) return launch_corr_stream<64, half_t>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
-        if (C == 128) return launch_corr_stream<128, half_t>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
-        if (C == 256) return launch_corr_stream<256, half_t>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
-    } else if (cv_dtype == S2M2_F32) {
-        if (C == 128) return launch_corr_stream<128, float>(tokens_tiled, cv, B, h, w, cv_pitch, bnd, st, e0, e1);
-    }
-    return set_error("corr_tiled: unsupported C=%d / cv dtype %d (fp16 tokens; C = 64, 128, 256 with an fp16 volume, C = 128 with fp32)", C, cv_dtype);
 }
 
 extern "C" int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
@@ -827,51 +572,6 @@ extern "C" int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int 
     g_band = -1;
     g_pitch = 0;
     return rc;
-}
-
-// measurement aid (profiles/r03/k1_store_path.txt): what does the memory system give K1's STORE pattern alone?  mode 0 / 1: one block per
-// volume row of ceil(w / 32) waves, a wave owns 32 rows and writes them as 64-column (128-byte for fp16) segments, 8 rows per store
-// instruction, pair by pair -- exactly the store loop of ln_corr_kernel, from registers, no loads, no MFMA (1: non-temporal);
-// mode 2 / 3: the same bytes as one linear stream of 16-byte stores from 2048 blocks (3: non-temporal).
-namespace s2m2 {
-__global__ __launch_bounds__(1024) void store_pattern_kernel(half_t* cv, int w, int pitch, int mode, long long total16) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    Vec16<half_t> v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v.v[e] = (half_t)(float)(lane + e);
-    if (mode >= 2) {
-        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total16; q += (long long)gridDim.x * blockDim.x)
-            store_cv(cv + q * 8, v, mode & 1);
-        return;
-    }
-    half_t* cvrow = cv + (size_t)blockIdx.x * w * pitch;
-    const int i0 = wv * 32;
-    const int npair = (w + 63) / 64;
-    for (int pp = 0; pp < npair; ++pp) {
-        int pr = pp + wv;
-        pr = pr % npair;
-        const int j0 = pr * 64;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int q = it * 64 + lane;
-            const int rr = q >> 3, pc = q & 7;
-            const int i = i0 + rr, j = j0 + pc * 8;
-            if (i < w && j < w) store_cv(cvrow + (size_t)i * pitch + j, v, mode & 1);
-        }
-    }
-}
-}  // namespace s2m2
-
-extern "C" int s2m2_debug_store_pattern(void* cv, int rows, int w, int cv_pitch, int mode, void* stream, void* start_event, void* stop_event) {
-    using namespace s2m2;
-    S2M2_REQUIRE(cv && rows > 0 && w > 0 && w % 8 == 0 && w <= 512 && mode >= 0 && mode <= 3, "debug_store_pattern: bad arguments");
-    if (cv_pitch == 0) cv_pitch = w;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const long long total16 = (long long)rows * w * cv_pitch / 8;
-    const dim3 grid(mode >= 2 ? 2048 : rows), block(mode >= 2 ? 256 : ((w + 31) / 32) * 64);
-    hipExtLaunchKernelGGL(store_pattern_kernel, grid, block, 0, st, static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event), 0,
-                          static_cast<half_t*>(cv), w, cv_pitch, mode, total16);
-    return check_launch("debug_store_pattern");
 }
 
 extern "C" int s2m2_event_create(void** event) {

@@ -94,68 +94,26 @@ class Engine:
         self._bufs: Dict[object, Tensor] = {}
         self._ns = None                              # scratch namespace, see zeros()
         self._wsum: Dict[int, Tensor] = {}
-        self.fuse_ln = os.environ.get("S2M2_FUSE_LN", "1") != "0"      # A/B switch: 0 = separate K6 LayerNorm launches
-        self.use_chain = os.environ.get("S2M2_CHAIN", "1") != "0"      # A/B switch: 0 = one K5 launch per 1x1 layer instead of K9 chains
-        self._chain_ok: Dict[int, bool] = {}
-        self.fuse_stem = os.environ.get("S2M2_FUSE_STEM", "1") != "0"    # A/B switch: 0 = the two full-resolution stem layers as K5 launches
-        self.fuse_up = os.environ.get("S2M2_FUSE_UP", "1") != "0"        # A/B switch: 0 = stand-alone bilinear resample before the decoder fusions
-        self.fuse_fusion = os.environ.get("S2M2_FUSE_FUSION", "1") != "0"  # A/B switch: 0 = FeatureFusion as K5 launches instead of K10
-        self._fusion_ok: Dict[int, bool] = {}
-        self.fuse_heads = os.environ.get("S2M2_FUSE_HEADS", "1") != "0"  # A/B switch: 0 = FeatureFusion gate / fusion heads as two launches
-        self.fuse_pool = os.environ.get("S2M2_FUSE_POOL", "1") != "0"    # A/B switch: 0 = AvgPool2d(2) of the down_convs as its own K7 launch
-        self.use_frag = os.environ.get("S2M2_CONV_FRAG", "1") != "0"     # A/B switch: 0 = spatial layers on the v3 halo tiles (K order 0)
-        # epilogue-operand layers on the v5 kernel (64-pixel blocks): "1" (default) one-operand epilogues (residual add, r * h), "2" also the
-        # two-operand GRU blend (measured +35 us per pair: 176 registers, two blocks per CU), "0" none (v3 tiles)
-        self.frag_aux = os.environ.get("S2M2_FRAG_AUX", "1") != "0"
-        self.frag_aux2 = os.environ.get("S2M2_FRAG_AUX", "1") == "2"
-        # opt-in: banded cost volume (columns j <= i + 11) for use_positivity models.  Off by default: the reference's DispInit hands
-        # out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward (measured: profiles/r02/kbench.txt)
-        self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
-        # opt-in (S2M2_FUSE_QKV=1): the Q | K | V projection of an attention as fan-out stages of the K9 launch that produces its input,
-        # where there is one.  Measured neutral end to end (20 launches fewer per pair, 9.80-9.85 vs 9.84 ms same-box): at 1/16 and 1/32
-        # the chain's 32-row tiles occupy 76-152 CUs and three more weight streams double its length, which costs what the separate
-        # 456-block K5 launch cost -- off by default
-        self.fuse_qkv = os.environ.get("S2M2_FUSE_QKV", "0") == "1"
-        self.pw_ws = os.environ.get("S2M2_PW_WS", "1") != "0"           # A/B switch: 0 = plain 1x1 128 -> 128 layers at 1/4 resolution as K5 launches
-        self.fan_ws = os.environ.get("S2M2_FAN_WS", "1") != "0"         # A/B switch: 0 = the Q | K | V projection at 1/4 and 1/8 as a K5 launch
-        self.fuse_gru = os.environ.get("S2M2_FUSE_GRU", "1") != "0"     # A/B switch: 0 = the z and r gates of ConvGRU as two launches
-        self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"   # A/B switch: 0 = K1 normalises the tokens itself
-        self.cv_aligned = os.environ.get("S2M2_CV_ALIGNED", "1") != "0"  # A/B switch: 0 = dense cost-volume rows (pitch = w)
-        # opt-in experiment (S2M2_K1_STREAM=1, fp16): K9 writes the normalised tokens in MFMA-fragment order and K1 runs its streaming
-        # form (hip.corr_tiled: no LDS for tokens, no block barrier).  Measured (profiles/r03/k1_store_path.txt, bench A/B): 18.3 us
-        # stand-alone like the LDS form, but 22.4 vs 19.4 us inside the forward (the right row is re-read once per wave from L2 / MALL
-        # instead of once into LDS) -- off by default
-        self.k1_stream = os.environ.get("S2M2_K1_STREAM", "0") == "1"
-        # opt-in experiment (S2M2_K1_HYBRID=1, fp16, C 64 / 128): K9 writes the normalised LEFT tokens in fragment order and the right
-        # tokens row-major; K1 (hip.corr_hybrid) keeps its LDS right row but loads its left operand straight into registers
-        self.k1_hybrid = os.environ.get("S2M2_K1_HYBRID", "0") == "1"
-        # direct form of K9 for SHORT row counts (the attention blocks of the 1/32 .. 1/8 levels): weights in MFMA-fragment order, from
-        # global memory straight into the operand registers (hip.mlp_chain(frag=True)); S2M2_CHAIN_DIRECT=0: off,
-        # S2M2_CHAIN_DIRECT_MAX: largest row count that takes it; S2M2_CHAIN_DIRECT_QKV=0: without the next attention's Q|K|V as fan-out
-        self.chain_direct = os.environ.get("S2M2_CHAIN_DIRECT", "1") != "0"
-        self.chain_direct_max = int(os.environ.get("S2M2_CHAIN_DIRECT_MAX", str(1 << 30)))
-        self.chain_direct_qkv = os.environ.get("S2M2_CHAIN_DIRECT_QKV", "1") != "0"
+        self._chain_ok: Dict[object, bool] = {}
+        self._fusion_ok: Dict[object, bool] = {}
         self._wfrag = {}
-        self.pw_direct = os.environ.get("S2M2_PW_DIRECT", "1") != "0"
-        self.pool_direct = os.environ.get("S2M2_POOL_DIRECT", "1") != "0"            # down_convs (AvgPool2d(2) + 1x1) on the direct K9 form
-        self.qkv_direct = os.environ.get("S2M2_QKV_DIRECT", "1") != "0"              # a block's first Q|K|V projection as a fan-out-only launch
-        self.chain_direct_ln = os.environ.get("S2M2_CHAIN_DIRECT_LN", "1") != "0"    # the launch that also writes K1's normalised tokens
-        # the same for K10 (hip.feature_fusion(frag=True)): S2M2_FUSION_DIRECT=0: off, S2M2_FUSION_DIRECT_MAX: largest row count
-        self.fusion_direct = os.environ.get("S2M2_FUSION_DIRECT", "1") != "0"
-        self.fusion_direct_max = int(os.environ.get("S2M2_FUSION_DIRECT_MAX", str(1 << 30)))
-        self._tokens_normed = None                               # Tensor (row-major), hip.TiledTokens or hip.HybridTokens
+        # One path per layer: which kernel form a layer takes follows from dtype and width alone (fp16 at C = 128 / 256: the direct forms of
+        # K9 / K10 and the fragment-stream K5; other widths / fp32: the LDS-staged forms).  Two switches remain:
+        # S2M2_FUSE_K1LN=0: K1 normalises the tokens itself (s2m2_ln_corr) instead of reading the LayerNorm output of the K9 launch that
+        #   writes them -- bench.py reports both variants of the judged kernel (profiles/r04/ab_k1_fold.txt);
+        # S2M2_CV_BAND=1 (opt-in, use_positivity models): banded cost volume, columns j <= i + 11.  Off by default: the reference's DispInit
+        #   hands out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward
+        self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"
+        self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
+        self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
         self.k1_events = None                        # bench.py: list collecting (start, end) HIP events around K1
-        # opt-in experiment (S2M2_STREAMS=1): independent branches (the two paths of a ConvBlock2D, the z / r gates of the GRU) on a
-        # second HIP stream = parallel branches of the captured hipGraph.  Measured 69.1 vs 70.0 pairs/s without: the kernels already
-        # fill the chip, concurrency only adds contention -- off by default.
-        self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and os.environ.get("S2M2_STREAMS", "0") == "1") else None
 
     # ---- weight packing (once per engine) ------------------------------------------------------------
     def std(self, name: str, splits: Optional[Sequence[Tuple[int, int]]] = None, transposed: bool = False, frag: bool = True) -> Spec:
         """One nn.Conv2d / nn.Linear (or stride-1 nn.ConvTranspose2d when ``transposed``) as a K5 weight.  frag=False: the layer is
-        launched with a stride (or S2M2_FRAG_AUX=0 keeps the epilogue-operand layers on the v3 tiles), keep K order 0."""
+        launched with a stride (or its epilogue needs two operands: the GRU blend stays on the v3 tiles), keep K order 0."""
         key = (name, tuple(splits) if splits else None, transposed, bool(frag))     # frag selects the packing (K order 0 / 2)
         s = self._packed.get(key)
         if s is None:
@@ -165,7 +123,7 @@ class Engine:
             if w.dim() == 2:
                 w = w[:, :, None, None]
             cin_p = sum(pd for _, pd in splits) if splits else pack.pad8(w.shape[1])
-            frag = frag and self.use_frag and pack.frag_eligible(pack.pad8(w.shape[0]), cin_p, w.shape[2], w.shape[3], self.dtype)
+            frag = frag and pack.frag_eligible(pack.pad8(w.shape[0]), cin_p, w.shape[2], w.shape[3], self.dtype)
             wp = pack.pack_conv_frag(w, self.dtype, splits) if frag else pack.pack_conv(w, self.dtype, splits)
             s = Spec((wp, pack.pack_bias(self.p.get(name + ".bias"), w.shape[0]), w.shape[2], w.shape[3], pack.pad8(w.shape[0])))
             s.korder = 2 if frag else 0                            # spatial layers of wide tensors: weights as an MFMA fragment stream
@@ -196,7 +154,7 @@ class Engine:
                 biases.append(bb)
             wp = torch.cat(rows, 0)
             s = Spec((wp.to(self.dtype).contiguous(), torch.cat(biases).float().contiguous(), kh, kw, wp.shape[0]))
-            if self.use_frag and pack.frag_eligible(wp.shape[0], cin_total, kh, kw, self.dtype):
+            if pack.frag_eligible(wp.shape[0], cin_total, kh, kw, self.dtype):
                 w4 = wp.reshape(wp.shape[0], kh, kw, cin_total).permute(0, 3, 1, 2)            # back to (Cout, Cin, KH, KW): rows are padded already
                 s = Spec((pack.pack_conv_frag(w4, self.dtype, [(cin_total, cin_total)]), s[1], kh, kw, wp.shape[0]))
                 s.korder = 2
@@ -219,23 +177,16 @@ class Engine:
         the kernel -- needs the row sums of the packed weight, computed once per layer."""
         wp, bp, kh, kw_, cout = spec
         # a plain 1x1 C -> C layer (C = 128 / 256, fp16, optionally + residual): the direct form of K9 as a one-stage chain -- the weight as
-        # MFMA fragments straight into the operand registers instead of K5's LDS-staged K tiles (S2M2_PW_DIRECT=0: off)
-        if (self.pw_direct and self.chain_direct and kh == 1 and kw_ == 1 and len(srcs) == 1 and self.dtype == torch.float16
-                and srcs[0].shape[-1] == cout and tuple(wp.shape) == (cout, cout) and not getattr(spec, "korder", 0)
-                and set(kw) <= {"act", "epi", "aux0"} and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
+        # MFMA fragments straight into the operand registers instead of K5's LDS-staged K tiles
+        if (kh == 1 and kw_ == 1 and len(srcs) == 1 and srcs[0].shape[-1] == cout and tuple(wp.shape) == (cout, cout)
+                and not getattr(spec, "korder", 0) and set(kw) <= {"act", "epi", "aux0"}
+                and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
                 and kw.get("epi", hip.EPI_NONE) in (hip.EPI_NONE, hip.EPI_ADD) and ("aux0" in kw) == (kw.get("epi", hip.EPI_NONE) == hip.EPI_ADD)
-                and ("aux0" not in kw or tuple(kw["aux0"].shape) == tuple(srcs[0].shape))
-                and srcs[0].numel() // cout <= self.chain_direct_max and self.chain_frag_ok(cout, self.dtype)):
+                and ("aux0" not in kw or tuple(kw["aux0"].shape) == tuple(srcs[0].shape)) and self.chain_frag_ok(cout)):
             st = [(self.wfrag(spec), bp, kw.get("act", hip.ACT_NONE), self.wsum(spec) if ln else None)]
             if "aux0" in kw:
                 return hip.mlp_chain(srcs[0], st, res=kw["aux0"], res_stage=0, frag=True)
             return hip.mlp_chain(srcs[0], st, frag=True)
-        # a plain 1x1 C -> C layer on >= 32768 rows of 128 fp16 channels (1/4 resolution): the weights-stationary persistent form of K9 as a
-        # one-stage chain (the 32 KB weight resident in LDS, one pass over the rows) instead of the K5 tile kernel
-        if (self.pw_ws and kh == 1 and kw_ == 1 and len(srcs) == 1 and self.dtype == torch.float16 and cout == 128 and srcs[0].shape[-1] == 128
-                and tuple(wp.shape) == (128, 128) and srcs[0].numel() // 128 >= 32768 and not getattr(spec, "korder", 0)
-                and set(kw) <= {"act"} and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU) and self.chain_ok(128)):
-            return hip.mlp_chain(srcs[0], [(wp, bp, kw.get("act", hip.ACT_NONE), self.wsum(spec) if ln else None)])
         if ln:
             kw["ln_wsum"] = self.wsum(spec)
         if getattr(spec, "korder", 0):
@@ -255,32 +206,18 @@ class Engine:
             self._bufs[k] = b
         return b
 
-    # ---- two-stream fork / join ------------------------------------------------------------------------
-    def fork(self):
-        """Context manager: the body is enqueued on the side stream, after everything already enqueued on the current stream."""
-        return _Fork(self.side)
-
-    def join(self, *tensors: Tensor) -> None:
-        """The current stream waits for the side stream; tensors produced there are marked as used here (allocator safety)."""
-        if self.side is None:
-            return
-        cur = torch.cuda.current_stream(self.device)
-        cur.wait_stream(self.side)
-        for t in tensors:
-            t.record_stream(cur)
-
     # ---- building blocks -----------------------------------------------------------------------------
     def down(self, p: str, x: Tensor) -> Tensor:
         """nn.AvgPool2d(2) -> Conv2d 1x1 (unet.py:24-29, stacked_MRT.py:21-26): the pooling is folded into the GEMM's operand load (same
         mean, rounded to the activation dtype like the stand-alone K7 launch it replaces)."""
         spec = self.std(p + ".1")
         c = x.shape[-1]
-        if (self.pool_direct and self.chain_direct and self.fuse_pool and self.dtype == torch.float16 and spec[2] == 1 and spec[3] == 1
-                and x.dim() == 4 and x.shape[1] >= 2 and x.shape[2] >= 2 and tuple(spec[0].shape) in ((c, c), (2 * c, c)) and spec[4] == spec[0].shape[0]
-                and not getattr(spec, "korder", 0) and self.chain_frag_ok(c)):
+        pooled = spec[2] == 1 and spec[3] == 1 and x.dim() == 4 and x.shape[1] >= 2 and x.shape[2] >= 2
+        if (pooled and tuple(spec[0].shape) in ((c, c), (2 * c, c)) and spec[4] == spec[0].shape[0] and not getattr(spec, "korder", 0)
+                and self.chain_frag_ok(c)):
             # pooled 1x1 C -> C / C -> 2C: a fan-out-only launch of the direct K9 form, the 2x2 mean formed while the row tile is loaded
-            return hip.mlp_fan(x, self.wfrag(spec), spec[1], None, frag=True, pool2=True)
-        if self.fuse_pool and spec[2] == 1 and spec[3] == 1 and x.shape[1] >= 2 and x.shape[2] >= 2:
+            return hip.mlp_fan(x, self.wfrag(spec), spec[1], None, pool2=True)
+        if pooled:
             return self.cconv(spec, [x], pool2=True)
         return self.cconv(spec, [hip.resample2x(x, 0)])
 
@@ -296,18 +233,16 @@ class Engine:
     def conv_block(self, p: str, z: Tensor) -> Tensor:
         """ConvBlock2D (attentions.py:255-281): conv3-GELU-conv3 + conv1-ReLU-conv1."""
         c0, c2 = self.std(p + ".convs_1x.0"), self.std(p + ".convs_1x.2")
-        chain = self.use_chain and self.chain_ok(z.shape[-1]) and c0[4] == z.shape[-1] and c2[4] == z.shape[-1]
-        with self.fork():                                         # 1x1 branch in parallel with the first 3x3
-            if chain and self.chain_direct and z.numel() // z.shape[-1] <= self.chain_direct_max and self.chain_frag_ok(z.shape[-1], self.dtype):
-                u = b = hip.mlp_chain(z, [(self.wfrag(c0), c0[1], hip.ACT_RELU, None), (self.wfrag(c2), c2[1], hip.ACT_NONE, None)], frag=True)
-            elif chain:
-                u = b = hip.mlp_chain(z, [(c0[0], c0[1], hip.ACT_RELU, None), (c2[0], c2[1], hip.ACT_NONE, None)])
-            else:
-                u = self.cconv(c0, [z], act=hip.ACT_RELU)
-                b = self.cconv(c2, [u])
+        c = z.shape[-1]
+        same = c0[4] == c and c2[4] == c
+        if same and self.chain_frag_ok(c):                         # the 1x1 branch as one K9 launch (direct form)
+            b = hip.mlp_chain(z, [(self.wfrag(c0), c0[1], hip.ACT_RELU, None), (self.wfrag(c2), c2[1], hip.ACT_NONE, None)], frag=True)
+        elif same and self.chain_ok(c):
+            b = hip.mlp_chain(z, [(c0[0], c0[1], hip.ACT_RELU, None), (c2[0], c2[1], hip.ACT_NONE, None)])
+        else:
+            b = self.cconv(c2, [self.cconv(c0, [z], act=hip.ACT_RELU)])
         t = self.cconv(self.std(p + ".convs.0"), [z], act=hip.ACT_GELU)
-        self.join(b, u)
-        return self.cconv(self.std(p + ".convs.2", frag=self.frag_aux), [t], epi=hip.EPI_ADD, aux0=b)
+        return self.cconv(self.std(p + ".convs.2"), [t], epi=hip.EPI_ADD, aux0=b)
 
     def dual_heads(self, p: str):
         """[gate.2 | fusion.2] stacked along K (the channel order of the hidden tensor) + the two biases"""
@@ -325,10 +260,10 @@ class Engine:
         return ok
 
     def k10(self, p: str, z0: Tensor, z1: Tensor, first: Spec, z1_coarse: bool = False) -> Tensor:
-        """one K10 launch; short row counts take the direct form (weights as one fragment stream, permuted once per layer)"""
+        """one K10 launch; fp16 at C = 128 / 256 takes the direct form (weights as one fragment stream, permuted once per layer)"""
         dual = self.dual_heads(p)
         c = z0.shape[-1]
-        if self.fusion_direct and z0.numel() // c <= self.fusion_direct_max and self.fusion_frag_ok(c):
+        if self.fusion_frag_ok(c):
             key = p + "|k10 fragment stream"
             ws = self._packed.get(key)
             if ws is None:
@@ -342,7 +277,7 @@ class Engine:
         spec = self.std(pu + ".1")
         c = z0.shape[-1]
         first = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
-        if (self.fuse_fusion and self.fuse_up and spec[2] == 1 and spec[3] == 1 and spec[4] == c and first[2] == 1 and first[3] == 1
+        if (spec[2] == 1 and spec[3] == 1 and spec[4] == c and first[2] == 1 and first[3] == 1
                 and self.p[p + ".feature_gate.0.weight"].shape[0] == c and self.fusion_ok(c)):
             return self.k10(p, z0, self.cconv(spec, [xc]), first, z1_coarse=True)
         return self.fusion(p, z0, self.up(pu, xc))
@@ -353,10 +288,10 @@ class Engine:
         c = z0.shape[-1]
         cg = self.p[p + ".feature_gate.0.weight"].shape[0]
         spec = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
-        if self.fuse_fusion and spec[2] == 1 and spec[3] == 1 and cg == c and self.fusion_ok(c):
+        if spec[2] == 1 and spec[3] == 1 and cg == c and self.fusion_ok(c):
             return self.k10(p, z0, z1, spec)                       # K10: the whole block in one launch, h never leaves the CU
         gf = self.cconv(spec, [z0, z1], act=hip.ACT_GELU)
-        if self.fuse_heads and cg % 64 == 0:
+        if cg % 64 == 0:
             # both second layers in one launch: weight rows [gate.2 | fusion.2] along K (= the channel order of gf), two accumulators
             dual = self.dual_heads(p)
             return hip.conv2d([gf], dual[0], dual[1], 1, 1, dual[0].shape[0], act=hip.ACT_SIGMOID, epi=hip.EPI_DUALMIX, aux0=z0, aux1=z1,
@@ -379,14 +314,9 @@ class Engine:
     def qkv(self, p: str, x: Tensor) -> Tensor:
         spec = self.qkv_spec(p)
         c = x.shape[-1]
-        rows = x.numel() // c
-        if (self.qkv_direct and self.chain_direct and self.fuse_ln and spec[2] == 1 and spec[3] == 1 and spec[4] == 3 * c
-                and self.dtype == torch.float16 and rows <= self.chain_direct_max and self.chain_frag_ok(c)):
-            return hip.mlp_fan(x, self.wfrag(spec), spec[1], self.wsum(spec), frag=True)    # direct form: fragments straight into registers
-        if (self.fan_ws and self.fuse_ln and spec[2] == 1 and spec[3] == 1 and spec[4] == 3 * c and rows >= 32768
-                and hip.mlp_fan_supported(c, 3, self.dtype)):
-            return hip.mlp_fan(x, spec[0], spec[1], self.wsum(spec))       # one pass over the rows, the stacked weight resident in LDS
-        return self.cconv(spec, [x], ln=self.fuse_ln) if self.fuse_ln else self.cconv(spec, [hip.layernorm(x)])
+        if spec[2] == 1 and spec[3] == 1 and spec[4] == 3 * c and self.chain_frag_ok(c):
+            return hip.mlp_fan(x, self.wfrag(spec), spec[1], self.wsum(spec))     # direct form: fragments straight into registers
+        return self.cconv(spec, [x], ln=True)                                    # pre-LayerNorm folded into the K5 launch
 
     def attn_core(self, p: str, z: Tensor, nh: int, two_d: bool, cross: bool, use_pe: bool, qkv: Optional[Tensor] = None) -> Tensor:
         """pre-LN -> fused QKV projection -> K4; returns the attention output BEFORE the output projection (see attn_ffn).  qkv: the
@@ -430,45 +360,32 @@ class Engine:
         (the rows are still in LDS): one launch and one round trip of the rows less per attention.  -> (result, qkv or None)."""
         c = z.shape[-1]
         proj, f0, f2 = self.std(pa + ".attn.proj"), self.std(pf + ".ffn.0"), self.std(pf + ".ffn.2")
-        if self.use_chain and self.chain_ok(c):
-            stages = [(proj[0], proj[1], hip.ACT_NONE, None), (f0[0], f0[1], hip.ACT_GELU, self.wsum(f0)), (f2[0], f2[1], hip.ACT_NONE, None)]
-            if (self.chain_direct and ln_out is None and z.numel() // c <= self.chain_direct_max and self.fuse_ln
-                    and self.chain_frag_ok(c, self.dtype)):
-                # short row counts: the launch lives for the latency of its weight stream -- fragments straight into registers, and the
-                # next attention's Q | K | V projection rides along as fan-out stages (one launch and one round trip of the rows less)
-                fstages = [(self.wfrag(sp), sp[1], act, ws) for sp, (_, _, act, ws) in zip((proj, f0, f2), stages)]
-                if next_attn is not None and self.chain_direct_qkv:
-                    qs = self.qkv_spec(next_attn)
-                    if qs[2] == 1 and qs[3] == 1 and qs[4] == 3 * c:
-                        out, qkv = hip.mlp_chain(o, fstages, res=z, res_stage=0, carry=True, fan=(self.wfrag(qs), qs[1], self.wsum(qs)), frag=True)
-                        return out, qkv
-                return hip.mlp_chain(o, fstages, res=z, res_stage=0, carry=True, frag=True), None
-            if next_attn is not None and self.fuse_qkv and self.fuse_ln and ln_out is None:
+        if ln_out is not None and not hip.mlp_chain_ln_out_supported(c, self.dtype):
+            ln_out = None                                          # (widths without the LayerNorm output: K1 normalises the tokens itself)
+        # K1 places image row y on XCD y / (h / 8): hand the token rows of that eighth of every image to the same XCD
+        n, h, w, _ = z.shape
+        grp = ((h // 8) * w if h % 8 == 0 else 0) if ln_out is not None else 0
+        acts = (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_NONE)
+        if self.chain_frag_ok(c):
+            # direct form: fragments straight into registers; the next attention's Q | K | V projection rides along as fan-out stages (one
+            # launch and one round trip of the rows less), or the launch that writes feature_tr_4x also writes K1's normalised tokens
+            st = [(self.wfrag(sp), sp[1], act, self.wsum(sp) if sp is f0 else None) for sp, act in zip((proj, f0, f2), acts)]
+            if ln_out is not None:
+                out, self._tokens_normed = hip.mlp_chain(o, st, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp, frag=True)
+                return out, None
+            if next_attn is not None:
                 qs = self.qkv_spec(next_attn)
                 if qs[2] == 1 and qs[3] == 1 and qs[4] == 3 * c:
-                    out, qkv = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, fan=(qs[0], qs[1], self.wsum(qs)))
-                    return out, qkv
-            if ln_out is not None and hip.mlp_chain_ln_out_supported(c, self.dtype):
-                # K1 places image row y on XCD y / (h / 8): hand the token rows of that eighth of every image to the same XCD
-                n, h, w, _ = z.shape
-                grp = (h // 8) * w if h % 8 == 0 else 0
-                tiled = self.k1_stream and hip.corr_tiled_supported(c, self.dtype)     # fragment order for the streaming form of K1
-                if self.k1_hybrid and not tiled and hip.corr_hybrid_supported(c, self.dtype) and w % 8 == 0:
-                    tiled = "left"
-                if (self.chain_direct and self.chain_direct_ln and not tiled and self.fuse_ln and z.numel() // c <= self.chain_direct_max
-                        and self.chain_frag_ok(c, self.dtype)):
-                    fstages = [(self.wfrag(sp), sp[1], act, ws) for sp, (_, _, act, ws) in zip((proj, f0, f2), stages)]
-                    out, self._tokens_normed = hip.mlp_chain(o, fstages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp, frag=True)
-                    return out, None
-                out, self._tokens_normed = hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp,
-                                                         ln_out_tiled=tiled)
+                    return hip.mlp_chain(o, st, res=z, res_stage=0, carry=True, fan=(self.wfrag(qs), qs[1], self.wsum(qs)), frag=True)
+            return hip.mlp_chain(o, st, res=z, res_stage=0, carry=True, frag=True), None
+        if self.chain_ok(c):                                       # LDS-staged form (fp32; fp16 at C = 384 / 512)
+            st = [(sp[0], sp[1], act, self.wsum(sp) if sp is f0 else None) for sp, act in zip((proj, f0, f2), acts)]
+            if ln_out is not None:
+                out, self._tokens_normed = hip.mlp_chain(o, st, res=z, res_stage=0, carry=True, ln_out=ln_out, xcd_group_rows=grp)
                 return out, None
-            return hip.mlp_chain(o, stages, res=z, res_stage=0, carry=True), None
-        z = self.cconv(proj, [o], epi=hip.EPI_ADD, aux0=z)
-        if self.fuse_ln:
-            hdn = self.cconv(f0, [z], ln=True, act=hip.ACT_GELU)
-        else:
-            hdn = self.cconv(f0, [hip.layernorm(z)], act=hip.ACT_GELU)
+            return hip.mlp_chain(o, st, res=z, res_stage=0, carry=True), None
+        z = self.cconv(proj, [o], epi=hip.EPI_ADD, aux0=z)         # widths K9 does not take (C = 192): three K5 launches
+        hdn = self.cconv(f0, [z], ln=True, act=hip.ACT_GELU)
         return self.cconv(f2, [hdn], epi=hip.EPI_ADD, aux0=z), None
 
     def chain_frag_ok(self, c: int, dtype=None) -> bool:
@@ -558,18 +475,14 @@ class Engine:
         r * h epilogue (s2m2_conv_desc.epi_cout0; fp16 / K order 2) -- 6 launches fewer per refinement step and cat(h, x) read once."""
         C = h.shape[-1]
         for sfx in ("1", "2"):
-            zr = None
-            if self.fuse_gru and self.frag_aux:
-                zr = self.merged(f"{p}|zr{sfx}", [(f"{p}.convz{sfx}", 0, 1.0, False), (f"{p}.convr{sfx}", 0, 1.0, False)], h.shape[-1] + x.shape[-1])
-            if zr is not None and getattr(zr, "korder", 0) == 2 and zr[4] == 2 * C and C % 128 == 0:
+            zr = self.merged(f"{p}|zr{sfx}", [(f"{p}.convz{sfx}", 0, 1.0, False), (f"{p}.convr{sfx}", 0, 1.0, False)], h.shape[-1] + x.shape[-1])
+            if getattr(zr, "korder", 0) == 2 and zr[4] == 2 * C and C % 128 == 0:
                 both = self.cconv(zr, [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h, epi_cout0=C)
                 z, rh = both[..., :C], both[..., C:]
             else:
-                with self.fork():
-                    z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
-                rh = self.cconv(self.std(f"{p}.convr{sfx}", frag=self.frag_aux), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
-                self.join(z)
-            h = self.cconv(self.std(f"{p}.convq{sfx}", frag=self.frag_aux2), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
+                z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
+                rh = self.cconv(self.std(f"{p}.convr{sfx}"), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
+            h = self.cconv(self.std(f"{p}.convq{sfx}", frag=False), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
 
     def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it,
@@ -632,7 +545,7 @@ class Engine:
         x8 = hip.image_prep(img0, img1, self.dtype)                             # (2B,H,W,8): channels 1..3 = normalised RGB, 0 free
         p = "cnn_backbone"                                                      # CNNEncoder (submodules.py:63-93)
         c0, c2 = self._conv0(), self.std(p + ".conv0.2")
-        if self.fuse_stem and tuple(c0[0].shape) == (16, 8) and tuple(c2[0].shape) == (16, 16) and c0[2] == 1 and c2[2] == 1:
+        if tuple(c0[0].shape) == (16, 8) and tuple(c2[0].shape) == (16, 16) and c0[2] == 1 and c2[2] == 1:
             st = self._packed.get("stem|fp32")                                  # conv0 = 1x1 - GELU - 1x1 per pixel on the VALU (K8)
             if st is None:
                 st = self._packed["stem|fp32"] = (c0[0].float().contiguous(), c0[1], c2[0].float().contiguous(), c2[1])
@@ -644,7 +557,7 @@ class Engine:
         f2 = self.cconv(self.std(p + ".conv1_down.2"), [t])
         f2 = hip.groupnorm_nhwc(f2, 8, self.p[p + ".norm1.weight"], self.p[p + ".norm1.bias"])
         t = self.cconv(self.std(p + ".conv2.0"), [f2], act=hip.ACT_GELU)
-        f2 = self.cconv(self.std(p + ".conv2.2", frag=self.frag_aux), [t], epi=hip.EPI_ADD, aux0=f2)
+        f2 = self.cconv(self.std(p + ".conv2.2"), [t], epi=hip.EPI_ADD, aux0=f2)
         f4 = self.cconv(self.std(p + ".conv2_down.0", frag=False), [f2], stride=2)
         py = self.unet("feat_pyramid", f4)
         z = py
@@ -671,16 +584,14 @@ class Engine:
         if normed is not None:
             if out is None:
                 out = self.cv_buffer(tr)
-            if isinstance(normed, hip.TiledTokens):
-                return hip.corr_tiled(normed, out=out, timer=timer, band=band)
-            if isinstance(normed, hip.HybridTokens):
-                return hip.corr_hybrid(normed, out=out, timer=timer, band=band)
             return hip.corr(normed, out=out, timer=timer, band=band)
+        if out is None:
+            out = self.cv_buffer(tr)
         return hip.ln_corr(tr, self.ln_w, self.ln_b, out=out, timer=timer, band=band)
 
     def cv_buffer(self, tr: Tensor) -> Tensor:
         twoB, h, w, _ = tr.shape
-        return hip.cv_alloc(twoB // 2, h, w, tr.dtype, tr.device, aligned=self.cv_aligned)
+        return hip.cv_alloc(twoB // 2, h, w, tr.dtype, tr.device)
 
     @torch.no_grad()
     def finish(self, tr: Tensor, py0: Tensor, f2_left: Tensor, x8: Tensor, cv: Tensor, cap: Optional[dict] = None):
@@ -738,16 +649,14 @@ class Engine:
         launch that writes the tokens (attn_ffn) and K1 is the correlation alone (s2m2_corr) -- the kernel bench.py's roofline line
         measures.  So that injected runs exercise THAT pair and not K1's own-LayerNorm form, the injected tokens go through the same
         launch form: a one-stage K9 chain with an identity weight (x * 1 summed with zeros in fp32 is exact in both modes) whose
-        LayerNorm output feeds hip.corr.  Row-major outputs only (the opt-in fragment-ordered K1 forms keep K1's own LayerNorm)."""
-        if not isinstance(self._tokens_normed, Tensor):
-            return None
+        LayerNorm output feeds hip.corr."""
         n, h, w, c = tr.shape
         eye = self._packed.get("identity|k9")
         if eye is None:
             eye = self._packed["identity|k9"] = Spec((torch.eye(c, device=tr.device, dtype=tr.dtype).contiguous(), None, 1, 1, c))
         grp = (h // 8) * w if h % 8 == 0 else 0
         ln_out = (self.ln_w, self.ln_b, 1e-5)
-        if self.chain_direct and self.chain_direct_ln and self.fuse_ln and self.chain_frag_ok(c, self.dtype):
+        if self.chain_frag_ok(c):
             return hip.mlp_chain(tr, [(self.wfrag(eye), None, hip.ACT_NONE, None)], ln_out=ln_out, xcd_group_rows=grp, frag=True)[1]
         return hip.mlp_chain(tr, [(eye[0], None, hip.ACT_NONE, None)], ln_out=ln_out, xcd_group_rows=grp)[1]
 
@@ -797,7 +706,7 @@ class GraphRunner:
                 self.state = eng.features(self.l, self.r)
             tr = self.state[0]
             self.normed = eng._tokens_normed
-            self.cv = eng.cv_buffer(tr) if self.normed is not None else torch.empty((B, tr.shape[1], tr.shape[2], tr.shape[2]), device=dev, dtype=tr.dtype)
+            self.cv = eng.cv_buffer(tr)
             eng.cost_volume(tr, out=self.cv, normed=self.normed)
             self.gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.gb, pool=self.ga.pool(), capture_error_mode=mode):
@@ -818,23 +727,3 @@ class GraphRunner:
             b = base.clone()                                       # one copy out of the graph's static output buffer
             return tuple(b[k] for k in range(len(self.out)))
         return tuple(o.clone() for o in self.out)
-
-
-class _Fork:
-    """``with engine.fork():`` -- run the body on the side stream (no-op without one)."""
-
-    def __init__(self, side):
-        self.side = side
-        self.ctx = None
-
-    def __enter__(self):
-        if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream(self.side.device))
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False

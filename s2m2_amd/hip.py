@@ -41,7 +41,7 @@ class ChainDesc(ctypes.Structure):
                 ("C", _i), ("nstage", _i), ("weight", _vp * 3), ("bias", _vp * 3), ("ln_wsum", _vp * 3), ("act", _i * 3),
                 ("res_stage", _i), ("carry", _i), ("ln_eps", ctypes.c_float), ("dtype", _i),
                 ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_out_eps", ctypes.c_float),
-                ("ln_out_tile_w", _i), ("ln_out_tile_rows", _ll), ("ln_out_rows", _vp), ("fan_weight", _vp), ("fan_bias", _vp), ("fan_ln_wsum", _vp), ("fan_out", _vp), ("fan_out_stride", _ll),
+                ("fan_weight", _vp), ("fan_bias", _vp), ("fan_ln_wsum", _vp), ("fan_out", _vp), ("fan_out_stride", _ll),
                 ("nfan", _i), ("xcd_group_rows", _ll), ("weight_frag", _i), ("pool_h", _i), ("pool_w", _i)]
 
 
@@ -55,15 +55,12 @@ SIGNATURES = {
     "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "s2m2_ln_corr_timed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_ln_corr_banded": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "s2m2_debug_store_pattern": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_event_create": (_i, [ctypes.POINTER(_vp)]),
     "s2m2_event_destroy": (_i, [_vp]),
     "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "s2m2_sinkhorn_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "s2m2_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "s2m2_corr_tiled_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
-    "s2m2_corr_tiled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "s2m2_corr_hybrid": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_ln_corr_pitched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
@@ -169,26 +166,18 @@ class KernelTimer:
 def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype: Optional[torch.dtype] = None,
             out: Optional[torch.Tensor] = None, timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
     """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w).  [A4]   timer: see KernelTimer.  band >= 0: only
-    columns j <= i + band are written (s2m2_ln_corr_banded), the rest of ``cv`` keeps whatever it held."""
+    columns j <= i + band are written, the rest of ``cv`` keeps whatever it held.  ``out`` may be a row-padded view (cv_alloc)."""
     _dev(feat, ln_w, ln_b)
     twoB, h, w, C = feat.shape
     B = twoB // 2
     cv_dtype = cv_dtype or feat.dtype
     cv = out if out is not None else torch.empty((B, h, w, w), device=feat.device, dtype=cv_dtype)
-    if tuple(cv.shape) != (B, h, w, w) or not cv.is_contiguous():
-        raise ValueError("ln_corr: out must be a contiguous (B,h,w,w) tensor")
-    cv_dtype = cv.dtype
-    if band >= 0:
-        _check(load().s2m2_ln_corr_banded(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
-                                          B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], band, _stream(),
-                                          timer.start if timer is not None else None, timer.stop if timer is not None else None),
-               "s2m2_ln_corr_banded")
-    elif timer is not None:
-        _check(load().s2m2_ln_corr_timed(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
-                                         B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream(), timer.start, timer.stop), "s2m2_ln_corr_timed")
-    else:
-        _check(load().s2m2_ln_corr(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(),
-                                   B, h, w, C, _DT[feat.dtype], _DT[cv_dtype], _stream()), "s2m2_ln_corr")
+    if tuple(cv.shape) != (B, h, w, w):
+        raise ValueError("ln_corr: out must be a (B,h,w,w) tensor")
+    pitch = _cv_pitch(cv, "ln_corr")
+    _check(load().s2m2_ln_corr_pitched(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(), B, h, w, C, pitch,
+                                       _DT[feat.dtype], _DT[cv.dtype], band, _stream(),
+                                       timer.start if timer is not None else None, timer.stop if timer is not None else None), "s2m2_ln_corr_pitched")
     _meter("ln_corr", 2.0 * B * h * w * w * C)
     return cv
 
@@ -211,97 +200,6 @@ def cv_alloc(B: int, h: int, w: int, dtype: torch.dtype, device, aligned: bool =
     per = 128 // (2 if dtype == torch.float16 else 4)
     pitch = (w + per - 1) // per * per if aligned else w
     return torch.empty((B, h, w, pitch), device=device, dtype=dtype)[..., :w]
-
-
-class TiledTokens:
-    """Normalised fp16 tokens of a stereo pair batch (2B,h,w,C) in the MFMA-fragment order of s2m2_corr_tiled (written by
-    mlp_chain(..., ln_out_tiled=True)): image rows cut into 32-token tiles, a tile = C/16 fragments of 1 KB (lane-major)."""
-
-    def __init__(self, B: int, h: int, w: int, C: int, device):
-        self.B, self.h, self.w, self.C = B, h, w, C
-        n = int(load().s2m2_corr_tiled_bytes(B, h, w, C))
-        self.buf = torch.empty(n // 2, device=device, dtype=torch.float16)
-
-    @staticmethod
-    def from_rows(tokens: torch.Tensor) -> "TiledTokens":
-        """(2B,h,w,C) fp16 rows -> fragment order (test / tool helper; the engine's tokens arrive tiled from K9)"""
-        twoB, h, w, C = tokens.shape
-        t = TiledTokens(twoB // 2, h, w, C, tokens.device)
-        nt = (w + 31) // 32
-        x = torch.zeros((twoB, h, nt * 32, C), device=tokens.device, dtype=torch.float16)
-        x[:, :, :w] = tokens
-        # (n, y, tile, r, kk, hh, e) -> (n, y, tile, kk, hh, r, e)
-        x = x.reshape(twoB, h, nt, 32, C // 16, 2, 8).permute(0, 1, 2, 4, 5, 3, 6).contiguous()
-        t.buf.copy_(x.reshape(-1))
-        return t
-
-    def to_rows(self) -> torch.Tensor:
-        nt = (self.w + 31) // 32
-        x = self.buf.reshape(2 * self.B, self.h, nt, self.C // 16, 2, 32, 8).permute(0, 1, 2, 5, 3, 4, 6)
-        return x.reshape(2 * self.B, self.h, nt * 32, self.C)[:, :, :self.w].contiguous()
-
-
-def corr_tiled(tokens: TiledTokens, cv_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None,
-               timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
-    """K1, streaming form (s2m2_corr_tiled) -> cv (B,h,w,w), a row-padded view (cv_alloc) unless ``out`` is given."""
-    B, h, w, C = tokens.B, tokens.h, tokens.w, tokens.C
-    cv = out if out is not None else cv_alloc(B, h, w, cv_dtype, tokens.buf.device)
-    if tuple(cv.shape) != (B, h, w, w):
-        raise ValueError("corr_tiled: out must be a (B,h,w,w) tensor")
-    pitch = _cv_pitch(cv, "corr_tiled")
-    _check(load().s2m2_corr_tiled(tokens.buf.data_ptr(), cv.data_ptr(), B, h, w, C, pitch, _DT[cv.dtype], band, _stream(),
-                                  timer.start if timer is not None else None, timer.stop if timer is not None else None), "s2m2_corr_tiled")
-    _meter("ln_corr", 2.0 * B * h * w * w * C)
-    return cv
-
-
-class HybridTokens:
-    """Normalised fp16 tokens of a stereo pair batch for s2m2_corr_hybrid (written by mlp_chain(..., ln_out_tiled="left")): the B left
-    images in the MFMA-fragment order of TiledTokens (``left``, a flat buffer), the B right images row-major (``right`` (B,h,w,C))."""
-
-    def __init__(self, B: int, h: int, w: int, C: int, device):
-        self.B, self.h, self.w, self.C = B, h, w, C
-        n = int(load().s2m2_corr_tiled_bytes(B, h, w, C)) // 2
-        self.left = torch.empty(n // 2, device=device, dtype=torch.float16)
-        self.right = torch.empty((B, h, w, C), device=device, dtype=torch.float16)
-
-    @staticmethod
-    def from_rows(tokens: torch.Tensor) -> "HybridTokens":
-        """(2B,h,w,C) fp16 rows -> left tiled / right row-major (test / tool helper)"""
-        twoB, h, w, C = tokens.shape
-        t = HybridTokens(twoB // 2, h, w, C, tokens.device)
-        both = TiledTokens.from_rows(tokens)
-        t.left.copy_(both.buf[:t.left.numel()])
-        t.right.copy_(tokens[twoB // 2:])
-        return t
-
-    def to_rows(self) -> torch.Tensor:
-        nt = (self.w + 31) // 32
-        x = self.left.reshape(self.B, self.h, nt, self.C // 16, 2, 32, 8).permute(0, 1, 2, 5, 3, 4, 6)
-        return torch.cat([x.reshape(self.B, self.h, nt * 32, self.C)[:, :, :self.w], self.right], 0).contiguous()
-
-
-def corr_hybrid(tokens: HybridTokens, cv_dtype: torch.dtype = torch.float16, out: Optional[torch.Tensor] = None,
-                timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
-    """K1 with the left tokens read in fragment order (s2m2_corr_hybrid) -> cv (B,h,w,w), a row-padded view unless ``out`` is given."""
-    B, h, w, C = tokens.B, tokens.h, tokens.w, tokens.C
-    cv = out if out is not None else cv_alloc(B, h, w, cv_dtype, tokens.left.device)
-    if tuple(cv.shape) != (B, h, w, w):
-        raise ValueError("corr_hybrid: out must be a (B,h,w,w) tensor")
-    pitch = _cv_pitch(cv, "corr_hybrid")
-    _check(load().s2m2_corr_hybrid(tokens.left.data_ptr(), tokens.right.data_ptr(), cv.data_ptr(), B, h, w, C, pitch, _DT[cv.dtype], band,
-                                   _stream(), timer.start if timer is not None else None, timer.stop if timer is not None else None),
-           "s2m2_corr_hybrid")
-    _meter("ln_corr", 2.0 * B * h * w * w * C)
-    return cv
-
-
-def corr_hybrid_supported(C: int, dtype: torch.dtype) -> bool:
-    return dtype == torch.float16 and C in (64, 128)
-
-
-def corr_tiled_supported(C: int, dtype: torch.dtype) -> bool:
-    return dtype == torch.float16 and C in (64, 128, 256)
 
 
 def corr(tokens: torch.Tensor, cv_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
@@ -461,11 +359,13 @@ def mlp_fan_supported(C: int, nfan: int, dtype: torch.dtype) -> bool:
 
 
 def mlp_fan(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ln_wsum: Optional[torch.Tensor], ln_eps: float = 1e-5,
-            frag: bool = False, pool2: bool = False) -> torch.Tensor:
+            frag: bool = True, pool2: bool = False) -> torch.Tensor:
     """n stacked C -> C layers on the rows of x (..., C) -> (..., n*C) in one pass over the rows (s2m2_mlp_chain with nstage = 0: the
-    weights-stationary fan-out form; pre-LayerNorm folded in when ln_wsum is given).  weight packed (n*C, C).  frag: the weight is in
-    MFMA-fragment order (pack.chain_frag) -> the direct form (mlp_chain_frag_supported; any row count, n <= 4).  pool2 (with frag; x
-    (N,H,W,C)): nn.AvgPool2d(2) in front of the layers, folded into the tile load -> (N, H//2, W//2, n*C)."""
+    fan-out-only launch of the direct form; pre-LayerNorm folded in when ln_wsum is given).  weight (n*C, C) in MFMA-fragment order
+    (pack.chain_frag; mlp_fan_supported: fp16, C = 128 / 256, any row count, n <= 4).  pool2 (x (N,H,W,C)): nn.AvgPool2d(2) in front of
+    the layers, folded into the tile load -> (N, H//2, W//2, n*C)."""
+    if not frag:
+        raise ValueError("mlp_fan: the fan-out-only launch exists in the direct form only (weight in fragment order, frag=True)")
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_fan")
     n = weight.shape[0] // C
@@ -507,14 +407,12 @@ def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
               ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0,
-              ln_out_tiled=False, fan=None, frag: bool = False):
+              fan=None, frag: bool = False):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
     res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
     ln_out = (gamma fp32 (C), beta fp32 (C), eps): also return LayerNorm(out) * gamma + beta  -> (out, normalised).
     xcd_group_rows: placement hint (s2m2_chain_desc): x is images of 8 groups of that many rows, group g runs on XCD g.
-    ln_out_tiled (x (N,h,w,C) fp16): the normalised rows come back as a TiledTokens buffer in the fragment order corr_tiled reads;
-    ln_out_tiled="left": as a HybridTokens pair (left images in fragment order, right images row-major) for corr_hybrid.
     fan = (packed weight (n*C, C), fp32 bias (n*C) or None, ln_wsum fp32 (n*C) or None): n further C -> C layers on the OUTPUT rows
     (pre-LayerNorm folded in when ln_wsum is given), returned as one (..., n*C) tensor: the fused QKV projection of the next attention.
     frag: every weight (stages and fan) is in MFMA-fragment order (pack.chain_frag) -> the direct form of the kernel, meant for short row
@@ -554,20 +452,8 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
         _dev(gam, bet)
         if gam.dtype != torch.float32 or bet.dtype != torch.float32 or gam.numel() != C or bet.numel() != C:
             raise ValueError(f"mlp_chain: ln_out gamma / beta must be fp32 ({C})")
-        if ln_out_tiled:
-            if x.dim() != 4 or x.dtype != torch.float16 or x.shape[0] % 2:
-                raise ValueError("mlp_chain: ln_out_tiled needs (2B,h,w,C) fp16 rows")
-            d.ln_out_tile_w = x.shape[2]
-            if ln_out_tiled == "left":
-                normed = HybridTokens(x.shape[0] // 2, x.shape[1], x.shape[2], C, x.device)
-                d.ln_out_tile_rows, d.ln_out_rows = rows // 2, normed.right.data_ptr()
-                ln_ptr = normed.left.data_ptr()
-            else:
-                normed = TiledTokens(x.shape[0] // 2, x.shape[1], x.shape[2], C, x.device)
-                ln_ptr = normed.buf.data_ptr()
-        else:
-            normed = torch.empty(x.shape, device=x.device, dtype=x.dtype)
-            ln_ptr = normed.data_ptr()
+        normed = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+        ln_ptr = normed.data_ptr()
         d.ln_out, d.ln_out_stride, d.ln_gamma, d.ln_beta, d.ln_out_eps = ln_ptr, C, gam.data_ptr(), bet.data_ptr(), float(eps)
     fan_out = None
     nfan = 0

@@ -96,19 +96,7 @@ def make():
     def feature_fusion_frag_supported(C, dtype):
         return False
 
-    def corr_tiled_supported(C, dtype):
-        return False                                     # (the CPU stand-in keeps row-major tokens: the fp32 wiring test never tiles)
-
-    class TiledTokens:                                   # only the isinstance() check of Engine.cost_volume needs it
-        pass
-
-    class HybridTokens:
-        pass
-
-    def corr_hybrid_supported(C, dtype):
-        return False
-
-    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0, ln_out_tiled=False, fan=None):
+    def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0, fan=None, frag=False):
         t, ys = x.float(), []
         for s, (w, b, act, wsum) in enumerate(stages):
             a = F.layer_norm(t, (t.shape[-1],), eps=ln_eps) if wsum is not None else t
@@ -231,8 +219,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, corr_tiled_supported, corr_hybrid_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
-    ns.TiledTokens = TiledTokens
-    ns.HybridTokens = HybridTokens
     return ns

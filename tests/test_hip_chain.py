@@ -65,7 +65,7 @@ CASES = [  # C, dtype, rows-shape, nstage, ln_stage, acts, res_stage, carry
     (256, torch.float32, (2, 16, 19), 3, 1, (0, 1, 0), 0, True),
     (256, torch.float32, (1, 6, 11), 2, -1, (2, 0), -1, False),
     (128, torch.float32, (1, 9, 30), 2, 0, (1, 0), 1, False),
-    # >= 32768 rows at C = 128 fp16: the weights-stationary persistent form (mlp_chain_ws_kernel), incl. ragged row counts
+    # long row counts at C = 128 fp16 (64-row tiles), incl. ragged row counts
     (128, torch.float16, (2, 256, 304), 3, 1, (0, 1, 0), 0, True),
     (128, torch.float16, (1, 255, 303), 2, -1, (2, 0), -1, False),
     (128, torch.float16, (1, 250, 301), 1, 0, (1,), 0, False),
@@ -161,25 +161,6 @@ def test_chain_xcd_placement_hint_changes_nothing_but_the_block_order(hip):
     assert torch.equal(a[0], c)
 
 
-@pytest.mark.parametrize("hh", [5, 300])              # 300: 43 200 rows -> the weights-stationary form
-def test_chain_layernorm_output_in_fragment_order(hip, hh):
-    """ln_out_tiled: the same normalised rows, stored in the MFMA-fragment order s2m2_corr_tiled reads (ragged last 32-token tile)."""
-    C, dtype = 128, torch.float16
-    g = torch.Generator(device="cuda").manual_seed(9)
-    x = (torch.randn(2, hh, 72, C, device="cuda", generator=g) * 2).to(dtype)        # w = 72: tiles of 32, 32, 8 tokens
-    res = torch.randn(2, hh, 72, C, device="cuda", generator=g).to(dtype)
-    raw, packed = _make(C, 3, dtype, 1, (0, 1, 0), 21)
-    gam = 1 + 0.1 * torch.randn(C, device="cuda", generator=g)
-    bet = 0.05 * torch.randn(C, device="cuda", generator=g)
-    y0, n0 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5))
-    y1, t1 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), ln_out_tiled=True)
-    assert torch.equal(y0, y1) and isinstance(t1, hip.TiledTokens)
-    assert torch.equal(t1.to_rows(), n0)
-    y2, t2 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=True, ln_out=(gam, bet, 1e-5), ln_out_tiled="left")
-    assert torch.equal(y0, y2) and isinstance(t2, hip.HybridTokens)       # left image tiled, right image row-major
-    assert torch.equal(t2.to_rows(), n0) and torch.equal(t2.right, n0[1:])
-
-
 @pytest.mark.parametrize("C,dtype,shp,nst,nfan,ln", [(128, torch.float16, (2, 50, 61), 3, 3, True), (256, torch.float16, (2, 32, 38), 3, 3, True),
                                                       (256, torch.float16, (1, 64, 76), 3, 3, True), (384, torch.float16, (1, 16, 19), 3, 3, True),
                                                       (512, torch.float16, (1, 5, 7), 2, 2, False), (128, torch.float32, (2, 20, 31), 3, 3, True),
@@ -216,31 +197,6 @@ def test_chain_fan_out_stages(hip, C, dtype, shp, nst, nfan, ln):
         y3, n3, q3 = hip.mlp_chain(x, packed, res=res, res_stage=0, carry=nst == 3, ln_out=(gam, bet, 1e-5), fan=(wp, bp, wsum))
         assert torch.equal(y3, y) and torch.equal(q3, q)
         assert float((n3.float() - F.layer_norm(y.float(), (C,))).abs().max()) < (2e-5 if dtype == torch.float32 else 4e-3)
-
-
-@pytest.mark.parametrize("shp,nfan,ln", [((2, 256, 304), 3, True), ((1, 255, 303), 3, True), ((2, 128, 152), 3, True), ((1, 7, 9), 3, True),
-                                         ((1, 200, 300), 2, False), ((1, 100, 100), 1, True)])
-def test_fan_only_weights_stationary(hip, shp, nfan, ln):
-    """s2m2_mlp_chain with nstage = 0: nfan C -> C layers on the SAME input rows in one pass (the Q | K | V projection at 1/4 and 1/8
-    resolution) == the stand-alone K5 launch with the same folded pre-LayerNorm, and == F.linear(F.layer_norm(x)) in fp32."""
-    C, dtype = 128, torch.float16
-    assert hip.mlp_fan_supported(C, nfan, dtype) and not hip.mlp_fan_supported(256, 3, dtype) and not hip.mlp_fan_supported(C, 3, torch.float32)
-    g = torch.Generator(device="cuda").manual_seed(shp[1] + nfan)
-    x = (torch.randn(*shp, C, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
-    wq = (torch.randn(nfan * C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
-    bq = torch.randn(nfan * C, device="cuda", generator=g) * 0.3
-    wp, bp = pack.pack_conv(wq, dtype), pack.pack_bias(bq, nfan * C)
-    wsum = wp.float().sum(1).contiguous() if ln else None
-    q = hip.mlp_fan(x, wp, bp, wsum)
-    assert q.shape == (*shp, nfan * C)
-    a = F.layer_norm(x.float(), (C,)) if ln else x.float()
-    ref = F.linear(a, wq.reshape(nfan * C, C).float(), bq)
-    scale = max(1.0, float(ref.abs().max()))
-    assert float((q.float() - ref).abs().max()) < 4e-3 * scale
-    sep = hip.conv2d([x.reshape(1, 1, -1, C)], wp, bp, 1, 1, nfan * C, ln_wsum=wsum).reshape(q.shape)
-    assert float((q.float() - sep.float()).abs().max()) < 2 ** -7 * scale
-    q2 = hip.mlp_fan(x, wp, None, wsum)                     # no bias
-    assert float((q2.float() - (ref - bq)).abs().max()) < 4e-3 * scale
 
 
 # ---- direct form (s2m2_chain_desc.weight_frag: weights in MFMA-fragment order, straight into the operand registers) ------------------------
@@ -314,7 +270,7 @@ def test_chain_direct_form_rejects_unsupported(hip):
                                            (128, (1, 256, 304), 3, True), (128, (1, 7, 9), 1, False), (256, (1, 5, 3), 4, False)])
 def test_fan_only_direct_form(hip, C, shp, nfan, ln):
     """nstage = 0 with weight_frag: the fan-out layers alone (a block's first Q | K | V projection) in the direct form == the K5 launch with the
-    folded pre-LayerNorm within fp16 rounding and, where it exists, the weights-stationary form bit for bit (same operands, k16 order and epilogue)."""
+    folded pre-LayerNorm within fp16 rounding; the form exists for fp16 at C = 128 / 256 only."""
     dtype = torch.float16
     g = torch.Generator(device="cuda").manual_seed(C + nfan)
     wide = (torch.randn(*shp, C + 8, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
@@ -329,8 +285,9 @@ def test_fan_only_direct_form(hip, C, shp, nfan, ln):
         y = hip.mlp_fan(x, wf, bp, ws, frag=True)
         assert y.shape == ref.shape
         assert float((y.float() - ref.float()).abs().max()) < 1.5e-2
-    if hip.mlp_fan_supported(C, nfan, dtype):
-        assert torch.equal(y, hip.mlp_fan(x, wp, bp, ws))
+    assert hip.mlp_fan_supported(C, nfan, dtype) and not hip.mlp_fan_supported(384, nfan, dtype) and not hip.mlp_fan_supported(C, nfan, torch.float32)
+    with pytest.raises(ValueError, match="direct form"):
+        hip.mlp_fan(x, wp, bp, ws, frag=False)
     t = F.layer_norm(x.float(), (C,)) if ln else x.float()
     full = F.linear(t, wq.float().reshape(nfan * C, C), bp[:nfan * C])
     assert float((y.float() - full).abs().max()) < 2e-2

@@ -360,7 +360,7 @@ def test_sinkhorn_and_lookup_read_row_padded_volumes(hip, w, dtype, pos):
 
 
 def test_forward_with_folded_layernorm_matches_k1_with_its_own(monkeypatch):
-    """S2M2_FUSE_K1LN / S2M2_CV_ALIGNED (defaults on): DispInit's LayerNorm as the second output of the last K9 chain + the correlation
+    """S2M2_FUSE_K1LN (default on): DispInit's LayerNorm as the second output of the last K9 chain + the correlation
     alone on a row-padded volume, against K1 normalising the tokens itself on a dense volume.  fp32: the cost volumes agree to
     summation order, everything downstream to the parity tolerance; fp16: both are valid fp16 forwards."""
     from s2m2_amd.model import S2M2
@@ -371,7 +371,6 @@ def test_forward_with_folded_layernorm_matches_k1_with_its_own(monkeypatch):
     caps = []
     for fold in ("1", "0"):
         monkeypatch.setenv("S2M2_FUSE_K1LN", fold)
-        monkeypatch.setenv("S2M2_CV_ALIGNED", fold)
         m = S2M2(128, 1, 1, use_positivity=True, refine_iter=2)
         m.load_state_dict(sd, strict=True)
         m = m.cuda().eval()
@@ -379,7 +378,7 @@ def test_forward_with_folded_layernorm_matches_k1_with_its_own(monkeypatch):
         out = m(l, r, capture=cap)
         eng = m.engine(torch.float32)
         assert (eng._tokens_normed is not None) == (fold == "1")
-        assert (cap["cv"].stride(2) > cap["cv"].shape[3]) == (fold == "1")
+        assert cap["cv"].stride(2) > cap["cv"].shape[3]            # both forms write rows on 128-byte lines (s2m2_ln_corr_pitched)
         caps.append((cap, out, [t.clone() for t in m(l, r)], [t.clone() for t in m(l, r)]))          # eager, eager (first plain call), graph replay
     (ca, oa, ea, ga), (cb, ob, eb, gb) = caps
     assert float((ca["cv"] - cb["cv"]).abs().max()) < 2e-4 * float(cb["cv"].abs().max())
@@ -389,92 +388,3 @@ def test_forward_with_folded_layernorm_matches_k1_with_its_own(monkeypatch):
         assert float((oa[0] - ob[0]).abs().max()) < 2e-2
     for x, y in zip(ea, ga):                                  # graph replay == eager on the folded path
         assert torch.equal(x, y)
-
-
-# ---- K1, streaming form (s2m2_corr_tiled: fp16 tokens in MFMA-fragment order, written by the K9 launch that normalises them) -----------
-@pytest.mark.parametrize("C,h,w,B,cvdt", [(128, 3, 304, 1, torch.float16), (128, 2, 160, 2, torch.float16), (256, 2, 304, 1, torch.float16),
-                                          (64, 2, 40, 1, torch.float16), (128, 2, 8, 1, torch.float16), (128, 1, 608, 1, torch.float16),
-                                          (128, 2, 72, 1, torch.float32), (128, 1, 1200, 1, torch.float16)])
-def test_corr_tiled_equals_corr_bit_for_bit(hip, C, h, w, B, cvdt):
-    """Same fp16 operands, same k order of the MFMA chain (k16 step by k16 step), same fp32 accumulators: the streaming form must
-    reproduce the LDS form's volume BIT FOR BIT, incl. ragged last tiles, rows split over several blocks (w = 1200), banded stores and
-    row-padded outputs; and TiledTokens.from_rows / to_rows are inverse permutations."""
-    g = torch.Generator(device="cuda").manual_seed(C + w)
-    tok = torch.nn.functional.layer_norm(torch.randn(2 * B, h, w, C, device="cuda", generator=g) * 1.5 + 0.2, (C,)).half()
-    tiled = hip.TiledTokens.from_rows(tok)
-    assert torch.equal(tiled.to_rows(), tok)
-    ref = hip.corr(tok, cv_dtype=cvdt)
-    cv = hip.corr_tiled(tiled, cv_dtype=cvdt)
-    assert cv.shape == ref.shape and cv.stride(2) == ref.stride(2)
-    assert torch.equal(cv, ref)
-    dense = torch.empty((B, h, w, w), device="cuda", dtype=cvdt)
-    hip.corr_tiled(tiled, out=dense)
-    assert torch.equal(dense, ref)
-    banded = torch.full_like(dense, -777.0)
-    hip.corr_tiled(tiled, out=banded, band=11)
-    i = torch.arange(w, device="cuda")[:, None]
-    j = torch.arange(w, device="cuda")[None, :]
-    inside = (j <= i + 11).expand(B, h, w, w)
-    assert torch.equal(banded[inside], ref[inside])
-    assert not bool(((banded != -777.0) & (j >= (i | 31) + 11 + 64).expand(B, h, w, w)).any())
-    if cv.stride(2) > w:                                            # padding columns are never written
-        base = torch.full((B, h, w, cv.stride(2)), 5.0, device="cuda", dtype=cvdt)
-        hip.corr_tiled(tiled, out=base[..., :w])
-        assert bool((base[..., w:] == 5.0).all())
-
-
-@pytest.mark.parametrize("C,h,w,B,cvdt", [(128, 3, 304, 1, torch.float16), (128, 2, 160, 2, torch.float16), (64, 2, 40, 1, torch.float16),
-                                          (128, 2, 8, 1, torch.float16), (128, 1, 608, 2, torch.float16), (128, 2, 72, 1, torch.float32),
-                                          (128, 1, 1200, 1, torch.float16), (64, 3, 392, 1, torch.float16)])
-def test_corr_hybrid_equals_corr_bit_for_bit(hip, C, h, w, B, cvdt):
-    """s2m2_corr_hybrid (left tokens in fragment order straight into the MFMA operand registers, right tokens row-major through LDS):
-    same operands, same MFMA chains as s2m2_corr -> the same volume BIT FOR BIT, incl. ragged tiles, several blocks per row, bands."""
-    g = torch.Generator(device="cuda").manual_seed(C + w + 1)
-    tok = torch.nn.functional.layer_norm(torch.randn(2 * B, h, w, C, device="cuda", generator=g) * 1.5 + 0.2, (C,)).half()
-    hy = hip.HybridTokens.from_rows(tok)
-    assert torch.equal(hy.to_rows(), tok)
-    ref = hip.corr(tok, cv_dtype=cvdt)
-    cv = hip.corr_hybrid(hy, cv_dtype=cvdt)
-    assert cv.shape == ref.shape and cv.stride(2) == ref.stride(2)
-    assert torch.equal(cv, ref)
-    dense = torch.empty((B, h, w, w), device="cuda", dtype=cvdt)
-    hip.corr_hybrid(hy, out=dense)
-    assert torch.equal(dense, ref)
-    banded = torch.full_like(dense, -777.0)
-    refb = torch.full_like(dense, -777.0)
-    hip.corr_hybrid(hy, out=banded, band=11)
-    hip.corr(tok, out=refb, band=11)
-    assert torch.equal(banded, refb)
-    with pytest.raises(RuntimeError, match="C=256"):
-        t = hip.HybridTokens(1, 1, 32, 256, "cuda")
-        hip.corr_hybrid(t)
-
-
-@pytest.mark.parametrize("k1env", ["S2M2_K1_STREAM", "S2M2_K1_HYBRID"])
-def test_fp16_forward_is_bit_identical_with_either_form_of_k1(monkeypatch, k1env):
-    """S2M2_K1_STREAM=1 (opt-in, fp16): K9 writes the normalised tokens in fragment order and K1 runs its streaming form;
-    S2M2_K1_HYBRID=1: only the left tokens in fragment order, K1 keeps its LDS right row; off: row-major tokens and the LDS form.  Same operands, same MFMA chains -> the same cost volume and therefore the same forward, bit for bit
-    (eager and hipGraph replay)."""
-    from s2m2_amd import hip as H
-    from s2m2_amd.model import S2M2
-    from s2m2_amd.weights import seeded_state_dict, synthetic_pair
-    sd = seeded_state_dict(128, 1, 1, 0)
-    l, r = synthetic_pair(160, 608, 1, 24, 3)
-    l, r = l.cuda(), r.cuda()
-    outs = []
-    for stream in ("1", "0"):
-        monkeypatch.setenv(k1env, stream)
-        m = S2M2(128, 1, 1, use_positivity=True, refine_iter=2)
-        m.load_state_dict(sd, strict=True)
-        m = m.cuda().eval()
-        with torch.autocast("cuda", dtype=torch.float16):
-            cap = {}
-            m(l, r, capture=cap)
-            kind = H.TiledTokens if k1env == "S2M2_K1_STREAM" else H.HybridTokens
-            assert isinstance(m.engine(torch.float16)._tokens_normed, kind) == (stream == "1")
-            a = [t.clone() for t in m(l, r)]
-            b = [t.clone() for t in m(l, r)]                       # graph replay
-        assert all(torch.equal(x, y) for x, y in zip(a, b))
-        outs.append((cap["cv"].clone(), a))
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert all(torch.equal(x, y) for x, y in zip(outs[0][1], outs[1][1]))
