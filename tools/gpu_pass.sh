@@ -12,7 +12,7 @@ has() { [[ " $STEPS " == *" $1 "* ]]; }
 python -c "import s2m2_amd.hip as h; h.load(); print('lib ok, ABI', h.ABI_VERSION)" > $OUT/load.log 2>&1 || { cat $OUT/load.log; python -m s2m2_amd.build > $OUT/build.log 2>&1; }
 git -C $R rev-parse HEAD > $OUT/head.txt 2>/dev/null
 if has tests; then
-  timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --maxfail=${MAXFAIL:-25} -rfs -p no:cacheprovider ${PYTEST_ARGS:-} > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt
+  timeout ${TEST_TIMEOUT:-1500} python -m pytest ${TEST_PATHS:-tests} -m gpu -q --maxfail=${MAXFAIL:-25} -rfs -p no:cacheprovider ${PYTEST_ARGS:-} > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt
   tail -25 $OUT/pytest_gpu.txt
 fi
 if has bench; then
@@ -34,14 +34,16 @@ fi
 if has k1ab; then
   # fold-vs-own-LayerNorm and store mode, alternating same-box runs of the bench (no CPU baseline, no secondary)
   : > $OUT/ab_k1.txt
-  for rep in 1 2 3 4 5; do
-    for cfg in ${K1AB_CFGS:-"S2M2_FUSE_K1LN=1" "S2M2_FUSE_K1LN=0"}; do
-      env $cfg timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/ab_tmp.json 2>> $OUT/ab_k1.err
+  # K1AB_CFGS: configurations separated by ';', variables of one configuration by ','   (default: fold vs own LayerNorm)
+  IFS=';' read -ra CFGS <<< "${K1AB_CFGS:-S2M2_FUSE_K1LN=1;S2M2_FUSE_K1LN=0}"
+  for rep in $(seq 1 ${K1AB_REPS:-5}); do
+    for cfg in "${CFGS[@]}"; do
+      env ${cfg//,/ } timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/ab_tmp.json 2>> $OUT/ab_k1.err
       python - >> $OUT/ab_k1.txt <<PY
 import json
 try:
     d = json.load(open("$OUT/ab_tmp.json"))
-    print("rep $rep  $cfg  ms_per_step %.4f  pairs/s %.2f  K1 %.2f us  frac %.4f  (%s)" % (d["ms_per_step"], d["value"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["roofline"]["variant"][:60]))
+    print("rep $rep  %-44s ms_per_step %.4f  pairs/s %.2f  K1 %.2f us  frac %.4f" % ("$cfg", d["ms_per_step"], d["value"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"]))
 except Exception as e:
     print("rep $rep  $cfg  FAILED", e)
 PY
