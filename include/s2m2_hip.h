@@ -31,7 +31,8 @@ enum { S2M2_F32 = 0, S2M2_F16 = 1 };
  * compares the two before its first call (s2m2_amd/hip.py: load() refuses a library whose major.minor differs from the binding's).
  * History: 100 = rounds 1-2; 300 = round 3 changed signatures IN PLACE (cv_pitch inserted into s2m2_sinkhorn_regress / s2m2_cv_lookup,
  * s2m2_conv_desc / s2m2_chain_desc grew epi_cout0, ln_out*, fan_*, weight_frag, pool_h / pool_w) -- a caller built against 100 must be
- * rebuilt; 400 = round 4 (fused-level entry points added, no existing signature changed). */
+ * rebuilt; 400 = round 4 (s2m2_pw_direct, s2m2_ln_corr_pitched added; the round-3 experiment entry
+ * points s2m2_corr_tiled / s2m2_corr_hybrid / s2m2_debug_store_pattern and the ln_out_tile* fields of s2m2_chain_desc removed). */
 #define S2M2_ABI_VERSION 400
 int s2m2_version(void);
 const char* s2m2_last_error(void);
@@ -261,6 +262,36 @@ int s2m2_mlp_chain_frag_supported(int C, int dtype);
  * ONE pass over the rows): 1 where the library has that form (the direct form, weight_frag = 1: fp16, C = 128 / 256, nfan 1..4), else 0 */
 int s2m2_mlp_fan_supported(int C, int nfan, int dtype);
 int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
+
+/*
+ * K11 -- a 1x1 layer with any channel counts in the direct style (fp16; round 4): Conv2d(kernel 1) / Linear / ConvTranspose2d(2, stride 2) on
+ *   up to four channel-concatenated sources (reference: LocalRefiner's corr_feat / conf_occ_feat / disp_corr_ctx_cat 1x1 layers,
+ *   refinenet.py:87-106,138-146; the up_conv 1x1 layers of Unet / MRT on the coarse grid, unet.py:32-37, stacked_MRT.py:29-34; the
+ *   ConvTranspose heads of the upsampling masks, submodules.py:104-113,131-144), bias, NONE / GELU / RELU.
+ *     out[m, :] = act(W . cat_i(src_i[m, :]) + bias)      rows m of `rows` tokens; src_i: src_c[i] channels (multiples of 8), row stride
+ *   src_stride[i]; K = sum src_c, K rounded up to 16 in {32, 48, 64, 96, 128, 192, 256, 384}; Cout a multiple of 8 with 1, 2, 3, 4, 6 or 8
+ *   32-cout tiles: ask s2m2_pw_direct_supported(K, Cout, dtype).
+ *   weight_frag: the (Cout, K) weight zero-padded to (32 * tiles, 16 * steps) in MFMA-fragment order -- 16-byte slot (t * steps + s) * 64 + l
+ *   holds row 32 t + l % 32, columns 16 s + 8 (l / 32) .. + 7 (pack.pw_frag); bias fp32 (Cout) or NULL.
+ *   shuffle2 > 0: the ConvTranspose2d(2, s 2) store of s2m2_conv_desc (Cout = 4 * shuffle2, rows = N * Ho * Wo input pixels).
+ */
+typedef struct s2m2_pw_desc {
+    const void* src[4];
+    int src_c[4];
+    long long src_stride[4];
+    int nsrc;
+    long long rows;
+    const void* weight_frag;
+    const float* bias;
+    void* out;
+    long long out_stride;
+    int Cout;
+    int act;
+    int shuffle2, Ho, Wo;
+    int dtype;
+} s2m2_pw_desc;
+int s2m2_pw_direct_supported(int K, int Cout, int dtype);
+int s2m2_pw_direct(const s2m2_pw_desc* desc, void* stream);
 
 /*
  * K10 -- FeatureFusion with 1x1 kernels in ONE launch (reference feature_fusion.py:4-33 with kernel_size = 1: every fusion of

@@ -60,7 +60,13 @@ struct AttnCfg {
 #ifndef S2M2_ATTN_KSPLIT_KT
 #define S2M2_ATTN_KSPLIT_KT 8            // (experiment builds: 4 = the round-2 stages of 128 keys)
 #endif
-    static constexpr int KT = (KSPLIT_ && !PE_ && sizeof(T) == 2 && DP_ <= 64) ? S2M2_ATTN_KSPLIT_KT : (DP <= 64 ? 4 : (DP <= 128 ? 2 : 1));
+    // d = 96 / 128 in fp16 (the 1-D attention at 1/4 resolution: 304 keys, 512 (batch, head) pairs): stages of 128 keys -- three stages per
+    // row instead of five; a block's life is a chain of (load latency, two barriers, two sub-tiles of work) links (S2M2_ATTN_WIDE_KT=2: round 3)
+#ifndef S2M2_ATTN_WIDE_KT
+#define S2M2_ATTN_WIDE_KT 4
+#endif
+    static constexpr int KT = (KSPLIT_ && !PE_ && sizeof(T) == 2 && DP_ <= 64) ? S2M2_ATTN_KSPLIT_KT
+                              : (DP <= 64 ? 4 : (DP <= 128 ? (sizeof(T) == 2 ? S2M2_ATTN_WIDE_KT : 2) : 1));
     static constexpr int KVT = 32 * KT;                  // keys per stage
     static constexpr int KRS = DP + VEC;                 // K tile row stride (elements)
     static constexpr int VRS = KVT + 4;                  // Vt row stride (elements): keys of one stage + pad
@@ -252,15 +258,22 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 const int kv0 = t * KVT + sub * 32;
                 if (kv0 >= a.Nk) break;
                 // ---- S^T = K . Q^T
-                float16_t sacc;
+                // (two accumulators over even / odd k16 steps: back-to-back MFMAs on ONE accumulator wait for each other's 16 passes --
+                // at d = 128 that chain was 8 x 64 cycles per sub-tile with two waves per SIMD to hide it)
+                float16_t sacc, sacc1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; sacc1[r] = 0.f; }
                 const T* kp = Ks + (size_t)(sub * 32 + l31) * KRS + hi * 8;
 #pragma unroll
                 for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
                     Frag<T> kf;
                     load_frag(kf, kp + kk * 16);
-                    mma32(sacc, kf, qf[kk]);
+                    if (CFG::KSTEPS >= 4 && (kk & 1)) mma32(sacc1, kf, qf[kk]);
+                    else mma32(sacc, kf, qf[kk]);
+                }
+                if (CFG::KSTEPS >= 4) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r];
                 }
                 // ---- online softmax (lane: one query, keys crow(r, hi) of this sub-tile)
                 // scores in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 = 2^x): m_run, m_new are log2-domain maxima

@@ -305,7 +305,7 @@ struct ChainStage {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
                 }
-                if (m < p.rows) store_out16(outp + m * p.out_stride + pcx * VEC, v);
+                if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + pcx * VEC) = v;
                 if (p.nfan > 0) *reinterpret_cast<Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC) = v;   // the stored rows: A operand of the fan-out stages
                 if (ln2) {                                         // block-uniform
                     // statistics of the STORED (rounded) row, two passes in fp32 like K1 / nn.LayerNorm: biased variance, eps inside
@@ -325,7 +325,7 @@ struct ChainStage {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
                     if (m < p.rows) {
-                        store_out16(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC, o);
+                        *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
                     }
                 }
             }
@@ -435,7 +435,7 @@ __device__ __forceinline__ void chain_fan(const ChainArgs& p, ChainStream<CFG, T
             const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
             const long long m = m0 + row;
             const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Aoth + (size_t)row * ARS + pcx * VEC);
-            if (m < p.rows) store_out16(outp + m * p.fan_out_stride + pcx * VEC, v);
+            if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.fan_out_stride + pcx * VEC) = v;
         }
         __syncthreads();                                           // Aoth is staged again by the next fan-out stage
     }

@@ -82,24 +82,6 @@ template <int N, bool ASYNC = (S2M2_UNTRACKED_LOADS != 0)> __device__ __forceinl
 }
 __device__ __forceinline__ void settle(raw16_t& v) { asm volatile("" : "+v"(v)); }
 
-// 16-byte store of an OUTPUT piece (activation rows that the NEXT kernel reads, never this one).  Build switch -DS2M2_STORE_SC1=1: the store
-// carries sc1 (system-scope write-through): the line goes to the memory side (Infinity Cache / HBM) as it is written instead of staying dirty
-// in the writing XCD's L2 until the release at the end of the kernel flushes it -- with 4 MB of L2 per XCD up to 32 MB of a 40 MB activation
-// tensor are flushed while no wave runs (measured on K1, profiles/r04/k1_store_modes.txt: 19.2 -> 16.8 us).
-#ifndef S2M2_STORE_SC1
-#define S2M2_STORE_SC1 0
-#endif
-template <typename V> __device__ __forceinline__ void store_out16(void* dst, const V& v) {
-    static_assert(sizeof(V) == 16, "16-byte piece");
-    typedef float f4_t __attribute__((ext_vector_type(4)));
-    const f4_t r = __builtin_bit_cast(f4_t, v);
-#if S2M2_STORE_SC1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(r) : "memory");
-#else
-    *reinterpret_cast<f4_t*>(dst) = r;
-#endif
-}
-
 // 16-byte vector of T (8 halfs / 4 floats)
 template <typename T> struct Vec16;
 template <> struct alignas(16) Vec16<half_t> { half_t v[8]; };

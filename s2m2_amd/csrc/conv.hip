@@ -159,7 +159,7 @@ __device__ __forceinline__ void store_tile(const ConvArgs& p, const T* Cs, int t
             const long long n = t / p.Ho;
             opix = (n * (2 * p.Ho) + 2 * y + (sub >> 1)) * (2LL * p.Wo) + 2 * x + (sub & 1);
         }
-        if (!(S2M2_CONV_DBG & 32)) store_out16(outp + opix * p.out_stride + oc, v);
+        if (!(S2M2_CONV_DBG & 32)) *reinterpret_cast<Vec16<T>*>(outp + opix * p.out_stride + oc) = v;
     }
 }
 
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_igemm_kernel(ConvArgs p) {
             if (q >= AX::TOTAL || !pix(r, m) || co >= p.Cout) continue;
             Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Cs + (size_t)r * CFG::CRS + pcc * VEC);
             aux_combine(v, S2M2_EPI_ADD, mix[it], mix[it]);
-            store_out16(outp + m * p.out_stride + co, v);
+            *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + co) = v;
         }
         return;
     } else {

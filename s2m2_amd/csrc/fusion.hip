@@ -196,7 +196,7 @@ __device__ __forceinline__ void fusion_mix_store(const FusionArgs& p, const floa
         const int idx = tid + CFG::NT * it, row = idx / CFG::PPR, pcx = idx - row * CFG::PPR;
         const long long m = m0 + row;
         if (m < p.rows)
-            store_out16(outp + m * p.out_stride + pcx * VEC, *reinterpret_cast<const raw16_t*>(H + (size_t)row * HRS + pcx * VEC));
+            *reinterpret_cast<raw16_t*>(outp + m * p.out_stride + pcx * VEC) = *reinterpret_cast<const raw16_t*>(H + (size_t)row * HRS + pcx * VEC);
     }
 }
 

@@ -188,9 +188,9 @@ template <> __device__ __forceinline__ void store_quad<float>(float* dst, float 
 }
 
 // 16-byte store of a cost-volume piece.  The volume is written once and is larger than the L2 of the XCD that writes it; ``mode`` picks the
-// cache policy of the store (S2M2_K1_NT, measured in profiles/r04/k1_store_modes.txt): 0 default (write-back L2: the dirty lines are flushed
-// when the kernel ends), 1 nt (streaming hint), 2 sc1, 3 sc0 sc1 (write-through to memory: nothing is left to flush at the end of the
-// kernel), 4 sc0 sc1 nt
+// cache policy of the store (S2M2_K1_NT, measured in profiles/r04/k1_store_modes.txt): 0 plain (write-back L2: up to 32 MB of dirty lines are
+// flushed by the release at the end of the kernel, while no wave runs), 1 nt (streaming hint: slower), 2 sc1 = THE DEFAULT (write-through:
+// the lines drain to the memory side while the kernel is still storing), 3 sc0 sc1 (same speed), 4 sc0 sc1 nt (slower)
 template <typename TO>
 __device__ __forceinline__ void store_cv(TO* dst, const Vec16<TO>& v, int mode) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -467,7 +467,9 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;
     const int pitch = g_pitch > 0 ? g_pitch : w;
-    static const int k1_flags = getenv("S2M2_K1_NT") ? atoi(getenv("S2M2_K1_NT")) : 0;      // A/B switch: cache policy of the volume stores (store_cv)
+    // cache policy of the volume stores (store_cv): sc1 write-through by default -- measured (profiles/r04/k1_store_modes.txt, ab_k1_store.txt)
+    // 19.2 -> 16.8 us back to back and 19.7-20.7 -> 17.7 us inside the forward against the write-back default of rounds 1-3; S2M2_K1_NT=0..4 A/B
+    static const int k1_flags = getenv("S2M2_K1_NT") ? atoi(getenv("S2M2_K1_NT")) : 2;
     if (g_ev_start || g_ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
                               static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);

@@ -104,13 +104,8 @@ class Engine:
         # S2M2_CV_BAND=1 (opt-in, use_positivity models): banded cost volume, columns j <= i + 11.  Off by default: the reference's DispInit
         #   hands out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"
+        self.pw_on = os.environ.get("S2M2_PW_DIRECT", "1") != "0"      # (A/B of K11 while it is being measured)
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
-        # S2M2_OVERLAP=0: no second stream.  Default: branches of the forward that do not depend on each other -- the f2x layers of the two
-        #   upsampling-mask heads (submodules.py:106,131: they only need the backbone's 1/2-resolution features) next to the feature pyramid
-        #   and the transformer, and feat_fusion_layer + ctx_feat + tanh (s2m2.py:164-166) next to Sinkhorn + the global refiner -- are
-        #   enqueued on a side stream = parallel branches of the captured hipGraph: the pyramid levels at 1/16 and 1/32 resolution run grids
-        #   of 20-150 blocks on 256 CUs, the side branch fills the idle ones (profiles/r04/ab_overlap.txt)
-        self.side = torch.cuda.Stream(device=self.device) if (self.device.type == "cuda" and os.environ.get("S2M2_OVERLAP", "1") != "0") else None
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -193,6 +188,11 @@ class Engine:
             if "aux0" in kw:
                 return hip.mlp_chain(srcs[0], st, res=kw["aux0"], res_stage=0, frag=True)
             return hip.mlp_chain(srcs[0], st, frag=True)
+        # any other plain 1x1 layer (rectangular, up to four concatenated sources, ConvTranspose 2x2 s2 included): K11, the direct form
+        if (self.pw_on and kh == 1 and kw_ == 1 and not ln and not getattr(spec, "korder", 0) and len(srcs) <= 4 and set(kw) <= {"act", "shuffle2"}
+                and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
+                and wp.shape[1] == sum(t.shape[-1] for t in srcs) and self.pw_ok(wp.shape[1], cout)):
+            return hip.pw_direct(srcs, self.wpw(spec), bp, cout, act=kw.get("act", hip.ACT_NONE), shuffle2=kw.get("shuffle2", 0))
         if ln:
             kw["ln_wsum"] = self.wsum(spec)
         if getattr(spec, "korder", 0):
@@ -211,18 +211,6 @@ class Engine:
             b = torch.zeros(shape, device=self.device, dtype=dtype or self.dtype)
             self._bufs[k] = b
         return b
-
-    # ---- independent branches on a side stream ---------------------------------------------------------
-    def fork(self):
-        """``with engine.fork():`` -- the body is enqueued on the side stream, ordered after everything enqueued on the current stream so
-        far (so every tensor the body reads is complete, and every block the caching allocator hands the body was released by work that is
-        ordered before it).  No-op without a side stream.  Tensors produced in the body may be used on the current stream after join()."""
-        return _Fork(self.side)
-
-    def join(self) -> None:
-        """the current stream waits for the side stream"""
-        if self.side is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
 
     # ---- building blocks -----------------------------------------------------------------------------
     def down(self, p: str, x: Tensor) -> Tensor:
@@ -419,6 +407,21 @@ class Engine:
             ok = self._fusion_ok[("frag", c)] = hip.feature_fusion_frag_supported(c, self.dtype)
         return ok
 
+    def pw_ok(self, k: int, cout: int) -> bool:
+        """K11 (hip.pw_direct) exists for a (cout, k) 1x1 layer in this dtype (asked once per shape)"""
+        ok = self._chain_ok.get(("pw", k, cout))
+        if ok is None:
+            ok = self._chain_ok[("pw", k, cout)] = hip.pw_direct_supported(k, cout, self.dtype)
+        return ok
+
+    def wpw(self, spec: Spec) -> Tensor:
+        """a packed 1x1 weight in the fragment order of K11 (pack.pw_frag), permuted once per layer"""
+        wp = spec[0]
+        wf = self._wfrag.get(("pw", wp.data_ptr()))
+        if wf is None:
+            wf = self._wfrag[("pw", wp.data_ptr())] = pack.pw_frag(wp)
+        return wf
+
     def chain_ok(self, c: int) -> bool:
         ok = self._chain_ok.get(c)
         if ok is None:
@@ -536,30 +539,22 @@ class Engine:
         return (hn,) + tuple(hip.refine_update(dco, disp, conf, occ, self.use_positivity, want_small=want_small))
 
     # ---- upsampling masks ----------------------------------------------------------------------------
-    def mask4x_f2x(self, p: str, f2x: Tensor) -> Tensor:
-        """conv_y of UpsampleMask4x (submodules.py:106): depends on the backbone's 1/2-resolution features only"""
-        return self.cconv(self.std(p + ".conv_y"), [f2x])
-
-    def mask1x_f2x(self, p: str, f2x: Tensor) -> Tensor:
-        """conv_ctx of UpsampleMask1x (ConvTranspose 2x2 s2, submodules.py:131): depends on the 1/2-resolution features only"""
-        sc, cc = self.convT2(p + ".conv_ctx")
-        return self.cconv(sc, [f2x], shuffle2=cc)
-
-    def mask4x(self, p: str, hidden: Tensor, f2x: Tensor, pre: Optional[Tensor] = None) -> Tensor:
-        """UpsampleMask4x (submodules.py:96-115) -> logits (B,H,W,16), 9 used.  pre: conv_y(f2x) if features() already computed it."""
+    def mask4x(self, p: str, hidden: Tensor, f2x: Tensor) -> Tensor:
+        """UpsampleMask4x (submodules.py:96-115) -> logits (B,H,W,16), 9 used."""
         sx, cx = self.convT2(p + ".conv_x")
         a = self.cconv(sx, [hidden], shuffle2=cx)
-        b = pre if pre is not None else self.mask4x_f2x(p, f2x)
+        b = self.cconv(self.std(p + ".conv_y"), [f2x])
         y = self.cconv(self.std(p + ".conv_concat.0"), [a, b], act=hip.ACT_RELU)
         s2, c2 = self.convT2(p + ".conv_concat.2")
         return self.cconv(s2, [y], shuffle2=c2)
 
-    def mask1x(self, p: str, rgb8: Tensor, f2x: Tensor, pre: Optional[Tensor] = None) -> Tensor:
+    def mask1x(self, p: str, rgb8: Tensor, f2x: Tensor) -> Tensor:
         """UpsampleMask1x (submodules.py:118-145) -> logits (B,H,W,16), 9 used.  rgb8: (B,H,W,8) with the x4-upsampled disparity in
         channel 0 (written by K7) and the normalised image in channels 1..3."""
         ab = self.cconv(self.merged(p + "|dispRgb", [(p + ".conv_disp.0", 0, 1.0, True), (p + ".conv_rgb.0", 1, 1.0, True)], 8),
                         [rgb8], act=hip.ACT_RELU)
-        c = pre if pre is not None else self.mask1x_f2x(p, f2x)
+        sc, cc = self.convT2(p + ".conv_ctx")
+        c = self.cconv(sc, [f2x], shuffle2=cc)
         y = self.cconv(self.std(p + ".conv_concat.0"), [ab, c], act=hip.ACT_RELU)
         return self.cconv(self.std(p + ".conv_concat.2", transposed=True), [y])
 
@@ -585,10 +580,6 @@ class Engine:
         t = self.cconv(self.std(p + ".conv2.0"), [f2], act=hip.ACT_GELU)
         f2 = self.cconv(self.std(p + ".conv2.2"), [t], epi=hip.EPI_ADD, aux0=f2)
         f4 = self.cconv(self.std(p + ".conv2_down.0", frag=False), [f2], stride=2)
-        pre = None
-        if self.side is not None:
-            with self.fork():                                     # joined at the end of this function
-                pre = (self.mask4x_f2x("upsample_mask_4x_refine", f2[:B]), self.mask1x_f2x("upsample_mask_1x", f2[:B]))
         py = self.unet("feat_pyramid", f4)
         z = py
         # DispInit's LayerNorm (submodules.py:165,216) is folded into the launch that writes feature_tr_4x -- the last K9 chain of the
@@ -598,8 +589,7 @@ class Engine:
         for i in range(self.ntr):
             last = i == self.ntr - 1 and self.fuse_k1ln
             z = self.mrt(f"transformer.uformer_list.{i}", *z, ln_out=(self.ln_w, self.ln_b, 1e-5) if last else None)
-        self.join()
-        return z[0], py[0], f2[:B], x8[:B], pre                                 # tokens (2B,h,w,C), pyramid 1/4, left 1/2 features, image, mask-head branches
+        return z[0], py[0], f2[:B], x8[:B]                                      # tokens (2B,h,w,C), pyramid 1/4, left 1/2 features, image
 
     @torch.no_grad()
     def cost_volume(self, tr: Tensor, out: Optional[Tensor] = None, banded: bool = True, normed: Optional[Tensor] = None) -> Tensor:
@@ -625,15 +615,10 @@ class Engine:
         return hip.cv_alloc(twoB // 2, h, w, tr.dtype, tr.device)
 
     @torch.no_grad()
-    def finish(self, tr: Tensor, py0: Tensor, f2_left: Tensor, x8: Tensor, pre, cv: Tensor, cap: Optional[dict] = None):
-        """Sinkhorn + regression, global refiner, refinement loop, convex upsampling (s2m2.py:153-197).  pre: features()'s side-branch
-        outputs (conv_y / conv_ctx of the mask heads) or None."""
+    def finish(self, tr: Tensor, py0: Tensor, f2_left: Tensor, x8: Tensor, cv: Tensor, cap: Optional[dict] = None):
+        """Sinkhorn + regression, global refiner, refinement loop, convex upsampling (s2m2.py:153-197)."""
         B = cv.shape[0]
         tr0 = tr[:B]
-        with self.fork():                                         # s2m2.py:164-166 needs neither DispInit nor the global refiner
-            fus = self.fusion("feat_fusion_layer", tr0, py0[:B])
-            ctx = self.cconv(self.std("ctx_feat.2"), [self.cconv(self.std("ctx_feat.0"), [fus], act=hip.ACT_GELU)])
-            hidden = hip.tanh(ctx)
         # parity tests only ("teacher forcing", cap["inject"]): continue from the checker's tensors at a stage boundary, so that a
         # legitimate flip of a near-tie argmax (SURVEY.md 8c) is not what the stages downstream are judged on
         inj = (cap.get("inject") or {}) if cap is not None else {}
@@ -646,9 +631,13 @@ class Engine:
             if "disp0" in inj:
                 disp, conf, occ = (inj[k].to(cv.device, torch.float32).contiguous() for k in ("disp0", "conf0", "occ0"))
         disp = self.global_refiner("global_refiner", tr0, disp, conf)
-        self.join()
         if cap is not None:
             cap["disp_g"] = disp
+        # (measured and dropped, profiles/r04/ab_overlap.txt: this branch -- and the f2x layers of the two mask heads -- on a second stream as
+        # parallel branches of the captured hipGraph: 8.95 vs 8.83 ms per pair and K1 19.4 vs 17.7 us, the side kernels evict K1's tokens)
+        fus = self.fusion("feat_fusion_layer", tr0, py0[:B])
+        ctx = self.cconv(self.std("ctx_feat.2"), [self.cconv(self.std("ctx_feat.0"), [fus], act=hip.ACT_GELU)])
+        hidden = hip.tanh(ctx)
         if cap is not None:
             cap["ctx"] = ctx.permute(0, 3, 1, 2)
         small = None
@@ -659,9 +648,9 @@ class Engine:
             small = res[4] if more else None
             if cap is not None:
                 cap[f"disp_it{it}"], cap[f"conf_it{it}"], cap[f"occ_it{it}"] = disp, conf, occ
-        m4 = self.mask4x("upsample_mask_4x_refine", hidden, f2_left, pre[0] if pre else None)
+        m4 = self.mask4x("upsample_mask_4x_refine", hidden, f2_left)
         d_up, o_up, c_up = hip.convex_upsample([disp, occ, conf], m4, 4, scales=[4.0, 1.0, 1.0], chan_out=x8[..., 0])
-        m1 = self.mask1x("upsample_mask_1x", x8, f2_left, pre[1] if pre else None)
+        m1 = self.mask1x("upsample_mask_1x", x8, f2_left)
         if cap is not None:
             cap.update(hidden=hidden.permute(0, 3, 1, 2), mask4x=m4[..., :9].permute(0, 3, 1, 2), disp_up4=d_up,
                        mask1x=m1[..., :9].permute(0, 3, 1, 2))
@@ -670,13 +659,13 @@ class Engine:
 
     @torch.no_grad()
     def run(self, img0: Tensor, img1: Tensor, cap: Optional[dict] = None):
-        tr, py0, f2_left, x8, pre = self.features(img0, img1)
+        tr, py0, f2_left, x8 = self.features(img0, img1)
         normed = self._tokens_normed
         if cap is not None and "feature_tr_4x" in (cap.get("inject") or {}):           # parity tests only, see finish()
             tr = cap["inject"]["feature_tr_4x"].to(tr.device, tr.dtype).permute(0, 2, 3, 1).contiguous()
             normed = self._normed_like_the_forward(tr) if normed is not None else None
         cv = self.cost_volume(tr, banded=cap is None, normed=normed)   # captured runs hand out the full volume, like the reference
-        return self.finish(tr, py0, f2_left, x8, pre, cv, cap)
+        return self.finish(tr, py0, f2_left, x8, cv, cap)
 
     def _normed_like_the_forward(self, tr: Tensor):
         """Parity tests only (injected ``feature_tr_4x``).  In a free-running forward DispInit's LayerNorm is the second output of the K9
@@ -761,23 +750,3 @@ class GraphRunner:
             b = base.clone()                                       # one copy out of the graph's static output buffer
             return tuple(b[k] for k in range(len(self.out)))
         return tuple(o.clone() for o in self.out)
-
-
-class _Fork:
-    """``with engine.fork():`` -- run the body on the side stream (no-op without one)."""
-
-    def __init__(self, side):
-        self.side = side
-        self.ctx = None
-
-    def __enter__(self):
-        if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream(self.side.device))
-            self.ctx = torch.cuda.stream(self.side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
-        return False

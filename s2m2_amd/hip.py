@@ -45,6 +45,12 @@ class ChainDesc(ctypes.Structure):
                 ("nfan", _i), ("xcd_group_rows", _ll), ("weight_frag", _i), ("pool_h", _i), ("pool_w", _i)]
 
 
+class PwDesc(ctypes.Structure):
+    """mirror of s2m2_pw_desc (include/s2m2_hip.h)"""
+    _fields_ = [("src", _vp * 4), ("src_c", _i * 4), ("src_stride", _ll * 4), ("nsrc", _i), ("rows", _ll), ("weight_frag", _vp), ("bias", _vp),
+                ("out", _vp), ("out_stride", _ll), ("Cout", _i), ("act", _i), ("shuffle2", _i), ("Ho", _i), ("Wo", _i), ("dtype", _i)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
 ABI_VERSION = 400                     # include/s2m2_hip.h: S2M2_ABI_VERSION (checked in load())
 
@@ -60,6 +66,8 @@ SIGNATURES = {
     "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "s2m2_sinkhorn_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
     "s2m2_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "s2m2_pw_direct_supported": (_i, [_i, _i, _i]),
+    "s2m2_pw_direct": (_i, [ctypes.POINTER(PwDesc), _vp]),
     "s2m2_ln_corr_pitched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
@@ -473,6 +481,49 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
     _meter("mlp_chain", 2.0 * rows * C * C * (len(stages) + nfan))
     res_t = (out,) + ((normed,) if normed is not None else ()) + ((fan_out,) if fan_out is not None else ())
     return res_t[0] if len(res_t) == 1 else res_t
+
+
+def pw_direct_supported(K: int, Cout: int, dtype: torch.dtype) -> bool:
+    """K11 exists for this layer shape (K = concatenated input channels, multiple of 8)"""
+    return bool(load().s2m2_pw_direct_supported(K, Cout, _DT[dtype]))
+
+
+def pw_direct(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], Cout: int, act: int = ACT_NONE, shuffle2: int = 0) -> torch.Tensor:
+    """K11: a 1x1 layer on the channel concatenation of ``srcs`` ((N,H,W,Ci) / (..., Ci) tensors with contiguous channels and the same leading
+    shape), weight in the fragment order of pack.pw_frag, fp32 bias (Cout) or None -> (..., Cout).  shuffle2 = C' > 0: the ConvTranspose2d(2,
+    stride 2) store, Cout = 4 * C' -> (N, 2H, 2W, C')."""
+    x0 = srcs[0]
+    d = PwDesc()
+    d.nsrc = len(srcs)
+    K = 0
+    rows = None
+    for i, x in enumerate(srcs):
+        r, xs = _token_rows(x, "pw_direct")
+        if rows is not None and r != rows:
+            raise ValueError("pw_direct: sources must have the same number of rows")
+        rows = r
+        if x.dtype != x0.dtype or not x.is_cuda:
+            raise ValueError("pw_direct: sources must be device tensors of one dtype")
+        d.src[i], d.src_c[i], d.src_stride[i] = x.data_ptr(), x.shape[-1], xs
+        K += x.shape[-1]
+    if weight_frag.dtype != x0.dtype or not weight_frag.is_cuda or not weight_frag.is_contiguous() or weight_frag.dim() != 4 or \
+            tuple(weight_frag.shape[2:]) != (64, 8) or weight_frag.shape[0] != (Cout + 31) // 32 or weight_frag.shape[1] != (K + 15) // 16:
+        raise ValueError(f"pw_direct: weight must be pack.pw_frag of a ({Cout}, {K}) matrix, got {tuple(weight_frag.shape)} {weight_frag.dtype}")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() < Cout or not bias.is_cuda):
+        raise ValueError(f"pw_direct: bias must be fp32 ({Cout}) on the device")
+    if shuffle2:
+        if x0.dim() != 4 or Cout != 4 * shuffle2:
+            raise ValueError("pw_direct: shuffle2 needs (N,H,W,C) sources and Cout = 4 * shuffle2")
+        out = torch.empty((x0.shape[0], 2 * x0.shape[1], 2 * x0.shape[2], shuffle2), device=x0.device, dtype=x0.dtype)
+        d.shuffle2, d.Ho, d.Wo, d.out_stride = shuffle2, x0.shape[1], x0.shape[2], shuffle2
+    else:
+        out = torch.empty(tuple(x0.shape[:-1]) + (Cout,), device=x0.device, dtype=x0.dtype)
+        d.out_stride = Cout
+    d.rows, d.weight_frag, d.bias, d.out = rows, weight_frag.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr()
+    d.Cout, d.act, d.dtype = Cout, act, _DT[x0.dtype]
+    _check(load().s2m2_pw_direct(ctypes.byref(d), _stream()), "s2m2_pw_direct")
+    _meter("conv2d", 2.0 * rows * ((K + 15) // 16 * 16) * ((Cout + 31) // 32 * 32))
+    return out
 
 
 def feature_fusion_supported(C: int, dtype: torch.dtype) -> bool:

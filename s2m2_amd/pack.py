@@ -99,6 +99,16 @@ def chain_frag(wp: torch.Tensor) -> torch.Tensor:
     return t.contiguous().reshape(rows, C)
 
 
+def pw_frag(wp: torch.Tensor) -> torch.Tensor:
+    """packed 1x1 weight (Cout, K) (pack_conv / pack_convT_2x2s2: row = cout, column = concatenated input channel) -> the fragment order of
+    s2m2_pw_direct: zero-padded to (32 * tiles, 16 * steps), then [tile][step][lane][8] with lane l holding row 32 t + l % 32, columns
+    16 s + 8 (l // 32) + e."""
+    cout, k = wp.shape
+    full = wp.new_zeros(((cout + 31) // 32 * 32, (k + 15) // 16 * 16))
+    full[:cout, :k] = wp
+    return _frag_rows(full).contiguous()
+
+
 def _frag_rows(w: torch.Tensor) -> torch.Tensor:
     """(R, K) -> (R/32, K/16, 64, 8): per 32-row tile and k16 step the MFMA A-fragment (lane l: row 32t + l % 32, k 16*step + 8*(l // 32) + e)"""
     R, K = w.shape

@@ -96,6 +96,18 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     c.x, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.res_stage, c.weight_frag, c.nfan = 4096, 256, 0, hip.F16, 8, 256, -1, 1, 5
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"nfan" in lib.s2m2_last_error()
 
+    # round 4: K11 (rectangular direct 1x1): shapes, sources, activation
+    assert lib.s2m2_pw_direct_supported(384, 256, hip.F16) == 1 and lib.s2m2_pw_direct_supported(80, 128, hip.F16) == 0
+    assert lib.s2m2_pw_direct(None, None) != 0 and b"null descriptor" in lib.s2m2_last_error()
+    w = hip.PwDesc()
+    w.nsrc, w.rows, w.weight_frag, w.out, w.out_stride, w.Cout, w.dtype = 1, 8, 4096, 4096, 128, 128, hip.F16
+    w.src[0], w.src_c[0], w.src_stride[0] = 4096, 12, 128
+    assert lib.s2m2_pw_direct(ctypes.byref(w), None) != 0 and b"multiples of 8" in lib.s2m2_last_error()
+    w.src_c[0] = 128
+    w.act = hip.ACT_SIGMOID
+    assert lib.s2m2_pw_direct(ctypes.byref(w), None) != 0 and b"act=" in lib.s2m2_last_error()
+    w.act, w.shuffle2 = hip.ACT_NONE, 24
+    assert lib.s2m2_pw_direct(ctypes.byref(w), None) != 0 and b"shuffle2" in lib.s2m2_last_error()
     assert lib.s2m2_feature_fusion_supported(128, hip.F16) == 1 and lib.s2m2_feature_fusion_supported(384, hip.F16) == 0
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 64, 192, 4096, 4096, 4096, 4096, 4096, 0, 0, hip.F16, None) != 0
     assert b"not supported" in lib.s2m2_last_error()

@@ -51,6 +51,10 @@ PY
   done
   cat $OUT/ab_k1.txt
 fi
+if has micro; then
+  timeout 600 python tools/pwbench.py > $OUT/pwbench.txt 2>&1; cat $OUT/pwbench.txt
+  timeout 600 python tools/attnbench.py > $OUT/attnbench.txt 2>&1; cat $OUT/attnbench.txt
+fi
 if has parity; then
   timeout 1200 python tools/parity_report.py $OUT/parity_tables.txt c1 c1r3 c3r1 c2h noise_c1 noise_c3 > $OUT/parity_report.log 2>&1; tail -3 $OUT/parity_report.log
 fi
