@@ -60,13 +60,8 @@ struct AttnCfg {
 #ifndef S2M2_ATTN_KSPLIT_KT
 #define S2M2_ATTN_KSPLIT_KT 8            // (experiment builds: 4 = the round-2 stages of 128 keys)
 #endif
-    // d = 96 / 128 in fp16 (the 1-D attention at 1/4 resolution: 304 keys, 512 (batch, head) pairs): stages of 128 keys -- three stages per
-    // row instead of five; a block's life is a chain of (load latency, two barriers, two sub-tiles of work) links (S2M2_ATTN_WIDE_KT=2: round 3)
-#ifndef S2M2_ATTN_WIDE_KT
-#define S2M2_ATTN_WIDE_KT 4
-#endif
-    static constexpr int KT = (KSPLIT_ && !PE_ && sizeof(T) == 2 && DP_ <= 64) ? S2M2_ATTN_KSPLIT_KT
-                              : (DP <= 64 ? 4 : (DP <= 128 ? (sizeof(T) == 2 ? S2M2_ATTN_WIDE_KT : 2) : 1));
+    // (measured and dropped in round 4, profiles/r04/attnbench.txt: stages of 128 keys and two QK accumulators at d = 128: 88 us vs 84 - 87)
+    static constexpr int KT = (KSPLIT_ && !PE_ && sizeof(T) == 2 && DP_ <= 64) ? S2M2_ATTN_KSPLIT_KT : (DP <= 64 ? 4 : (DP <= 128 ? 2 : 1));
     static constexpr int KVT = 32 * KT;                  // keys per stage
     static constexpr int KRS = DP + VEC;                 // K tile row stride (elements)
     static constexpr int VRS = KVT + 4;                  // Vt row stride (elements): keys of one stage + pad
@@ -75,6 +70,14 @@ struct AttnCfg {
     static constexpr size_t V_BYTES = (size_t)VROWS * VRS * sizeof(T);
     static constexpr int KP = DP / VEC;                  // 16-byte pieces per K/V row
     static constexpr int MAXW = (DP * sizeof(T) >= 384) ? 4 : 8;   // waves per block: 512 registers per lane for the wide heads
+    // key-split blocks of the 2-D attention at 1/32 (fp16, d <= 32: 16 (batch, head) pairs x 38 query tiles = 608 four-wave blocks): with
+    // plain launch bounds the compiler spent 208 registers (two waves per SIMD: the chip holds 512 such blocks -- two rounds, the second 19 %
+    // full).  Asked for three waves per SIMD it needs 121 without a spill: four blocks per CU, one round (S2M2_ATTN_MINWAVES=1: round 3)
+#ifndef S2M2_ATTN_MINWAVES
+#define S2M2_ATTN_MINWAVES 3
+#endif
+    // (d <= 48 without the positional encoding: 91 - 168 registers, no spills; wider heads and the PE variant spill at this budget)
+    static constexpr int MIN_WAVES_PER_EU = (!PE_ && sizeof(T) == 2 && DP_ <= 48) ? S2M2_ATTN_MINWAVES : 1;
     // KSPLIT merge scratch (reuses the K/V staging area after the key loop): running max / sum + the four partial O tiles
     static constexpr size_t MERGE_BYTES = KSPLIT ? (size_t)(256 + 4 * 32 * (ND * 32 + 1)) * sizeof(float) : 0;
     // PE area (tables + marginal bins) sits behind BOTH, so that it survives the merge
@@ -109,7 +112,7 @@ template <> __device__ __forceinline__ void load_vfrag<float>(Frag<float>& f, co
 }
 
 template <typename CFG, typename T>
-__global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(CFG::MAXW * 64, CFG::MIN_WAVES_PER_EU) void attention_kernel(AttnArgs a) {
     constexpr int VEC = CFG::VEC, KRS = CFG::KRS, VRS = CFG::VRS, ND = CFG::ND, KP = CFG::KP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);                                   // [KVT][KRS]
@@ -258,22 +261,15 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 const int kv0 = t * KVT + sub * 32;
                 if (kv0 >= a.Nk) break;
                 // ---- S^T = K . Q^T
-                // (two accumulators over even / odd k16 steps: back-to-back MFMAs on ONE accumulator wait for each other's 16 passes --
-                // at d = 128 that chain was 8 x 64 cycles per sub-tile with two waves per SIMD to hide it)
-                float16_t sacc, sacc1;
+                float16_t sacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; sacc1[r] = 0.f; }
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
                 const T* kp = Ks + (size_t)(sub * 32 + l31) * KRS + hi * 8;
 #pragma unroll
                 for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
                     Frag<T> kf;
                     load_frag(kf, kp + kk * 16);
-                    if (CFG::KSTEPS >= 4 && (kk & 1)) mma32(sacc1, kf, qf[kk]);
-                    else mma32(sacc, kf, qf[kk]);
-                }
-                if (CFG::KSTEPS >= 4) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r];
+                    mma32(sacc, kf, qf[kk]);
                 }
                 // ---- online softmax (lane: one query, keys crow(r, hi) of this sub-tile)
                 // scores in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 = 2^x): m_run, m_new are log2-domain maxima

@@ -441,8 +441,13 @@ __device__ __forceinline__ void chain_fan(const ChainArgs& p, ChainStream<CFG, T
     }
 }
 
+// (second launch bound: S2M2_CHAIN_MINWAVES waves per SIMD asked of the register allocator for the direct form at C = 128 -- experiment
+// builds; 1 = the allocator's own choice, 182 + 32 registers = two waves per SIMD for the three-stage 64-row tile)
+#ifndef S2M2_CHAIN_MINWAVES
+#define S2M2_CHAIN_MINWAVES 1
+#endif
 template <typename CFG, typename T>
-__global__ __launch_bounds__(CFG::NT) void mlp_chain_kernel(ChainArgs p) {
+__global__ __launch_bounds__(CFG::NT, (CFG::DIRECT && CFG::C == 128) ? S2M2_CHAIN_MINWAVES : 1) void mlp_chain_kernel(ChainArgs p) {
     constexpr int VEC = CFG::VEC, ARS = CFG::ARS, D = CFG::D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* A0 = reinterpret_cast<T*>(smem);

@@ -104,7 +104,6 @@ class Engine:
         # S2M2_CV_BAND=1 (opt-in, use_positivity models): banded cost volume, columns j <= i + 11.  Off by default: the reference's DispInit
         #   hands out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"
-        self.pw_on = os.environ.get("S2M2_PW_DIRECT", "1") != "0"      # (A/B of K11 while it is being measured)
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
@@ -189,7 +188,8 @@ class Engine:
                 return hip.mlp_chain(srcs[0], st, res=kw["aux0"], res_stage=0, frag=True)
             return hip.mlp_chain(srcs[0], st, frag=True)
         # any other plain 1x1 layer (rectangular, up to four concatenated sources, ConvTranspose 2x2 s2 included): K11, the direct form
-        if (self.pw_on and kh == 1 and kw_ == 1 and not ln and not getattr(spec, "korder", 0) and len(srcs) <= 4 and set(kw) <= {"act", "shuffle2"}
+        # (profiles/r04/pwbench.txt: 1.3 - 2.4 x the K5 launch per layer; ab_pw_direct.txt: 8.87 vs 9.00 ms per pair)
+        if (kh == 1 and kw_ == 1 and not ln and not getattr(spec, "korder", 0) and len(srcs) <= 4 and set(kw) <= {"act", "shuffle2"}
                 and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
                 and wp.shape[1] == sum(t.shape[-1] for t in srcs) and self.pw_ok(wp.shape[1], cout)):
             return hip.pw_direct(srcs, self.wpw(spec), bp, cout, act=kw.get("act", hip.ACT_NONE), shuffle2=kw.get("shuffle2", 0))
