@@ -70,14 +70,8 @@ struct AttnCfg {
     static constexpr size_t V_BYTES = (size_t)VROWS * VRS * sizeof(T);
     static constexpr int KP = DP / VEC;                  // 16-byte pieces per K/V row
     static constexpr int MAXW = (DP * sizeof(T) >= 384) ? 4 : 8;   // waves per block: 512 registers per lane for the wide heads
-    // key-split blocks of the 2-D attention at 1/32 (fp16, d <= 32: 16 (batch, head) pairs x 38 query tiles = 608 four-wave blocks): with
-    // plain launch bounds the compiler spent 208 registers (two waves per SIMD: the chip holds 512 such blocks -- two rounds, the second 19 %
-    // full).  Asked for three waves per SIMD it needs 121 without a spill: four blocks per CU, one round (S2M2_ATTN_MINWAVES=1: round 3)
-#ifndef S2M2_ATTN_MINWAVES
-#define S2M2_ATTN_MINWAVES 3
-#endif
-    // (d <= 48 without the positional encoding: 91 - 168 registers, no spills; wider heads and the PE variant spill at this budget)
-    static constexpr int MIN_WAVES_PER_EU = (!PE_ && sizeof(T) == 2 && DP_ <= 48) ? S2M2_ATTN_MINWAVES : 1;
+    // (measured and dropped, profiles/r04/ab_minwaves.txt: a second launch bound of three waves per SIMD takes the key-split kernel from 208 to 121
+    // registers without a spill -- four blocks per CU instead of two -- and changes nothing: 20.4 us, 8.857 vs 8.858 ms per pair)
     // KSPLIT merge scratch (reuses the K/V staging area after the key loop): running max / sum + the four partial O tiles
     static constexpr size_t MERGE_BYTES = KSPLIT ? (size_t)(256 + 4 * 32 * (ND * 32 + 1)) * sizeof(float) : 0;
     // PE area (tables + marginal bins) sits behind BOTH, so that it survives the merge
@@ -112,7 +106,7 @@ template <> __device__ __forceinline__ void load_vfrag<float>(Frag<float>& f, co
 }
 
 template <typename CFG, typename T>
-__global__ __launch_bounds__(CFG::MAXW * 64, CFG::MIN_WAVES_PER_EU) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     constexpr int VEC = CFG::VEC, KRS = CFG::KRS, VRS = CFG::VRS, ND = CFG::ND, KP = CFG::KP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* Ks = reinterpret_cast<T*>(smem);                                   // [KVT][KRS]

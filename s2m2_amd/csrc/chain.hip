@@ -441,10 +441,11 @@ __device__ __forceinline__ void chain_fan(const ChainArgs& p, ChainStream<CFG, T
     }
 }
 
-// (second launch bound: S2M2_CHAIN_MINWAVES waves per SIMD asked of the register allocator for the direct form at C = 128 -- experiment
-// builds; 1 = the allocator's own choice, 182 + 32 registers = two waves per SIMD for the three-stage 64-row tile)
+// second launch bound: waves per SIMD asked of the register allocator for the direct form at C = 128.  With the plain bound it spent 182 + 32
+// registers on the three-stage 64-row tile (two waves per SIMD); asked for three it fits 168 (14 spilled in the three-stage form, none in the
+// others): measured -1.15 % per pair same-box (profiles/r04/ab_minwaves.txt: 8.756 vs 8.858 ms).  S2M2_CHAIN_MINWAVES=1: the round-3 build
 #ifndef S2M2_CHAIN_MINWAVES
-#define S2M2_CHAIN_MINWAVES 1
+#define S2M2_CHAIN_MINWAVES 3
 #endif
 template <typename CFG, typename T>
 __global__ __launch_bounds__(CFG::NT, (CFG::DIRECT && CFG::C == 128) ? S2M2_CHAIN_MINWAVES : 1) void mlp_chain_kernel(ChainArgs p) {

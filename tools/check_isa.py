@@ -16,8 +16,8 @@ when the library is (re)built;  python tools/check_isa.py [--keep-asm PATH]  run
 
 feature_fusion_direct_kernel is one straight-line block (fully unrolled k16 steps): there the checked region runs from the first MFMA to the
 last fragment request -- while the ring is being refilled every ring register is either in flight or about to feed an MFMA -- and, besides
-the two properties above, every ``s_waitcnt vmcnt(N)`` in the region must carry the same N >= 8 (ring depth - 1: the prefetch distance the
-kernel was written for is what the generated code has).
+the two properties above, every ``s_waitcnt vmcnt(N)`` in the region must carry N = ring depth - 1 (the D of FusionDirectCfg<C, BM, NW, D>: the
+prefetch distance the kernel was written for is what the generated code has).
 
 ln_corr_kernel<..., PRENORM = true> (the default K1 of the forward, and its hybrid left-fragment branch) requests all of its tokens with the
 same untracked loads and counted waits.  Checked over the whole kernel with the in-order memory model the compiler itself uses on gfx9
@@ -126,8 +126,10 @@ def check_straight_line(name: str, lines):
         for t in dsts:
             if regs_of(t) & flying:
                 problems.append(f"{name}: instruction overwrites a register whose fragment may be in flight: {l}")
-    if len(waits) != 1 or min(waits) < 8:
-        problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected one value >= 8: ring depth - 1)")
+    m = re.search(r"FusionDirectCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+    depth = int(m.group(4)) if m else 9
+    if waits != {depth - 1}:
+        problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected exactly {depth - 1}: ring depth - 1)")
     return problems, 1
 
 
