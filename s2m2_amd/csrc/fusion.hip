@@ -310,11 +310,8 @@ __device__ __forceinline__ void static_steps(F&& f) {
     }
 }
 
-// S2M2_FUSION_MINWAVES (build switch, C = 128): waves per SIMD asked of the register allocator.  1: the allocator's choice (132 + 96 / 156 + 48
-// registers: two waves per SIMD) with rings of 12 / 24 fragments; 3: <= 168 registers with rings of 8 / 12 fragments (three waves per SIMD)
-#ifndef S2M2_FUSION_MINWAVES
-#define S2M2_FUSION_MINWAVES 1
-#endif
+// (measured and dropped, profiles/r04/ab_minwaves.txt: three waves per SIMD asked of the allocator at C = 128 -- <= 168 registers with rings of
+// 8 / 12 fragments instead of 132 + 96 / 156 + 48 with rings of 12 / 24 -- 8.793 vs 8.782 ms per pair; with 32-row tiles everywhere 8.768)
 template <int C_, int BM_, int NW_, int D_>
 struct FusionDirectCfg {
     static constexpr int C = C_, BM = BM_, NW = NW_, NT = 64 * NW_, D = D_;
@@ -331,7 +328,7 @@ struct FusionDirectCfg {
 };
 
 template <typename CFG>
-__global__ __launch_bounds__(CFG::NT, CFG::C == 128 ? S2M2_FUSION_MINWAVES : 1) void feature_fusion_direct_kernel(FusionArgs p) {
+__global__ __launch_bounds__(CFG::NT) void feature_fusion_direct_kernel(FusionArgs p) {
     using T = half_t;
     constexpr int C = CFG::C, BM = CFG::BM, XRS = CFG::XRS, HRS = CFG::HRS, D = CFG::D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -469,8 +466,7 @@ extern "C" int s2m2_feature_fusion_frag(const void* z0, const void* z1, void* ou
     // 32-row tiles while one round of them fits the chip, else 64-row tiles (half the weight traffic per row); S2M2_FUSION_DIRECT_BM forces one
     static const int force_bm = getenv("S2M2_FUSION_DIRECT_BM") ? atoi(getenv("S2M2_FUSION_DIRECT_BM")) : 0;
     const bool tall = force_bm ? force_bm == 64 : rows > (C == 128 ? 24576 : 8192);
-    if (C == 128) return tall ? launch_fusion_direct<128, 64, 4, S2M2_FUSION_MINWAVES >= 3 ? 8 : 12>(a, st)
-                              : launch_fusion_direct<128, 32, 4, S2M2_FUSION_MINWAVES >= 3 ? 12 : 24>(a, st);
+    if (C == 128) return tall ? launch_fusion_direct<128, 64, 4, 12>(a, st) : launch_fusion_direct<128, 32, 4, 24>(a, st);
     return tall ? launch_fusion_direct<256, 64, 8, 16>(a, st) : launch_fusion_direct<256, 32, 8, 24>(a, st);
 }
 
