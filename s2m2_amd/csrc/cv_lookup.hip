@@ -7,22 +7,9 @@
 // so the effective coordinate is off by ~1 ulp and a vanishing weight can land on the neighbouring row;
 // that arithmetic is reproduced here with contraction disabled.
 #include "common.h"
+#include "cv_lookup.h"
 
 namespace s2m2 {
-
-#pragma clang fp contract(off)
-__device__ __forceinline__ float roundtrip(float pix, float size) {
-    const float g = 2.0f * pix / (size - 1.0f) - 1.0f;     // reference Python (submodules.py:12-13)
-    return (g + 1.0f) * ((size - 1.0f) / 2.0f);            // ATen CPU unnormalize, align_corners=True
-}
-
-template <typename TI, int LEVEL>
-__device__ __forceinline__ float fetch(const TI* __restrict__ row, int x, int ws) {
-    // value of the sampled image at column x of this row; zeros padding outside [0, ws-1]
-    if (x < 0 || x >= ws) return 0.f;
-    if (LEVEL == 0) return to_f32(row[x]);
-    return (to_f32(row[2 * x]) + to_f32(row[2 * x + 1])) * 0.5f;
-}
 
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ cv, const float* __restrict__ disp,
@@ -40,40 +27,8 @@ __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ c
     const int b = (int)(rowid / h);
     const int level = t >= T;
     const int k = level ? t - T : t;
-    const float d = disp[pix];
-    const float dx = (float)(k - radius);
     const TI* img = cv + (size_t)rowid * w * pitch;       // (w rows = left pixel i, `pitch` elements apart) x (w cols = right pixel j)
-
-    float x, wsf;
-    int ws;
-    if (level == 0) { x = ((float)i - d) + dx; ws = w; }
-    else            { x = ((float)i / 2.0f - d / 2.0f) + dx; ws = w / 2; }
-    wsf = (float)ws;
-    const float ix = roundtrip(x, wsf);
-    const float iy = roundtrip((float)i, (float)w);
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const float wx = ix - x0f, wy = iy - y0f;
-    const float ex = 1.0f - wx, ey = 1.0f - wy;
-    // far out-of-range coordinates (huge |d|): every tap is zero padding
-    float out = 0.f;
-    if (x0f >= -2.0f && x0f <= wsf + 1.0f) {
-        const int x0 = (int)x0f, y0 = (int)y0f;
-        const float w00 = ey * ex, w01 = ey * wx, w10 = wy * ex, w11 = wy * wx;
-        if (y0 >= 0 && y0 < w) {
-            const TI* r0 = img + (size_t)y0 * pitch;
-            const float a = level ? fetch<TI, 1>(r0, x0, ws) : fetch<TI, 0>(r0, x0, ws);
-            const float c = level ? fetch<TI, 1>(r0, x0 + 1, ws) : fetch<TI, 0>(r0, x0 + 1, ws);
-            out = out + a * w00;
-            out = out + c * w01;
-        }
-        if (y0 + 1 >= 0 && y0 + 1 < w && wy != 0.0f) {
-            const TI* r1 = img + (size_t)(y0 + 1) * pitch;
-            const float a = level ? fetch<TI, 1>(r1, x0, ws) : fetch<TI, 0>(r1, x0, ws);
-            const float c = level ? fetch<TI, 1>(r1, x0 + 1, ws) : fetch<TI, 0>(r1, x0 + 1, ws);
-            out = out + a * w10;
-            out = out + c * w11;
-        }
-    }
+    const float out = lookup_tap<TI>(img, i, disp[pix], level, k, radius, w, pitch);
     TO* dst = (level ? corr2 : corr1) + (size_t)b * batch_stride + (size_t)(pix - (long long)b * h * w) * pix_stride + (size_t)k * tap_stride;
     *dst = from_f32<TO>(out);
 }
