@@ -532,7 +532,7 @@ def corr_feat(cv: torch.Tensor, disp: torch.Tensor, wa_frag: torch.Tensor, ba: O
     """K3 + both corr_feat layers of a refinement iteration in one launch (s2m2_corr_feat; fp16): cv (B,h,w,w) fp16 (row-padded view or
     dense), disp (B,1,h,w) fp32 -> (B,h,w,128) fp16.  wa_frag / wb_frag: pack.pw_frag of the block-diagonal (192, 32) / (128, 192) weights;
     corr_out: optional (B,h,w,32) fp16 buffer that receives the lookups (taps of level 0 in channels 0..8, of level 1 in 16..24)."""
-    _dev(cv, disp, wa_frag, wb_frag)
+    _dev(disp, wa_frag, wb_frag)                                  # (cv may be the row-padded view of cv_alloc: checked by _cv_pitch)
     B, h, w, _ = cv.shape
     if cv.dtype != torch.float16 or disp.dtype != torch.float32 or not disp.is_contiguous() or disp.numel() != B * h * w:
         raise ValueError("corr_feat: fp16 cv (B,h,w,w) and contiguous fp32 disp (B,1,h,w)")
