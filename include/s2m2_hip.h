@@ -292,17 +292,6 @@ typedef struct s2m2_pw_desc {
 } s2m2_pw_desc;
 int s2m2_pw_direct_supported(int K, int Cout, int dtype);
 int s2m2_pw_direct(const s2m2_pw_desc* desc, void* stream);
-/*
- * [A10 + A11 head] K3 and the two corr_feat layers of one refinement iteration as ONE launch (fp16): the two-level radius-4 lookup of
- *   s2m2_cv_lookup (reference submodules.py:39-60) feeding `corr / 16 -> Conv1x1(9 -> 96) -> GELU -> Conv1x1(96 -> 64)` of both levels
- *   (refinenet.py:87-96,138-141) as block-diagonal layers 32 -> 192 -> 128 (the 1/16 folded into the first weight by the caller):
- *   cv (B, h, w, cv_pitch) fp16, disp (B, 1, h, w) fp32 in 1/4-resolution pixels; wa_frag / wb_frag: pack.pw_frag of the (192, 32) and
- *   (128, 192) weights (level-0 taps in input columns 0..8, level-1 taps in 16..24), ba / bb fp32 biases; out (B*h*w, out_stride) fp16,
- *   128 channels written; corr_out: optional (B*h*w, 32) fp16 buffer that receives the lookups themselves (what s2m2_cv_lookup would have
- *   written: parity captures), or NULL.  Bit-identical to s2m2_cv_lookup + two s2m2_pw_direct launches.
- */
-int s2m2_corr_feat(const void* cv, const float* disp, const void* wa_frag, const float* ba, const void* wb_frag, const float* bb,
-                   void* out, long long out_stride, void* corr_out, int B, int h, int w, int cv_pitch, int dtype, void* stream);
 
 /*
  * K10 -- FeatureFusion with 1x1 kernels in ONE launch (reference feature_fusion.py:4-33 with kernel_size = 1: every fusion of

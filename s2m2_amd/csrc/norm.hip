@@ -126,20 +126,29 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     const int n = blockIdx.y;
     const int P = C / VEC, cpg = C / G;
     const long long total = HW * P;
+    // a thread always visits the same piece column (the (256 / P) * P lowest threads of a block stride by a multiple of P): its group's
+    // mean / rstd (fp64 statistics -> two fp64 divisions) and its 2 * VEC affine coefficients are formed ONCE, not per 16-byte piece --
+    // per piece they cost more than the memory traffic of the pass (round 4: 117 -> see profiles/r04/layer_trace_eager.txt)
+    const int nact = (256 / P) * P;
+    if ((int)threadIdx.x >= nact) return;
+    const int pi = threadIdx.x % P;
+    const int c0 = pi * VEC;
+    const int g = c0 / cpg;
     const double cnt = (double)HW * cpg;
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long long)gridDim.x * 256) {
-        const int pi = (int)(q % P);
-        const int c0 = pi * VEC;
-        const int g = c0 / cpg;
-        const double m = stats[((long long)n * G + g) * 2] / cnt;
-        double var = stats[((long long)n * G + g) * 2 + 1] / cnt - m * m;
-        var = var > 0 ? var : 0;
-        const float mean = (float)m, rstd = rsqrtf((float)var + eps);
+    const double m = stats[((long long)n * G + g) * 2] / cnt;
+    double var = stats[((long long)n * G + g) * 2 + 1] / cnt - m * m;
+    var = var > 0 ? var : 0;
+    const float mean = (float)m, rstd = rsqrtf((float)var + eps);
+    float ga[VEC], be[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; }
+    const long long stride = (long long)gridDim.x * nact;
+    for (long long q = (long long)blockIdx.x * nact + threadIdx.x; q < total; q += stride) {
         const long long off = ((long long)n * HW * P + q) * VEC;
         const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x + off);
         Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>((to_f32(v.v[e]) - mean) * rstd * gamma[c0 + e] + beta[c0 + e]);
+        for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>((to_f32(v.v[e]) - mean) * rstd * ga[e] + be[e]);
         *reinterpret_cast<Vec16<T>*>(y + off) = o;
     }
 }

@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
-#include "cv_lookup.h"
 #include "epilogue.h"
 
 namespace s2m2 {
@@ -179,144 +178,12 @@ static int dispatch_pw_n(const PwArgs& a, hipStream_t st) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// K3 + corr_feat fused (fp16): the two-level cost-volume lookup of one refinement iteration, `corr / 16 -> 1x1 (9 -> 96) -> GELU ->
-// 1x1 (96 -> 64)` for both levels (reference refinenet.py:87-96,138-141 on top of submodules.py:39-60), as ONE launch per iteration instead
-// of K3 + two K11 launches: a block owns 64 pixels, computes their 2 x 9 taps into an LDS tile (the arithmetic of cv_lookup.h, rounded to
-// fp16 exactly where K3 stored them), runs the two block-diagonal layers (32 -> 192 with GELU, 192 -> 128; the 1/16 is folded into the first
-// weight by the engine) with the 192-wide hidden rows staying in LDS, and stores the 128 correlation features.  Bit-identical to the three
-// launches it replaces (tests/test_hip_pw.py).  Six waves: one per 32-cout tile of the first layer, four of them own the tiles of the second.
-// ---------------------------------------------------------------------------------------------------------------------------
-struct CorrFeatArgs {
-    const void* cv;                     // (B, h, w, pitch) fp16, volume rows `pitch` apart
-    const float* disp;                  // (B, 1, h, w) fp32
-    const void* wa;                     // pack.pw_frag of the (192, 32) first layer (taps of level 0 in columns 0..8, of level 1 in 16..24)
-    const float* ba;                    // (192)
-    const void* wb;                     // pack.pw_frag of the (128, 192) second layer
-    const float* bb;                    // (128)
-    const void* zero;
-    void* out;                          // (B*h*w, out_stride) fp16, 128 channels written
-    long long out_stride;
-    void* corr;                         // optional (B*h*w, 32) fp16: the lookups themselves (parity captures), or null
-    long long rows;                     // B * h * w
-    int h, w, pitch;
-};
-
-struct CorrFeatS1 { static constexpr int MT = 2, NTL = 1, WM = 64, WN = 32, CRS = 192 + 8; };    // hidden tile [64][192 + pad]
-struct CorrFeatS2 { static constexpr int MT = 2, NTL = 1, WM = 64, WN = 32, CRS = 128 + 8; };    // staging tile [64][128 + pad]
-
-__global__ __launch_bounds__(384) void corr_feat_kernel(CorrFeatArgs p) {
-    using T = half_t;
-    constexpr int ARS = 32 + 8, HRS = CorrFeatS1::CRS, CRS = CorrFeatS2::CRS, KS1 = 2, KS2 = 12;
-    __shared__ __attribute__((aligned(16))) T A[64 * ARS];          // lookups: 9 + 9 taps in 32 channels
-    __shared__ __attribute__((aligned(16))) T H[64 * HRS];          // hidden rows; the staging tile of the output afterwards
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0..5: cout tile of the first layer; 0..3 also of the second
-    const long long m0 = (long long)blockIdx.x * 64;
-
-    // weights first: two fragments of layer one, twelve of layer two (waves 4, 5 have no second tile: they re-read tile 3, unused)
-    raw16_t wa[KS1], wb[KS2];
-    const raw16_t* qa = static_cast<const raw16_t*>(p.wa) + (size_t)wn * KS1 * 64 + lane;
-    const raw16_t* qb = static_cast<const raw16_t*>(p.wb) + (size_t)(wn < 4 ? wn : 3) * KS2 * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) wa[s] = global_load16(qa + s * 64);
-#pragma unroll
-    for (int s = 0; s < KS2; ++s) wb[s] = global_load16(qb + s * 64);
-    CoutRegs<CorrFeatS1> ba;
-    ba.load(p.ba, p.zero, 192, 0, wn, lane);
-    CoutRegs<CorrFeatS2> bb;
-    bb.load(p.bb, p.zero, 128, 0, wn < 4 ? wn : 3, lane);
-
-    // ---- lookups: element (pixel r, channel c) of the tile; c = 16 * level + k for k < 9, zero elsewhere
-    for (int idx = tid; idx < 64 * 32; idx += 384) {
-        const int r = idx >> 5, c = idx & 31;
-        const long long m = m0 + r;
-        const int level = c >> 4, k = c & 15;
-        float v = 0.f;
-        if (k < 9 && m < p.rows) {
-            const int i = (int)(m % p.w);
-            const long long rowid = m / p.w;
-            const T* img = static_cast<const T*>(p.cv) + (size_t)rowid * p.w * p.pitch;
-            v = lookup_tap<T>(img, i, p.disp[m], level, k, 4, p.w, p.pitch);
-        }
-        A[r * ARS + c] = (T)v;
-    }
-    __syncthreads();
-    if (p.corr != nullptr) {                                        // (block-uniform) the lookups themselves, for parity captures
-        for (int idx = tid; idx < 64 * 4; idx += 384) {
-            const int r = idx >> 2, pc = idx & 3;
-            if (m0 + r < p.rows)
-                *reinterpret_cast<raw16_t*>(static_cast<T*>(p.corr) + (m0 + r) * 32 + pc * 8) = *reinterpret_cast<const raw16_t*>(A + r * ARS + pc * 8);
-        }
-    }
-
-    // ---- layer one: hidden[:, 32 wn .. + 32) = GELU(Wa . taps + ba)
-    float16_t acc[2][1];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) {
-        Frag<T> wf;
-        wf.v = __builtin_bit_cast(half8_t, wa[s]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            Frag<T> xf;
-            load_frag(xf, A + (size_t)(i * 32 + l31) * ARS + hi * 8 + s * 16);
-            mma32(acc[i][0], wf, xf);
-        }
-    }
-    stage_tile<CorrFeatS1, T, S2M2_ACT_GELU>(acc, H, ba, 1.0f, 0, wn, lane);
-    __syncthreads();
-
-    // ---- layer two: out[:, 32 wn .. + 32) = Wb . hidden + bb   (waves 0..3)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-    if (wn < 4) {
-#pragma unroll
-        for (int s = 0; s < KS2; ++s) {
-            Frag<T> wf;
-            wf.v = __builtin_bit_cast(half8_t, wb[s]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                Frag<T> xf;
-                load_frag(xf, H + (size_t)(i * 32 + l31) * HRS + hi * 8 + s * 16);
-                mma32(acc[i][0], wf, xf);
-            }
-        }
-    }
-    __syncthreads();                                                // every wave is done reading the hidden rows: H becomes the staging tile
-    if (wn < 4) stage_tile<CorrFeatS2, T, S2M2_ACT_NONE>(acc, H, bb, 1.0f, 0, wn, lane);
-    __syncthreads();
-    T* outp = static_cast<T*>(p.out);
-    for (int idx = tid; idx < 64 * 16; idx += 384) {
-        const int r = idx >> 4, pc = idx & 15;
-        if (m0 + r < p.rows) *reinterpret_cast<raw16_t*>(outp + (m0 + r) * p.out_stride + pc * 8) = *reinterpret_cast<const raw16_t*>(H + (size_t)r * CRS + pc * 8);
-    }
-}
+// (measured and dropped in round 4, profiles/r04/ab_corr_feat.txt: the cost-volume lookup of a refinement iteration fused with its two corr_feat
+// layers into one launch -- a block computing the 2 x 9 taps of its 64 pixels into the LDS tile itself, 32 -> 192 GELU -> 128 with the hidden
+// rows resident -- was bit-identical to K3 + two K11 launches and SLOWER, 8.817 vs 8.754 ms per pair: 384 threads walking ~5 dependent tap
+// fetches each are a longer latency chain than K3's one thread per tap over the whole image followed by two 12-14 us GEMM launches.)
 
 }  // namespace s2m2
-
-extern "C" int s2m2_corr_feat(const void* cv, const float* disp, const void* wa_frag, const float* ba, const void* wb_frag, const float* bb,
-                              void* out, long long out_stride, void* corr_out, int B, int h, int w, int cv_pitch, int dtype, void* stream) {
-    using namespace s2m2;
-    S2M2_REQUIRE(cv && disp && wa_frag && wb_frag && out, "corr_feat: null pointer");
-    S2M2_REQUIRE(dtype == S2M2_F16, "corr_feat: fp16 only (the fp32 mode runs K3 and the two layers as separate launches)");
-    S2M2_REQUIRE(B > 0 && h > 0 && w > 1 && w % 2 == 0, "corr_feat: bad shape B=%d h=%d w=%d (w even)", B, h, w);
-    if (cv_pitch == 0) cv_pitch = w;
-    S2M2_REQUIRE(cv_pitch >= w && out_stride >= 128 && out_stride % 8 == 0, "corr_feat: cv_pitch=%d must be at least w, out_stride=%lld a multiple of 8 and at least 128",
-                 cv_pitch, out_stride);
-    CorrFeatArgs a;
-    a.cv = cv; a.disp = disp; a.wa = wa_frag; a.ba = ba; a.wb = wb_frag; a.bb = bb; a.out = out; a.out_stride = out_stride; a.corr = corr_out;
-    a.rows = (long long)B * h * w; a.h = h; a.w = w; a.pitch = cv_pitch;
-    a.zero = zero_page();
-    S2M2_REQUIRE(a.zero, "corr_feat: cannot allocate the zero page");
-    hipLaunchKernelGGL(corr_feat_kernel, dim3((unsigned)((a.rows + 63) / 64)), dim3(384), 0, static_cast<hipStream_t>(stream), a);
-    return check_launch("corr_feat");
-}
 
 extern "C" int s2m2_pw_direct_supported(int K, int Cout, int dtype) {
     const int nwn = (Cout + 31) / 32;

@@ -516,13 +516,8 @@ class Engine:
         sa = self.merged(p + "|corrA", [(p + ".corr_feat1.0", 0, 1 / 16, False), (p + ".corr_feat2.0", 16, 1 / 16, False)], 32)
         sb = self.merged(p + "|corrB", [(p + ".corr_feat1.2", 0, 1.0, False), (p + ".corr_feat2.2", 96, 1.0, False)], 192)
         corr = self.zeros("lr_corr", (B, h, w, 32))
-        if (self.dtype == torch.float16 and cv.dtype == torch.float16 and tuple(sa[0].shape) == (192, 32) and tuple(sb[0].shape) == (128, 192)
-                and os.environ.get("S2M2_CORR_FUSED", "1") != "0"):
-            # fp16: K3 and the two layers as ONE launch (hip.corr_feat, bit-identical to the three launches); captured runs also get the lookups
-            f12 = hip.corr_feat(cv, disp.contiguous(), self.wpw(sa), sa[1], self.wpw(sb), sb[1], corr_out=corr if cap is not None else None)
-        else:
-            hip.cv_lookup_into(cv, disp.contiguous(), corr, 0, 16, 4)                                    # K3
-            f12 = self.cconv(sb, [self.cconv(sa, [corr], act=hip.ACT_GELU)])
+        hip.cv_lookup_into(cv, disp.contiguous(), corr, 0, 16, 4)                                        # K3
+        f12 = self.cconv(sb, [self.cconv(sa, [corr], act=hip.ACT_GELU)])                                 # K11 x 2
         if cap is not None:
             # clones: lr_corr is persistent scratch that the next iteration overwrites
             cap[f"corr1_it{it}"], cap[f"corr2_it{it}"] = (corr[..., 0:9].permute(0, 3, 1, 2).clone(),

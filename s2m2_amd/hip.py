@@ -68,7 +68,6 @@ SIGNATURES = {
     "s2m2_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_pw_direct_supported": (_i, [_i, _i, _i]),
     "s2m2_pw_direct": (_i, [ctypes.POINTER(PwDesc), _vp]),
-    "s2m2_corr_feat": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _i, _i, _i, _i, _i, _vp]),
     "s2m2_ln_corr_pitched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
@@ -524,28 +523,6 @@ def pw_direct(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], Cou
     d.Cout, d.act, d.dtype = Cout, act, _DT[x0.dtype]
     _check(load().s2m2_pw_direct(ctypes.byref(d), _stream()), "s2m2_pw_direct")
     _meter("conv2d", 2.0 * rows * ((K + 15) // 16 * 16) * ((Cout + 31) // 32 * 32))
-    return out
-
-
-def corr_feat(cv: torch.Tensor, disp: torch.Tensor, wa_frag: torch.Tensor, ba: Optional[torch.Tensor], wb_frag: torch.Tensor,
-              bb: Optional[torch.Tensor], corr_out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """K3 + both corr_feat layers of a refinement iteration in one launch (s2m2_corr_feat; fp16): cv (B,h,w,w) fp16 (row-padded view or
-    dense), disp (B,1,h,w) fp32 -> (B,h,w,128) fp16.  wa_frag / wb_frag: pack.pw_frag of the block-diagonal (192, 32) / (128, 192) weights;
-    corr_out: optional (B,h,w,32) fp16 buffer that receives the lookups (taps of level 0 in channels 0..8, of level 1 in 16..24)."""
-    _dev(disp, wa_frag, wb_frag)                                  # (cv may be the row-padded view of cv_alloc: checked by _cv_pitch)
-    B, h, w, _ = cv.shape
-    if cv.dtype != torch.float16 or disp.dtype != torch.float32 or not disp.is_contiguous() or disp.numel() != B * h * w:
-        raise ValueError("corr_feat: fp16 cv (B,h,w,w) and contiguous fp32 disp (B,1,h,w)")
-    if tuple(wa_frag.shape) != (6, 2, 64, 8) or tuple(wb_frag.shape) != (4, 12, 64, 8) or wa_frag.dtype != torch.float16 or wb_frag.dtype != torch.float16:
-        raise ValueError("corr_feat: weights must be pack.pw_frag of a (192, 32) and a (128, 192) fp16 matrix")
-    if corr_out is not None and (tuple(corr_out.shape) != (B, h, w, 32) or corr_out.dtype != torch.float16 or not corr_out.is_contiguous()):
-        raise ValueError("corr_feat: corr_out must be a contiguous (B,h,w,32) fp16 tensor")
-    pitch = _cv_pitch(cv, "corr_feat")
-    out = torch.empty((B, h, w, 128), device=cv.device, dtype=torch.float16)
-    _check(load().s2m2_corr_feat(cv.data_ptr(), disp.data_ptr(), wa_frag.data_ptr(), ba.data_ptr() if ba is not None else None, wb_frag.data_ptr(),
-                                 bb.data_ptr() if bb is not None else None, out.data_ptr(), 128, corr_out.data_ptr() if corr_out is not None else None,
-                                 B, h, w, pitch, F16, _stream()), "s2m2_corr_feat")
-    _meter("conv2d", 2.0 * B * h * w * (32 * 192 + 192 * 128))
     return out
 
 

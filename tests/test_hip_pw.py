@@ -100,55 +100,3 @@ def test_pw_direct_rejects_what_it_does_not_take(hip):
         hip.pw_direct([x], wf, None, 96)                            # fragment tensor of another Cout
     with pytest.raises(RuntimeError, match="act"):
         hip.pw_direct([x], wf, None, 128, act=hip.ACT_TANH)
-
-
-@pytest.mark.parametrize("B,h,w,padded", [(1, 5, 72, True), (2, 3, 160, False), (1, 2, 304, True), (1, 1, 8, False)])
-def test_corr_feat_fused_equals_lookup_plus_two_layers_bit_for_bit(hip, B, h, w, padded):
-    """s2m2_corr_feat (K3 + corr_feat*.0 + GELU + corr_feat*.2 of both levels in one launch) against the three launches it replaces --
-    s2m2_cv_lookup into the 32-channel tile, then two K11 launches: same tap arithmetic, same rounding of the taps to fp16, same MFMA
-    chains and epilogues -> the 128 features AND the lookups are identical bit for bit; disparities incl. negative and out-of-range ones,
-    row counts that are not a multiple of the 64-pixel block, dense and row-padded volumes."""
-    dtype = torch.float16
-    g = torch.Generator(device="cuda").manual_seed(B * 1000 + w)
-    cv = hip.cv_alloc(B, h, w, dtype, "cuda") if padded else torch.empty(B, h, w, w, device="cuda", dtype=dtype)
-    cv.copy_((torch.randn(B, h, w, w, device="cuda", generator=g) * 20 + 100).to(dtype))
-    disp = (torch.rand(B, 1, h, w, device="cuda", generator=g) * (w + 20) - 10).float()           # some negative, some beyond the row
-    wa = (torch.randn(192, 32, 1, 1, device="cuda", generator=g) / 16 / math.sqrt(9)).to(dtype)
-    wa[:, 9:16] = 0
-    wa[:, 25:] = 0
-    wb = (torch.randn(128, 192, 1, 1, device="cuda", generator=g) / math.sqrt(96)).to(dtype)
-    ba = torch.randn(192, device="cuda", generator=g) * 0.3
-    bb = torch.randn(128, device="cuda", generator=g) * 0.3
-    wpa, wpb = pack.pack_conv(wa, dtype), pack.pack_conv(wb, dtype)
-    fa, fb = pack.pw_frag(wpa), pack.pw_frag(wpb)
-    bpa, bpb = pack.pack_bias(ba, 192), pack.pack_bias(bb, 128)
-    corr = torch.zeros(B, h, w, 32, device="cuda", dtype=dtype)
-    hip.cv_lookup_into(cv, disp, corr, 0, 16, 4)
-    ref = hip.pw_direct([hip.pw_direct([corr], fa, bpa, 192, act=hip.ACT_GELU)], fb, bpb, 128)
-    got_corr = torch.full_like(corr, 7.0)
-    for _ in range(3):
-        out = hip.corr_feat(cv, disp, fa, bpa, fb, bpb, corr_out=got_corr)
-        assert out.shape == (B, h, w, 128) and torch.equal(out, ref)
-        assert torch.equal(got_corr, corr)
-    assert torch.equal(hip.corr_feat(cv, disp, fa, bpa, fb, bpb), ref)                             # without the optional output
-    assert float(ref.float().abs().max()) > 0.1 and bool(torch.isfinite(ref).all())
-
-
-def test_forward_is_bit_identical_with_and_without_capture():
-    """Captured forwards (every parity test) and plain forwards (what bench.py times) differ in the refinement loop only by the optional
-    lookup output of s2m2_corr_feat: the fp16 outputs must be identical bit for bit, eager and hipGraph replay."""
-    from s2m2_amd.model import S2M2
-    from s2m2_amd.weights import seeded_state_dict, synthetic_pair
-    sd = seeded_state_dict(128, 1, 1, 0)
-    l, r = synthetic_pair(160, 352, 1, 24, 3)
-    l, r = l.cuda(), r.cuda()
-    m = S2M2(128, 1, 1, use_positivity=True, refine_iter=2)
-    m.load_state_dict(sd, strict=True)
-    m = m.cuda().eval()
-    with torch.autocast("cuda", dtype=torch.float16):
-        cap = {}
-        a = [t.clone() for t in m(l, r, capture=cap)]
-        b = [t.clone() for t in m(l, r)]
-        c = [t.clone() for t in m(l, r)]                           # graph replay
-    assert "corr1_it1" in cap and float(cap["corr1_it1"].float().abs().max()) > 1.0
-    assert all(torch.equal(x, y) for x, y in zip(a, b)) and all(torch.equal(x, y) for x, y in zip(a, c))
