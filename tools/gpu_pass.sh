@@ -15,6 +15,9 @@ if has tests; then
   timeout ${TEST_TIMEOUT:-1500} python -m pytest ${TEST_PATHS:-tests} -m gpu -q --maxfail=${MAXFAIL:-25} -rfs -p no:cacheprovider ${PYTEST_ARGS:-} > $OUT/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.txt
   tail -25 $OUT/pytest_gpu.txt
 fi
+if has smoke; then
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt; tail -3 $OUT/smoke.txt
+fi
 if has bench; then
   timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_N1.json 2> $OUT/bench_N1.err; echo "bench rc=$?"
   python - <<PY
