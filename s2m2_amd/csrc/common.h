@@ -82,6 +82,15 @@ template <int N, bool ASYNC = (S2M2_UNTRACKED_LOADS != 0)> __device__ __forceinl
 }
 __device__ __forceinline__ void settle(raw16_t& v) { asm volatile("" : "+v"(v)); }
 
+// flat thread index -> (gid / d, gid % d) in 32-bit arithmetic: a 64-bit division costs ~80 VALU instructions on gfx950, a 32-bit one ~25, and the
+// one-thread-per-element kernels (K3, K7, K8) decode two or three of them per thread -- for the lookups that was more than the work itself.
+// Callers guarantee gid < 2^31 (the host entry points check the element count).
+__device__ __forceinline__ void divmod32(long long gid, int d, int& quot, int& rem) {
+    const unsigned g = (unsigned)gid, q = g / (unsigned)d;
+    quot = (int)q;
+    rem = (int)(g - q * (unsigned)d);
+}
+
 // 16-byte vector of T (8 halfs / 4 floats)
 template <typename T> struct Vec16;
 template <> struct alignas(16) Vec16<half_t> { half_t v[8]; };

@@ -16,15 +16,16 @@ __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ c
                                                         TO* __restrict__ corr1, TO* __restrict__ corr2, int B, int h, int w,
                                                         int radius, long long batch_stride, long long pix_stride,
                                                         long long tap_stride, int pitch) {
+    // grid: x = (pixel column, tap) of one image row, y = image row (b * h + y): 32-bit index arithmetic only (round 4: the flat 64-bit
+    // index of rounds 1-3 cost five 64-bit divisions per thread -- more than the lookup itself)
     const int T = 2 * radius + 1;
-    const long long total = (long long)B * h * w * 2 * T;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int t = (int)(gid % (2 * T));
-    const long long pix = gid / (2 * T);                  // (b*h + y)*w + i
-    const int i = (int)(pix % w);
-    const long long rowid = pix / w;                      // b*h + y
-    const int b = (int)(rowid / h);
+    const unsigned t2 = blockIdx.x * blockDim.x + threadIdx.x;       // i * 2T + tap
+    if (t2 >= (unsigned)(w * 2 * T)) return;
+    const int i = (int)(t2 / (unsigned)(2 * T));
+    const int t = (int)(t2 - (unsigned)i * (unsigned)(2 * T));
+    const int rowid = blockIdx.y;                         // b*h + y
+    const int b = rowid / h;
+    const long long pix = (long long)rowid * w + i;       // (b*h + y)*w + i
     const int level = t >= T;
     const int k = level ? t - T : t;
     const TI* img = cv + (size_t)rowid * w * pitch;       // (w rows = left pixel i, `pitch` elements apart) x (w cols = right pixel j)
@@ -36,9 +37,8 @@ __global__ __launch_bounds__(256) void cv_lookup_kernel(const TI* __restrict__ c
 template <typename TI, typename TO>
 static int launch_lookup(const void* cv, const float* disp, void* c1, void* c2, int B, int h, int w, int radius, long long bs,
                          long long ps, long long ts, int pitch, hipStream_t st) {
-    const long long total = (long long)B * h * w * 2 * (2 * radius + 1);
-    const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL((cv_lookup_kernel<TI, TO>), dim3(blocks), dim3(256), 0, st, static_cast<const TI*>(cv), disp,
+    const int per_row = w * 2 * (2 * radius + 1);
+    hipLaunchKernelGGL((cv_lookup_kernel<TI, TO>), dim3((per_row + 255) / 256, B * h), dim3(256), 0, st, static_cast<const TI*>(cv), disp,
                        static_cast<TO*>(c1), static_cast<TO*>(c2), B, h, w, radius, bs, ps, ts, pitch);
     return check_launch("cv_lookup");
 }
@@ -50,7 +50,7 @@ extern "C" int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, vo
                               int cv_pitch, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(cv && disp && corr1 && corr2, "cv_lookup: null pointer");
-    S2M2_REQUIRE(B > 0 && h > 0 && w > 1 && radius >= 0 && radius <= 16, "cv_lookup: bad arguments");
+    S2M2_REQUIRE(B > 0 && h > 0 && w > 1 && radius >= 0 && radius <= 16 && (long long)B * h <= 65535, "cv_lookup: bad arguments (B * h <= 65535 image rows per launch)");
     S2M2_REQUIRE(w % 2 == 0, "cv_lookup: w=%d must be even", w);
     if (cv_pitch == 0) cv_pitch = w;
     S2M2_REQUIRE(cv_pitch >= w, "cv_lookup: cv_pitch=%d must be at least w=%d", cv_pitch, w);

@@ -469,7 +469,10 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     const int pitch = g_pitch > 0 ? g_pitch : w;
     // cache policy of the volume stores (store_cv): sc1 write-through by default -- measured (profiles/r04/k1_store_modes.txt, ab_k1_store.txt)
     // 19.2 -> 16.8 us back to back and 19.7-20.7 -> 17.7 us inside the forward against the write-back default of rounds 1-3; S2M2_K1_NT=0..4 A/B
-    static const int k1_flags = getenv("S2M2_K1_NT") ? atoi(getenv("S2M2_K1_NT")) : 2;
+    // (only for volume rows on 128-byte lines: a write-through store of a PARTIAL line is a read-modify-write at the memory side -- dense 608-byte
+    // rows measured 25.0 us with sc1 against 21.8 with plain stores, profiles/r04/kbench.txt; the engine always allocates aligned rows)
+    static const int k1_env = getenv("S2M2_K1_NT") ? atoi(getenv("S2M2_K1_NT")) : -1;
+    const int k1_flags = k1_env >= 0 ? k1_env : ((pitch * (int)sizeof(TO)) % 128 == 0 ? 2 : 0);
     if (g_ev_start || g_ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
                               static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);

@@ -21,7 +21,9 @@ __global__ __launch_bounds__(256) void image_prep_kernel(const TI* __restrict__ 
                                                          int B, long long HW) {
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= 2LL * B * HW) return;
-    const long long n = gid / HW, pix = gid - n * HW;
+    int ni, pixi;
+    divmod32(gid, (int)HW, ni, pixi);
+    const long long n = ni, pix = pixi;
     const TI* src = (n < B ? img0 + n * 3 * HW : img1 + (n - B) * 3 * HW) + pix;
     alignas(16) T o[8];
     o[0] = from_f32<T>(0.f);
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void refine_update_kernel(const T* __restrict_
     const float c = 1.0f / (1.0f + expf(-(to_f32(r[8]) + logit_eps(conf[gid], 1e-2f))));
     float o = 1.0f / (1.0f + expf(-(to_f32(r[9]) + logit_eps(occ[gid], 1e-2f))));
     if (use_pos) d = fmaxf(d, 0.f);
-    const float x = (float)(gid % w);
+    const float x = (float)((unsigned)gid % (unsigned)w);
     o = (x - d >= 0.f) ? o : 0.f;
     disp_out[gid] = d; conf_out[gid] = c; occ_out[gid] = o;
     if (small_next) {
@@ -119,7 +121,7 @@ static inline dim3 grid1(long long n) { return dim3((unsigned)((n + 255) / 256))
 
 extern "C" int s2m2_image_prep(const void* img0, const void* img1, void* x8, int B, int H, int W, int img_dtype, int dtype, void* stream) {
     using namespace s2m2;
-    S2M2_REQUIRE(img0 && img1 && x8 && B > 0 && H > 0 && W > 0, "image_prep: bad arguments");
+    S2M2_REQUIRE(img0 && img1 && x8 && B > 0 && H > 0 && W > 0 && 2LL * B * H * W < (1LL << 31), "image_prep: bad arguments (at most 2^31 pixels per launch)");
     const long long HW = (long long)H * W, n = 2LL * B * HW;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // img_dtype: S2M2_F32 / S2M2_F16 / 2 = uint8

@@ -37,10 +37,9 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(UpArgs a) {
     const long long total = (long long)a.B * Ho * Wo;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
-    const int X = (int)(gid % Wo);
-    const long long t = gid / Wo;
-    const int Y = (int)(t % Ho);
-    const int b = (int)(t / Ho);
+    int X, Y, b, t;
+    divmod32(gid, Wo, t, X);
+    divmod32(t, Ho, b, Y);
     const T* lg = static_cast<const T*>(a.logits);
     float l[9];
     if (!a.logit_up2) {
@@ -102,11 +101,10 @@ __global__ __launch_bounds__(256) void resample2x_kernel(const T* __restrict__ x
     const long long total = (long long)N * Ho * Wo * P;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
-    const int pc = (int)(gid % P);
-    long long t = gid / P;
-    const int X = (int)(t % Wo); t /= Wo;
-    const int Y = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+    int pc, X, Y, n, t, t1;
+    divmod32(gid, P, t, pc);
+    divmod32(t, Wo, t1, X);
+    divmod32(t1, Ho, n, Y);
     const T* xb = x + (long long)n * H * W * xs + pc * VEC;
     Vec16<T> o;
     if (MODE == 0) {
@@ -142,6 +140,7 @@ extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, co
     S2M2_REQUIRE(x && out && logits && scale, "convex_upsample: null pointer");
     S2M2_REQUIRE(nmaps >= 1 && nmaps <= 3, "convex_upsample: nmaps=%d (1..3)", nmaps);
     S2M2_REQUIRE(B > 0 && hs > 0 && ws > 0 && factor >= 1, "convex_upsample: bad shape");
+    S2M2_REQUIRE((long long)B * hs * factor * ws * factor < (1LL << 31), "convex_upsample: more than 2^31 output pixels");
     S2M2_REQUIRE(logit_stride >= 16 && logit_stride % 8 == 0, "convex_upsample: logit rows must be padded to >= 16 channels (stride %d)", logit_stride);
     S2M2_REQUIRE(!logit_up2 || factor == 2, "convex_upsample: logit_up2 needs factor 2");
     UpArgs a;
@@ -169,6 +168,7 @@ extern "C" int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int 
     S2M2_REQUIRE(x && y, "resample2x: null pointer");
     S2M2_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && x_stride % 8 == 0 && y_stride % 8 == 0, "resample2x: bad shape");
     S2M2_REQUIRE(mode == 0 || mode == 1, "resample2x: mode %d (0 = average pool 2x2, 1 = bilinear x2)", mode);
+    S2M2_REQUIRE((long long)N * H * W * 4 * (C / 4) < (1LL << 31), "resample2x: more than 2^31 output pieces");
     S2M2_REQUIRE(mode == 1 || (H % 2 == 0 && W % 2 == 0), "resample2x: average pooling needs even H, W");
     const int vec = dtype == S2M2_F16 ? 8 : 4;
     const long long Ho = mode == 0 ? H / 2 : H * 2, Wo = mode == 0 ? W / 2 : W * 2;

@@ -32,7 +32,9 @@ except Exception as e:
 PY
 fi
 if has k1modes; then
-  timeout 600 python tools/k1_modes.py c3 > $OUT/k1_store_modes.txt 2>&1; cat $OUT/k1_store_modes.txt
+  : > $OUT/k1_store_modes.txt
+  for CASE in ${K1MODES_CASES:-c3}; do timeout 600 python tools/k1_modes.py $CASE >> $OUT/k1_store_modes.txt 2>&1; done
+  cat $OUT/k1_store_modes.txt
 fi
 if has k1ab; then
   # fold-vs-own-LayerNorm and store mode, alternating same-box runs of the bench (no CPU baseline, no secondary)
