@@ -31,7 +31,7 @@ enum { S2M2_F32 = 0, S2M2_F16 = 1 };
  * compares the two before its first call (s2m2_amd/hip.py: load() refuses a library whose major.minor differs from the binding's).
  * History: 100 = rounds 1-2; 300 = round 3 changed signatures IN PLACE (cv_pitch inserted into s2m2_sinkhorn_regress / s2m2_cv_lookup,
  * s2m2_conv_desc / s2m2_chain_desc grew epi_cout0, ln_out*, fan_*, weight_frag, pool_h / pool_w) -- a caller built against 100 must be
- * rebuilt; 400 = round 4 (s2m2_pw_direct, s2m2_ln_corr_pitched added; the round-3 experiment entry
+ * rebuilt; 400 = round 4 (s2m2_pw_direct, s2m2_conv_narrow, s2m2_ln_corr_pitched added; the round-3 experiment entry
  * points s2m2_corr_tiled / s2m2_corr_hybrid / s2m2_debug_store_pattern and the ln_out_tile* fields of s2m2_chain_desc removed). */
 #define S2M2_ABI_VERSION 400
 int s2m2_version(void);
@@ -292,6 +292,32 @@ typedef struct s2m2_pw_desc {
 } s2m2_pw_desc;
 int s2m2_pw_direct_supported(int K, int Cout, int dtype);
 int s2m2_pw_direct(const s2m2_pw_desc* desc, void* stream);
+
+/*
+ * K12 -- spatial convolutions on NARROW inputs in the direct style (fp16; round 4): Conv2d / stride-1 ConvTranspose2d (as a convolution with
+ *   the flipped kernel) whose input has exactly 8 or 16 channels -- one or two 16-byte pieces per pixel (reference: UpsampleMask1x
+ *   conv_disp.0 | conv_rgb.0, submodules.py:124-129,139-141; LocalRefiner disp_feat.0 | conf_occ_feat.0, refinenet.py:93-101,141-142;
+ *   CNNEncoder conv1_down.0, submodules.py:69-71).  Shapes: 3x3 stride 1 on 8 channels (any Cout % 8 == 0), 5x5 stride 2 on 16 channels
+ *   (an even number of 32-cout tiles): ask s2m2_conv_narrow_supported.  Padding K / 2, Ho = ceil(H / stride) as s2m2_conv2d.
+ *     out[n, y, x, :] = act(sum_taps W[:, tap, :] . x[n, y*s - K/2 + ky, x*s - K/2 + kx, :] + bias)        act: NONE / GELU / RELU
+ *   x: (N, H, W, Cin) with pixel stride x_stride (elements, multiple of 8); out: (N, Ho, Wo, Cout), pixel stride out_stride.
+ *   weight_frag: the (Cout, KH*KW*Cin) matrix of s2m2_conv2d's K order 0 (K = (tap, channel)) zero-padded to (32 * tiles, 16 * steps) in
+ *   MFMA-fragment order, as for K11 (pack.pw_frag); bias fp32 (Cout) or NULL.
+ */
+typedef struct s2m2_narrow_desc {
+    const void* x;
+    long long x_stride;
+    int N, H, W, Cin;
+    const void* weight_frag;
+    const float* bias;
+    void* out;
+    long long out_stride;
+    int Cout, KH, KW, stride;
+    int act;
+    int dtype;
+} s2m2_narrow_desc;
+int s2m2_conv_narrow_supported(int KH, int KW, int stride, int Cin, int Cout, int dtype);
+int s2m2_conv_narrow(const s2m2_narrow_desc* desc, void* stream);
 
 /*
  * K10 -- FeatureFusion with 1x1 kernels in ONE launch (reference feature_fusion.py:4-33 with kernel_size = 1: every fusion of

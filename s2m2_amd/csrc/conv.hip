@@ -1536,6 +1536,8 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
         const long long blocks4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.Cout / 128);
         // layers with an epilogue operand: always 64-pixel blocks (4 operand pieces per thread instead of 8, 160 registers: three blocks per
         // CU -- measured -190 us per pair against the v3 tiles, where the 128-pixel variant was +90 us)
+        // (32-pixel blocks, PH = 1, for the 1/8 and 1/16 levels -- twice the blocks again, 8 MFMAs per tap and wave -- measured round 4:
+        // 8.18 / 8.18 / 8.21 ms per pair at thresholds 0 / 320 / 640 blocks, same box, 3 alternating runs: no gain, not kept)
         const int ph = tile == 2 || tile == 4 ? tile : (force_ph == 2 || force_ph == 4) ? force_ph
                        : (a.epi != S2M2_EPI_NONE || blocks4 <= 256) ? 2 : 4;
         // 4x40 patches (160 pixels, 5 MFMA tiles) instead of 4x32 where that saves a partial round of blocks: cost = rounds of the 512

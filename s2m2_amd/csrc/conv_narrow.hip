@@ -1,0 +1,274 @@
+// K12 -- spatial convolutions on NARROW inputs (8 or 16 channels: one or two 16-byte pieces per pixel) in the direct style (fp16).
+//
+// Replaces the K5 v1 launches (conv.hip: dense-K im2col tiles, both operands staged through LDS behind a block barrier per K tile) of
+//   UpsampleMask1x   conv_disp.0 | conv_rgb.0 merged: ConvTranspose2d(k 3, s 1) on (disp, rgb) -> 32, ReLU, full resolution   submodules.py:124-129,139-141
+//   LocalRefiner     disp_feat.0 | conf_occ_feat.0 merged: Conv2d(k 3) on (disp, conf, occ) -> 96 + 64, GELU, 1/4 resolution   refinenet.py:93-101,141-142
+//   CNNEncoder       conv1_down.0: Conv2d(16 -> 64, k 5, s 2), GELU, full -> half resolution                                 submodules.py:69-71
+// These layers are memory-bound (8 - 16 input channels against 32 - 160 output channels: 5 / 25 MFMA k16 steps per 32 pixels), the v1 tile
+// spent its time re-gathering the im2col operand and in per-K-tile barriers.
+//
+// One block = 4 waves = an output patch of (4 MT) rows x 32 columns.  The input patch + halo is loaded ONCE into LDS, pixel-major, 16 / 32
+// bytes per pixel; wave v owns output rows v MT .. v MT + MT - 1 of the patch (MT 32-pixel MFMA tiles) and ALL output channels.  With 8
+// input channels a k16 step is two taps: lane (l % 32, l / 32) reads the 16-byte pixel of tap 2s + l / 32 of ITS output pixel straight out of
+// the tile (tap 9 of a 3x3 kernel: a zero slot; the packed weight is zero there as well); with 16 channels a step is one tap, the lane halves
+// take the channel halves.  The weight fragments (pack.pw_frag of the K5 K-order-0 matrix: K = (tap, channel), zero-padded to k16 steps and
+// 32-cout tiles) go from global memory straight into MFMA operand registers -- they are a few KB, L2-resident, shared by every block.
+// Epilogue per wave, no block barrier: bias + activation in registers -> a wave-private staging tile [pixel][cout] -> 16-byte NHWC stores.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "epilogue.h"
+
+namespace s2m2 {
+
+struct NarrowArgs {
+    const void* x;
+    long long xstride;                  // pixel stride of x (elements)
+    int N, H, W, Ho, Wo;
+    const void* w;                      // fragment order: [cout tile][k16 step][lane] x 16 bytes
+    const float* bias;
+    const void* zero;
+    void* out;
+    long long out_stride;
+    int Cout, act;
+};
+
+template <int KH_, int KW_, int S_, int CIN_, int MT_, int NTL_, int NWN_ = 1>
+struct NarrowCfg {
+    static constexpr int KH = KH_, KW = KW_, S = S_, CIN = CIN_, MT = MT_, NTL = NTL_;
+    static constexpr int NW = 4, NT = 64 * NW;
+    // NWN waves share a set of MT output rows and split the couts of a group (NWN * NTL tiles) between them: a wave's weight stream is then
+    // 1 / NWN of the layer's and feeds NWN times the pixel tiles -- the 5x5 layer (25 KB of fragments per cout tile) is bound by the
+    // L2 -> CU weight traffic, not by its LDS reads
+    static constexpr int NWN = NWN_, NWM = NW / NWN_;
+    static constexpr int PW = 32, PH = NWM * MT;                          // output patch
+    static constexpr int HW = (PW - 1) * S + KW, HH = (PH - 1) * S + KH;  // input patch + halo
+    // stride 2: the columns of a tile row are stored even ones first, then the odd ones -- the 32 lanes of a fragment read (columns 2 l + kx)
+    // then touch CONSECUTIVE slots instead of every second one (which is an 8-way LDS bank conflict on 16-byte reads)
+    static constexpr int HWE = (HW + 1) / 2;                              // even columns of a tile row
+    static __device__ __forceinline__ int col_slot(int hx) { return S == 2 ? (hx & 1) * HWE + (hx >> 1) : hx; }
+    static constexpr int PPX = CIN / 8;                                   // 16-byte pieces per input pixel
+    static constexpr int NPIECE = HW * HH * PPX;
+    static constexpr int A_IT = (NPIECE + NT - 1) / NT;
+    static constexpr int NTAP = KH * KW, K = NTAP * CIN, NS = (K + 15) / 16;
+    static constexpr bool RESIDENT = NS * MT <= 12;                       // the pixel fragments of a wave stay in registers across cout groups
+    static constexpr int SM = MT < 2 ? MT : 2;                            // pixel tiles a wave stages at a time
+    struct Stage {                                                        // (names used by stage_tile / CoutRegs)
+        static constexpr int MT = SM, NTL = NTL_, WM = 32 * SM, WN = 32 * NTL_, CRS = WN + 8;
+    };
+    static constexpr int WN = Stage::WN, CRS = Stage::CRS;                // couts of a wave per group; staging row stride
+    static constexpr int CPR = WN / 8, C_IT = Stage::WM * CPR / 64;       // 16-byte pieces per staged row / per lane and staging pass
+    static constexpr size_t A_BYTES = (size_t)(NPIECE + 1) * 16;          // + one zero slot
+    static constexpr size_t STG_BYTES = (size_t)NW * Stage::WM * CRS * sizeof(half_t);
+    static constexpr size_t LDS_BYTES = A_BYTES + STG_BYTES;
+    static_assert((CIN == 8 || CIN == 16) && (Stage::WM * CPR) % 64 == 0 && MT % SM == 0 && NW % NWN == 0 && LDS_BYTES <= 80 * 1024,
+                  "unsupported narrow-input tile");
+};
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::NT) void conv_narrow_kernel(NarrowArgs p, int tiles_x, int tiles_y, int gpb) {
+    using T = half_t;
+    constexpr int KW = CFG::KW, S = CFG::S, MT = CFG::MT, NTL = CFG::NTL, NS = CFG::NS, HW = CFG::HW, CRS = CFG::CRS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    raw16_t* A = reinterpret_cast<raw16_t*>(smem);                  // [HH][HW][PPX] pieces, then one zero slot
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pm = wv / CFG::NWN, cn = wv - pm * CFG::NWN;          // row set / cout share of this wave
+    T* stg = reinterpret_cast<T*>(smem + CFG::A_BYTES) + (size_t)wv * CFG::Stage::WM * CRS;     // wave-private staging tile [32 SM][CRS]
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int n = bx / tiles_y;
+    const int oy0 = ty * CFG::PH, ox0 = tx * CFG::PW;
+    const int iy0 = oy0 * S - CFG::KH / 2, ix0 = ox0 * S - KW / 2;
+
+    // ---- 1. input patch + halo -> LDS (zero outside the image: the convolution's padding)
+    const T* xin = static_cast<const T*>(p.x);
+    raw16_t ra[CFG::A_IT];
+#pragma unroll
+    for (int it = 0; it < CFG::A_IT; ++it) {
+        const int idx = tid + CFG::NT * it, pix = idx / CFG::PPX, part = idx - pix * CFG::PPX;
+        const int hy = pix / HW, hx = pix - hy * HW;
+        const int yy = iy0 + hy, xx = ix0 + hx;
+        const bool ok = idx < CFG::NPIECE && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        ra[it] = global_load16(ok ? xin + (((long long)n * p.H + yy) * p.W + xx) * p.xstride + part * 8 : static_cast<const T*>(p.zero));
+    }
+#pragma unroll
+    for (int it = 0; it < CFG::A_IT; ++it) {
+        const int idx = tid + CFG::NT * it;
+        if (idx < CFG::NPIECE) {
+            const int pix = idx / CFG::PPX, part = idx - pix * CFG::PPX;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            A[(hy * HW + CFG::col_slot(hx)) * CFG::PPX + part] = ra[it];
+        }
+    }
+    if (tid == 0) A[CFG::NPIECE] = (raw16_t){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // ---- 2. pixel fragment of MFMA tile i (output row pm * MT + i of the patch), k16 step s: one 16-byte LDS read per lane
+    auto xfrag = [&](int i, int s) __attribute__((always_inline)) {
+        const int r = (pm * MT + i) * S;
+        int piece;
+        if constexpr (CFG::CIN == 8) {                              // two taps per step, the lane half picks the tap
+            const int t0 = 2 * s, t1 = 2 * s + 1;
+            const int o0 = ((r + t0 / KW) * HW + CFG::col_slot(l31 * S + t0 % KW));
+            const int o1 = t1 < CFG::NTAP ? ((r + t1 / KW) * HW + CFG::col_slot(l31 * S + t1 % KW)) : CFG::NPIECE;
+            piece = hi ? o1 : o0;
+        } else {                                                    // one tap per step, the lane half picks the channel half
+            piece = ((r + s / KW) * HW + CFG::col_slot(l31 * S + s % KW)) * 2 + hi;
+        }
+        Frag<T> f;
+        f.v = __builtin_bit_cast(half8_t, A[piece]);
+        return f;
+    };
+    Frag<T> xres[CFG::RESIDENT ? MT : 1][CFG::RESIDENT ? NS : 1];
+    if constexpr (CFG::RESIDENT) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) xres[i][s] = xfrag(i, s);
+    }
+
+    // ---- 3. groups of NWN * NTL 32-cout tiles: K loop (NS steps x MT tiles x NTL couts, no synchronisation), then the wave's own epilogue
+    // (small grids: the groups are spread over blockIdx.y -- every block then re-loads the few KB of its input tile and takes gpb of them)
+    const int ngroups = (p.Cout + CFG::NWN * CFG::WN - 1) / (CFG::NWN * CFG::WN);
+    const int cg0 = blockIdx.y * gpb, cg1 = cg0 + gpb < ngroups ? cg0 + gpb : ngroups;
+    T* outp = static_cast<T*>(p.out);
+    for (int cg = cg0; cg < cg1; ++cg) {
+        const int cout0 = (cg * CFG::NWN + cn) * CFG::WN;            // first cout of this wave in this group
+        const raw16_t* wq = static_cast<const raw16_t*>(p.w) + (size_t)(cout0 / 32) * NS * 64 + lane;
+        CoutRegs<typename CFG::Stage> bias;
+        bias.load(p.bias, p.zero, p.Cout, cout0, 0, lane);
+        float16_t acc[MT][NTL];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // weight fragments in consumption order f = (step, cout tile): a register ring of D untracked loads with counted waits (common.h) --
+        // left to the compiler, two or three requests were in flight and every k16 step waited for an L2 round trip.  D - 1 requests up
+        // front, then every step issues exactly one (past the end: the last fragment again), so the number in flight is constant, and every
+        // request is consumed (settle) before its slot is requested again: a request whose result is overwritten unread is, to the register
+        // allocator, a dead definition -- its destination gets reused while the load is still landing (seen as a memory fault: the first
+        // version requested fragment D - 1 twice).
+        constexpr int NF = NS * NTL, D = NF < 8 ? NF : 8;
+        static_assert(D >= 2, "ring depth");
+        raw16_t ring[D];
+        auto fptr = [&](int f) __attribute__((always_inline)) {
+            const int ff = f < NF ? f : NF - 1;
+            return wq + (size_t)((ff % NTL) * NS + ff / NTL) * 64;
+        };
+#pragma unroll
+        for (int f = 0; f < D - 1; ++f) global_load16_async(ring[f], fptr(f));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            Frag<T> xf[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if constexpr (CFG::RESIDENT) xf[i] = xres[i][s]; else xf[i] = xfrag(i, s);
+            }
+#pragma unroll
+            for (int j = 0; j < NTL; ++j) {
+                const int f = s * NTL + j;
+                global_load16_async(ring[(f + D - 1) % D], fptr(f + D - 1));     // the slot consumed one fragment ago (fragment 0: the last free one)
+                wait_vmcnt<D - 1>();                                 // D - 1 requests are younger than fragment f's
+                settle(ring[f % D]);
+                Frag<T> wf;
+                wf.v = __builtin_bit_cast(half8_t, ring[f % D]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) mma32(acc[i][j], wf, xf[i]);
+            }
+        }
+        wait_vmcnt<0>();                                            // drain the tail requests before their registers are reused
+#pragma unroll
+        for (int f = 0; f < D; ++f) settle(ring[f]);
+        // the staging tile is private to the wave: LDS operations of one wave execute in order, no block barrier -- only the compiler must
+        // not move the reads above the writes (or the next pass's writes above these reads)
+        using STG = typename CFG::Stage;
+#pragma unroll
+        for (int h = 0; h < MT / CFG::SM; ++h) {
+            const float16_t (&sub)[CFG::SM][NTL] = *reinterpret_cast<const float16_t (*)[CFG::SM][NTL]>(&acc[h * CFG::SM]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            switch (p.act) {                                        // block-uniform
+                case S2M2_ACT_GELU: stage_tile<STG, T, S2M2_ACT_GELU>(sub, stg, bias, 1.0f, 0, 0, lane); break;
+                case S2M2_ACT_RELU: stage_tile<STG, T, S2M2_ACT_RELU>(sub, stg, bias, 1.0f, 0, 0, lane); break;
+                default: stage_tile<STG, T, S2M2_ACT_NONE>(sub, stg, bias, 1.0f, 0, 0, lane); break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < CFG::C_IT; ++it) {
+                const int q = lane + 64 * it, row = q / CFG::CPR, pc = q - row * CFG::CPR;
+                const int i = h * CFG::SM + (row >> 5), px = row & 31;
+                const int oy = oy0 + pm * MT + i, ox = ox0 + px, co = cout0 + pc * 8;
+                if (oy < p.Ho && ox < p.Wo && co < p.Cout) {
+                    const raw16_t v = *reinterpret_cast<const raw16_t*>(stg + (size_t)row * CRS + pc * 8);
+                    *reinterpret_cast<raw16_t*>(outp + (((long long)n * p.Ho + oy) * p.Wo + ox) * p.out_stride + co) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int KH, int KW, int S, int CIN, int MT, int NTL, int NWN>
+static int launch_narrow(const NarrowArgs& a, hipStream_t st) {
+    using CFG = NarrowCfg<KH, KW, S, CIN, MT, NTL, NWN>;
+    auto kern = conv_narrow_kernel<CFG>;
+    static size_t lds_granted[kMaxDevices] = {};
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "conv_narrow")) return 1;
+    const int tx = (a.Wo + CFG::PW - 1) / CFG::PW, ty = (a.Ho + CFG::PH - 1) / CFG::PH;
+    const long long nblk = (long long)a.N * tx * ty;
+    if (nblk >= (1LL << 31)) return set_error("conv_narrow: %lld blocks", nblk);
+    // cout groups per block: all of them on a grid that fills the chip by itself, one where every CU would get less than ~4 blocks
+    const int ngroups = (a.Cout + CFG::NWN * CFG::WN - 1) / (CFG::NWN * CFG::WN);
+    const int gpb = nblk >= 1024 ? ngroups : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)((ngroups + gpb - 1) / gpb)), dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty, gpb);
+    return check_launch("conv_narrow");
+}
+
+// 8 output rows per block where that still gives every CU several blocks, else 4
+static bool narrow_tall(const NarrowArgs& a) {
+    static const int force_mt = getenv("S2M2_NARROW_MT") ? atoi(getenv("S2M2_NARROW_MT")) : 0;       // A/B switch: 1 = 4-row blocks, 2 = 8-row blocks
+    const long long blocks8 = (long long)a.N * ((a.Wo + 31) / 32) * ((a.Ho + 7) / 8);
+    return force_mt ? force_mt == 2 : blocks8 >= 1024;
+}
+
+}  // namespace s2m2
+
+extern "C" int s2m2_conv_narrow_supported(int KH, int KW, int stride, int Cin, int Cout, int dtype) {
+    if (dtype != S2M2_F16 || Cout <= 0 || Cout % 8) return 0;
+    if (KH == 3 && KW == 3 && stride == 1 && Cin == 8) return 1;
+    if (KH == 5 && KW == 5 && stride == 2 && Cin == 16) return ((Cout + 31) / 32) % 2 == 0;          // two cout tiles per group
+    return 0;
+}
+
+extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(d, "conv_narrow: null descriptor");
+    S2M2_REQUIRE(d->x && d->weight_frag && d->out, "conv_narrow: null pointer");
+    S2M2_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && (long long)d->N * d->H * d->W < (1LL << 31), "conv_narrow: N=%d H=%d W=%d", d->N, d->H, d->W);
+    S2M2_REQUIRE(s2m2_conv_narrow_supported(d->KH, d->KW, d->stride, d->Cin, d->Cout, d->dtype),
+                 "conv_narrow: %dx%d stride %d Cin=%d Cout=%d dtype=%d is not supported (ask s2m2_conv_narrow_supported)", d->KH, d->KW, d->stride,
+                 d->Cin, d->Cout, d->dtype);
+    S2M2_REQUIRE(d->x_stride >= d->Cin && d->x_stride % 8 == 0 && d->out_stride >= d->Cout && d->out_stride % 8 == 0,
+                 "conv_narrow: x_stride=%lld / out_stride=%lld must cover the channels and be multiples of 8", d->x_stride, d->out_stride);
+    S2M2_REQUIRE(d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_GELU || d->act == S2M2_ACT_RELU, "conv_narrow: act=%d (NONE, GELU or RELU)", d->act);
+    NarrowArgs a;
+    a.x = d->x; a.xstride = d->x_stride; a.N = d->N; a.H = d->H; a.W = d->W;
+    a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
+    a.w = d->weight_frag; a.bias = d->bias; a.out = d->out; a.out_stride = d->out_stride; a.Cout = d->Cout; a.act = d->act;
+    a.zero = zero_page();
+    S2M2_REQUIRE(a.zero, "conv_narrow: cannot allocate the zero page");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool tall = narrow_tall(a);
+    if (d->Cin == 8) return tall ? launch_narrow<3, 3, 1, 8, 2, 1, 1>(a, st) : launch_narrow<3, 3, 1, 8, 1, 1, 1>(a, st);
+    // 5x5: wave pairs split the two cout tiles of a group and share 2 / 4 output rows (A/B switch S2M2_NARROW_NWN=1: every wave both tiles)
+    static const bool split = !(getenv("S2M2_NARROW_NWN") && atoi(getenv("S2M2_NARROW_NWN")) == 1);
+    if (split) return tall ? launch_narrow<5, 5, 2, 16, 4, 1, 2>(a, st) : launch_narrow<5, 5, 2, 16, 2, 1, 2>(a, st);
+    return tall ? launch_narrow<5, 5, 2, 16, 2, 2, 1>(a, st) : launch_narrow<5, 5, 2, 16, 1, 2, 1>(a, st);
+}

@@ -193,6 +193,12 @@ class Engine:
                 and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
                 and wp.shape[1] == sum(t.shape[-1] for t in srcs) and self.pw_ok(wp.shape[1], cout)):
             return hip.pw_direct(srcs, self.wpw(spec), bp, cout, act=kw.get("act", hip.ACT_NONE), shuffle2=kw.get("shuffle2", 0))
+        # a 3x3 (or 5x5 stride-2) layer on ONE 8- / 16-channel tensor (the (disp, rgb) / (disp, conf, occ) side inputs, the stem's output): K12,
+        # the direct form for narrow inputs (profiles/r04/narrowbench.txt)
+        if (kh > 1 and not ln and not getattr(spec, "korder", 0) and len(srcs) == 1 and srcs[0].dim() == 4 and set(kw) <= {"act", "stride"}
+                and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU) and wp.shape[1] == kh * kw_ * srcs[0].shape[-1]
+                and self.narrow_ok(kh, kw_, kw.get("stride", 1), srcs[0].shape[-1], cout)):
+            return hip.conv_narrow(srcs[0], self.wpw(spec), bp, kh, kw_, cout, stride=kw.get("stride", 1), act=kw.get("act", hip.ACT_NONE))
         if ln:
             kw["ln_wsum"] = self.wsum(spec)
         if getattr(spec, "korder", 0):
@@ -412,6 +418,14 @@ class Engine:
         ok = self._chain_ok.get(("pw", k, cout))
         if ok is None:
             ok = self._chain_ok[("pw", k, cout)] = hip.pw_direct_supported(k, cout, self.dtype)
+        return ok
+
+    def narrow_ok(self, kh: int, kw: int, stride: int, cin: int, cout: int) -> bool:
+        """K12 (hip.conv_narrow) exists for this spatial layer on a cin-channel tensor in this dtype (asked once per shape)"""
+        key = ("narrow", kh, kw, stride, cin, cout)
+        ok = self._chain_ok.get(key)
+        if ok is None:
+            ok = self._chain_ok[key] = hip.conv_narrow_supported(kh, kw, stride, cin, cout, self.dtype)
         return ok
 
     def wpw(self, spec: Spec) -> Tensor:

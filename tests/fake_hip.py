@@ -99,6 +99,9 @@ def make():
     def pw_direct_supported(K, Cout, dtype):
         return False                                     # (fp16 only; the CPU stand-in is the fp32 wiring)
 
+    def conv_narrow_supported(KH, KW, stride, Cin, Cout, dtype):
+        return False                                     # (fp16 only)
+
     def mlp_chain(x, stages, res=None, res_stage=-1, carry=False, ln_eps=1e-5, ln_out=None, xcd_group_rows=0, fan=None, frag=False):
         t, ys = x.float(), []
         for s, (w, b, act, wsum) in enumerate(stages):
@@ -222,6 +225,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, pw_direct_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, pw_direct_supported, conv_narrow_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
         setattr(ns, f.__name__, f)
     return ns

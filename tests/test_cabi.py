@@ -108,6 +108,21 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_pw_direct(ctypes.byref(w), None) != 0 and b"act=" in lib.s2m2_last_error()
     w.act, w.shuffle2 = hip.ACT_NONE, 24
     assert lib.s2m2_pw_direct(ctypes.byref(w), None) != 0 and b"shuffle2" in lib.s2m2_last_error()
+    # round 4: K12 (spatial layers on 8- / 16-channel tensors, direct form): shapes, strides, activation
+    assert lib.s2m2_conv_narrow_supported(3, 3, 1, 8, 160, hip.F16) == 1 and lib.s2m2_conv_narrow_supported(5, 5, 2, 16, 64, hip.F16) == 1
+    assert lib.s2m2_conv_narrow_supported(5, 5, 2, 16, 32, hip.F16) == 0 and lib.s2m2_conv_narrow_supported(3, 3, 1, 16, 32, hip.F16) == 0
+    assert lib.s2m2_conv_narrow_supported(3, 3, 1, 8, 32, hip.F32) == 0 and lib.s2m2_conv_narrow_supported(3, 3, 1, 8, 12, hip.F16) == 0
+    assert lib.s2m2_conv_narrow(None, None) != 0 and b"null descriptor" in lib.s2m2_last_error()
+    nd = hip.NarrowDesc()
+    nd.x, nd.x_stride, nd.N, nd.H, nd.W, nd.Cin, nd.weight_frag, nd.out, nd.out_stride = 4096, 8, 1, 8, 8, 8, 4096, 4096, 32
+    nd.Cout, nd.KH, nd.KW, nd.stride, nd.act, nd.dtype = 32, 3, 3, 2, hip.ACT_NONE, hip.F16
+    assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"not supported" in lib.s2m2_last_error()       # 3x3 with a stride
+    nd.stride, nd.x_stride = 1, 12
+    assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"multiples of 8" in lib.s2m2_last_error()
+    nd.x_stride, nd.out_stride = 16, 24
+    assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"out_stride" in lib.s2m2_last_error()          # narrower than Cout
+    nd.out_stride, nd.act = 32, hip.ACT_TANH
+    assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"act=" in lib.s2m2_last_error()
     assert lib.s2m2_feature_fusion_supported(128, hip.F16) == 1 and lib.s2m2_feature_fusion_supported(384, hip.F16) == 0
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 64, 192, 4096, 4096, 4096, 4096, 4096, 0, 0, hip.F16, None) != 0
     assert b"not supported" in lib.s2m2_last_error()

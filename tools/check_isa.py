@@ -84,12 +84,14 @@ def check_function(name: str, lines):
     return problems, nloops
 
 
-def check_straight_line(name: str, lines):
-    """feature_fusion_direct_kernel: region = first MFMA .. last 16-byte global load of the kernel's instruction stream"""
+def check_straight_line(name: str, lines, depth=None, min_mfma=16, exact=True):
+    """feature_fusion_direct_kernel / conv_narrow_kernel: region = first MFMA .. last 16-byte global load of the kernel's instruction stream.
+    depth: ring depth (default: parsed from FusionDirectCfg); exact: the counted waits inside the region are exactly {depth - 1}, else depth - 1
+    is the STRICTEST wait there (the compiler may add looser ones of its own for tracked loads)"""
     ins = [l.split(";")[0].strip() for l in lines if l.strip() and not l.strip().startswith((".", ";"))]
     mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
     ld = [i for i, l in enumerate(ins) if l.startswith("global_load_dwordx4")]
-    if len(mf) < 16 or not ld or ld[-1] < mf[0]:
+    if len(mf) < min_mfma or not ld or ld[-1] < mf[0]:
         return [f"{name}: no MFMA / fragment-load region found (the check no longer matches the generated code)"], 0
     lo, hi = mf[0], ld[-1]
     # registers whose fragment request may still be in flight: set by a 16-byte load, cleared by the MFMA that consumes them (the allocator
@@ -126,10 +128,13 @@ def check_straight_line(name: str, lines):
         for t in dsts:
             if regs_of(t) & flying:
                 problems.append(f"{name}: instruction overwrites a register whose fragment may be in flight: {l}")
-    m = re.search(r"FusionDirectCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
-    depth = int(m.group(4)) if m else 9
-    if waits != {depth - 1}:
+    if depth is None:
+        m = re.search(r"FusionDirectCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        depth = int(m.group(4)) if m else 9
+    if exact and waits != {depth - 1}:
         problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected exactly {depth - 1}: ring depth - 1)")
+    if not exact and (not waits or min(waits) != depth - 1):
+        problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected {depth - 1} = ring depth - 1 as the strictest)")
     return problems, 1
 
 
@@ -232,9 +237,21 @@ def main() -> int:
         text = compile_asm(SRC, keep or os.path.join(td, "conv.s"))
         ftext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "fusion.hip"), os.path.join(td, "fusion.s"))
         ktext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "ln_corr.hip"), os.path.join(td, "ln_corr.s"))
-        if text is None or ftext is None or ktext is None:
+        ntext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "conv_narrow.hip"), os.path.join(td, "conv_narrow.s"))
+        if text is None or ftext is None or ktext is None or ntext is None:
             return 2
     bad = check_ln_corr(ktext)
+    nfuncs = functions(ntext, "_ZN4s2m218conv_narrow_kernel")
+    if not nfuncs:
+        print("check_isa: no conv_narrow_kernel instantiation found in the assembly")
+        return 1
+    for name, lines in nfuncs.items():
+        m = re.search(r"NarrowCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        kh, kw, _, cin, mt, ntl, _ = (int(g) for g in m.groups())
+        ns = (kh * kw * cin + 15) // 16
+        problems, n = check_straight_line(name, lines, depth=min(ns * ntl, 8), min_mfma=ns * mt * ntl, exact=False)
+        print(f"check_isa: conv_narrow_kernel<{kh}x{kw}, Cin {cin}, MT {mt}, NTL {ntl}>: {n} refill region(s), {len(problems)} problem(s)")
+        bad += problems
     ffuncs = functions(ftext, "_ZN4s2m228feature_fusion_direct_kernel")
     if not ffuncs:
         print("check_isa: no feature_fusion_direct_kernel instantiation found in the assembly")
