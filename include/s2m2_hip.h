@@ -298,16 +298,23 @@ int s2m2_pw_direct(const s2m2_pw_desc* desc, void* stream);
  *   the flipped kernel) whose input has exactly 8 or 16 channels -- one or two 16-byte pieces per pixel (reference: UpsampleMask1x
  *   conv_disp.0 | conv_rgb.0, submodules.py:124-129,139-141; LocalRefiner disp_feat.0 | conf_occ_feat.0, refinenet.py:93-101,141-142;
  *   CNNEncoder conv1_down.0, submodules.py:69-71).  Shapes: 3x3 stride 1 on 8 channels (any Cout % 8 == 0), 5x5 stride 2 on 16 channels
- *   (an even number of 32-cout tiles): ask s2m2_conv_narrow_supported.  Padding K / 2, Ho = ceil(H / stride) as s2m2_conv2d.
+ *   (an even number of 32-cout tiles), and the second form below: ask s2m2_conv_narrow_supported (Cin = all input channels).  Padding K / 2, Ho = ceil(H / stride) as s2m2_conv2d.
  *     out[n, y, x, :] = act(sum_taps W[:, tap, :] . x[n, y*s - K/2 + ky, x*s - K/2 + kx, :] + bias)        act: NONE / GELU / RELU
  *   x: (N, H, W, Cin) with pixel stride x_stride (elements, multiple of 8); out: (N, Ho, Wo, Cout), pixel stride out_stride.
  *   weight_frag: the (Cout, KH*KW*Cin) matrix of s2m2_conv2d's K order 0 (K = (tap, channel)) zero-padded to (32 * tiles, 16 * steps) in
  *   MFMA-fragment order, as for K11 (pack.pw_frag); bias fp32 (Cout) or NULL.
+ *   Second form, same entry point -- 3x3 stride 1 with FEW OUTPUT channels on wider inputs (UpsampleMask1x conv_concat.0, submodules.py:
+ *   133-137,143; LocalRefiner disp_feat.2 and disp_update.2 | conf_occ_update.2, refinenet.py:93-96,108-118; GlobalRefiner out_feat,
+ *   refinenet.py:61-66): Cin = 48 (Cout <= 64), 96 (Cout <= 96), 128 / 256 (Cout <= 32), from one or two channel-concatenated sources
+ *   (x, x1).  Cin = 128 / 256: the K columns of the weight matrix chunk-major, K = (chunk of 64 channels, tap, channel) (pack.narrow_frag).
  */
 typedef struct s2m2_narrow_desc {
     const void* x;
     long long x_stride;
-    int N, H, W, Cin;
+    int N, H, W, Cin;                  /* Cin: ALL input channels (x holds the first Cin - Cin1 of them) */
+    const void* x1;                    /* second source: channels [Cin - Cin1, Cin), pixel stride x1_stride; Cin1 = 0: none */
+    long long x1_stride;
+    int Cin1;
     const void* weight_frag;
     const float* bias;
     void* out;

@@ -81,6 +81,21 @@ template <int N, bool ASYNC = (S2M2_UNTRACKED_LOADS != 0)> __device__ __forceinl
     if constexpr (ASYNC) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));   // ordered against the loads / settle() by volatility alone
 }
 __device__ __forceinline__ void settle(raw16_t& v) { asm volatile("" : "+v"(v)); }
+// counted wait whose count is a constant only after unrolling (the tail of a fully unrolled ring: fewer and fewer requests are younger than
+// the fragment consumed next); n is clamped to [0, 8]
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+        case 8: wait_vmcnt<8>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        default: wait_vmcnt<0>(); break;
+    }
+}
 
 // flat thread index -> (gid / d, gid % d) in 32-bit arithmetic: a 64-bit division costs ~80 VALU instructions on gfx950, a 32-bit one ~25, and the
 // one-thread-per-element kernels (K3, K7, K8) decode two or three of them per thread -- for the lookups that was more than the work itself.

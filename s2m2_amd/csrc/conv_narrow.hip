@@ -14,6 +14,16 @@
 // take the channel halves.  The weight fragments (pack.pw_frag of the K5 K-order-0 matrix: K = (tap, channel), zero-padded to k16 steps and
 // 32-cout tiles) go from global memory straight into MFMA operand registers -- they are a few KB, L2-resident, shared by every block.
 // Epilogue per wave, no block barrier: bias + activation in registers -> a wave-private staging tile [pixel][cout] -> 16-byte NHWC stores.
+//
+// Second form, same entry point (conv_px_kernel): 3x3 layers with FEW OUTPUT channels on wider inputs -- the other layers K5 ran on its
+// LDS-staged tiles because they are no multiple of the 128-cout blocks of the fragment-stream kernel (K5 v5):
+//   UpsampleMask1x   conv_concat.0: Conv2d(cat(32, 16) -> 48, k 3), ReLU, full resolution                                  submodules.py:133-137,143
+//   LocalRefiner     disp_feat.2: Conv2d(96 -> 96, k 3)                                                                    refinenet.py:93-96
+//                    disp_update.2 | conf_occ_update.2 merged: Conv2d(2C -> 1 + 2, k 3), out_feat of GlobalRefiner (C -> 1)   refinenet.py:61-66,108-118
+// The same pixel split (a wave = its own output rows x ALL couts, up to three 32-cout tiles), the input patch + halo in LDS per chunk of
+// CH = 48 / 96 / 64 channels (row stride CH + 8 halfs), the K loop of a chunk = 9 taps x CH / 16 steps x NTL fragments through the same
+// register ring; further chunks (Cin = 128 / 256: 2 / 4 of 64 channels) re-load the tile behind a block barrier.  Fragment order per cout
+// tile: (chunk, tap, k16 step) = the K order 0 of K5 for one chunk, columns permuted chunk-major for several (pack.narrow_frag).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -24,6 +34,9 @@ namespace s2m2 {
 struct NarrowArgs {
     const void* x;
     long long xstride;                  // pixel stride of x (elements)
+    const void* x1;                     // conv_px_kernel: second source (channels [c0, Cin)), or x again
+    long long x1stride;
+    int c0, Cin, nchunk;                // channels of x; all input channels; channel chunks of CH
     int N, H, W, Ho, Wo;
     const void* w;                      // fragment order: [cout tile][k16 step][lane] x 16 bytes
     const float* bias;
@@ -148,17 +161,15 @@ __global__ __launch_bounds__(CFG::NT) void conv_narrow_kernel(NarrowArgs p, int 
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         // weight fragments in consumption order f = (step, cout tile): a register ring of D untracked loads with counted waits (common.h) --
         // left to the compiler, two or three requests were in flight and every k16 step waited for an L2 round trip.  D - 1 requests up
-        // front, then every step issues exactly one (past the end: the last fragment again), so the number in flight is constant, and every
-        // request is consumed (settle) before its slot is requested again: a request whose result is overwritten unread is, to the register
-        // allocator, a dead definition -- its destination gets reused while the load is still landing (seen as a memory fault: the first
-        // version requested fragment D - 1 twice).
+        // front, then every fragment issues the request D - 1 ahead of it (none past the end: the counted waits of the fully unrolled tail
+        // shrink instead).  Every request is consumed by an MFMA before its slot is requested again: a request whose result is overwritten
+        // unread -- or only "used" by a final settle() -- is a dead definition to the register allocator, which then reuses or copies its
+        // destination while the load is still landing (seen as a memory fault in the first version, which requested fragment D - 1 twice;
+        // tools/check_isa.py flags the copies).
         constexpr int NF = NS * NTL, D = NF < 8 ? NF : 8;
         static_assert(D >= 2, "ring depth");
         raw16_t ring[D];
-        auto fptr = [&](int f) __attribute__((always_inline)) {
-            const int ff = f < NF ? f : NF - 1;
-            return wq + (size_t)((ff % NTL) * NS + ff / NTL) * 64;
-        };
+        auto fptr = [&](int f) __attribute__((always_inline)) { return wq + (size_t)((f % NTL) * NS + f / NTL) * 64; };
 #pragma unroll
         for (int f = 0; f < D - 1; ++f) global_load16_async(ring[f], fptr(f));
 #pragma unroll
@@ -171,8 +182,8 @@ __global__ __launch_bounds__(CFG::NT) void conv_narrow_kernel(NarrowArgs p, int 
 #pragma unroll
             for (int j = 0; j < NTL; ++j) {
                 const int f = s * NTL + j;
-                global_load16_async(ring[(f + D - 1) % D], fptr(f + D - 1));     // the slot consumed one fragment ago (fragment 0: the last free one)
-                wait_vmcnt<D - 1>();                                 // D - 1 requests are younger than fragment f's
+                if (f + D - 1 < NF) global_load16_async(ring[(f + D - 1) % D], fptr(f + D - 1));   // the slot consumed one fragment ago (fragment 0: the last free one)
+                wait_vmcnt_n(NF - 1 - f < D - 1 ? NF - 1 - f : D - 1);   // requests younger than fragment f's (f is a constant after unrolling)
                 settle(ring[f % D]);
                 Frag<T> wf;
                 wf.v = __builtin_bit_cast(half8_t, ring[f % D]);
@@ -180,9 +191,6 @@ __global__ __launch_bounds__(CFG::NT) void conv_narrow_kernel(NarrowArgs p, int 
                 for (int i = 0; i < MT; ++i) mma32(acc[i][j], wf, xf[i]);
             }
         }
-        wait_vmcnt<0>();                                            // drain the tail requests before their registers are reused
-#pragma unroll
-        for (int f = 0; f < D; ++f) settle(ring[f]);
         // the staging tile is private to the wave: LDS operations of one wave execute in order, no block barrier -- only the compiler must
         // not move the reads above the writes (or the next pass's writes above these reads)
         using STG = typename CFG::Stage;
@@ -215,6 +223,156 @@ __global__ __launch_bounds__(CFG::NT) void conv_narrow_kernel(NarrowArgs p, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_px_kernel: 3x3 stride 1, Cin = nchunk * CH (CH = 48 / 96 / 64), NTL cout tiles per block (blockIdx.y: which), one or two sources
+template <int CH_, int NTL_, int MT_, int NW_ = 4>
+struct PxCfg {
+    static constexpr int CH = CH_, NTL = NTL_, MT = MT_, KS = CH_ / 16, NTAP = 9;
+    // NW: waves per block = output rows per block / MT.  The layers at 1/4 resolution are chains of memory latencies (a tile load per chunk,
+    // then a K loop of a few hundred cycles): FEWER waves per block = more, smaller blocks per CU whose chains interleave
+    static constexpr int NW = NW_, NT = 64 * NW;
+    static constexpr int PW = 32, PH = NW * MT, HW = PW + 2, HH = PH + 2;
+    static constexpr int RS = CH + 8;                                     // LDS row stride (elements): 16 bytes of padding per halo pixel
+    static constexpr int PPX = CH / 8, NPIECE = HW * HH * PPX, A_IT = (NPIECE + NT - 1) / NT;
+    static constexpr int NF = NTAP * KS * NTL;                            // fragments of a chunk, per wave
+    static constexpr int D = 8;                                           // ring depth
+    static constexpr int SM = MT < 2 ? MT : 2;
+    struct Stage {
+        static constexpr int MT = SM, NTL = NTL_, WM = 32 * SM, WN = 32 * NTL_, CRS = WN + 8;
+    };
+    static constexpr int WN = Stage::WN, CRS = Stage::CRS, CPR = WN / 8, C_IT = Stage::WM * CPR / 64;
+    static constexpr size_t A_BYTES = (size_t)HW * HH * RS * sizeof(half_t);
+    static constexpr size_t STG_BYTES = (size_t)NW * Stage::WM * CRS * sizeof(half_t);
+    static constexpr size_t LDS_BYTES = A_BYTES + STG_BYTES;
+    static_assert(CH % 16 == 0 && (Stage::WM * CPR) % 64 == 0 && MT % SM == 0 && LDS_BYTES <= 80 * 1024, "unsupported pixel-split tile");
+};
+
+template <typename CFG>
+__global__ __launch_bounds__(CFG::NT) void conv_px_kernel(NarrowArgs p, int tiles_x, int tiles_y) {
+    using T = half_t;
+    constexpr int MT = CFG::MT, NTL = CFG::NTL, KS = CFG::KS, HW = CFG::HW, RS = CFG::RS, CRS = CFG::CRS, D = CFG::D, NF = CFG::NF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* A = reinterpret_cast<T*>(smem);                              // [HH][HW][RS] halo tile of one channel chunk
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    T* stg = reinterpret_cast<T*>(smem + CFG::A_BYTES) + (size_t)wv * CFG::Stage::WM * CRS;
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const int n = bx / tiles_y;
+    const int oy0 = ty * CFG::PH, ox0 = tx * CFG::PW;
+
+    // blockIdx.y: which group of NTL cout tiles (small grids: the cout tiles of a layer are spread over blocks that each re-load the
+    // input tile -- three times the blocks, each a third as long, instead of a grid that ends in a quarter-full round)
+    const int cout0 = blockIdx.y * CFG::WN;
+    CoutRegs<typename CFG::Stage> bias;
+    bias.load(p.bias, p.zero, p.Cout, cout0, 0, lane);
+    float16_t acc[MT][NTL];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nstot = p.nchunk * CFG::NTAP * KS;                    // k16 steps of a cout tile
+    const raw16_t* wbase = static_cast<const raw16_t*>(p.w) + (size_t)(cout0 / 32) * nstot * 64 + lane;
+    const T* x0 = static_cast<const T*>(p.x);
+    const T* x1 = static_cast<const T*>(p.x1);
+
+    for (int chunk = 0; chunk < p.nchunk; ++chunk) {
+        // ---- halo tile of this chunk (zero outside the image / beyond Cin)
+        if (chunk > 0) __syncthreads();                             // every wave is done with the previous chunk's tile
+        raw16_t ra[CFG::A_IT];
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const int idx = tid + CFG::NT * it, pix = idx / CFG::PPX, part = idx - pix * CFG::PPX;
+            const int hy = pix / HW, hx = pix - hy * HW;
+            const int yy = oy0 - 1 + hy, xx = ox0 - 1 + hx;
+            const int c = chunk * CFG::CH + part * 8;
+            const bool ok = idx < CFG::NPIECE && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && c < p.Cin;
+            const long long pixel = ((long long)n * p.H + yy) * p.W + xx;
+            const T* src = c < p.c0 ? x0 + pixel * p.xstride + c : x1 + pixel * p.x1stride + (c - p.c0);
+            ra[it] = global_load16(ok ? src : static_cast<const T*>(p.zero));
+        }
+#pragma unroll
+        for (int it = 0; it < CFG::A_IT; ++it) {
+            const int idx = tid + CFG::NT * it, pix = idx / CFG::PPX, part = idx - pix * CFG::PPX;
+            if (idx < CFG::NPIECE) *reinterpret_cast<raw16_t*>(A + (size_t)pix * RS + part * 8) = ra[it];
+        }
+        __syncthreads();
+
+        // ---- K loop of the chunk: fragments in consumption order f = (tap, k16 step, cout tile) through the register ring (see above)
+        const raw16_t* wq = wbase + (size_t)chunk * CFG::NTAP * KS * 64;
+        raw16_t ring[D];
+        auto fptr = [&](int f) __attribute__((always_inline)) { return wq + ((size_t)(f % NTL) * nstot + f / NTL) * 64; };
+#pragma unroll
+        for (int f = 0; f < D - 1; ++f) global_load16_async(ring[f], fptr(f));
+        const T* arow = A + (size_t)(wv * MT * HW + l31) * RS + hi * 8;
+#pragma unroll
+        for (int tap = 0; tap < CFG::NTAP; ++tap) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<T> xf[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) load_frag(xf[i], arow + (size_t)((i + tap / 3) * HW + tap % 3) * RS + ks * 16);
+#pragma unroll
+                for (int j = 0; j < NTL; ++j) {
+                    const int f = (tap * KS + ks) * NTL + j;
+                    if (f + D - 1 < NF) global_load16_async(ring[(f + D - 1) % D], fptr(f + D - 1));
+                    wait_vmcnt_n(NF - 1 - f < D - 1 ? NF - 1 - f : D - 1);
+                    settle(ring[f % D]);
+                    Frag<T> wf;
+                    wf.v = __builtin_bit_cast(half8_t, ring[f % D]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) mma32(acc[i][j], wf, xf[i]);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue per wave (wave-private staging tile, as above)
+    using STG = typename CFG::Stage;
+    T* outp = static_cast<T*>(p.out);
+#pragma unroll
+    for (int h = 0; h < MT / CFG::SM; ++h) {
+        const float16_t (&sub)[CFG::SM][NTL] = *reinterpret_cast<const float16_t (*)[CFG::SM][NTL]>(&acc[h * CFG::SM]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        switch (p.act) {                                            // block-uniform
+            case S2M2_ACT_GELU: stage_tile<STG, T, S2M2_ACT_GELU>(sub, stg, bias, 1.0f, 0, 0, lane); break;
+            case S2M2_ACT_RELU: stage_tile<STG, T, S2M2_ACT_RELU>(sub, stg, bias, 1.0f, 0, 0, lane); break;
+            default: stage_tile<STG, T, S2M2_ACT_NONE>(sub, stg, bias, 1.0f, 0, 0, lane); break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < CFG::C_IT; ++it) {
+            const int q = lane + 64 * it, row = q / CFG::CPR, pc = q - row * CFG::CPR;
+            const int i = h * CFG::SM + (row >> 5), px = row & 31;
+            const int oy = oy0 + wv * MT + i, ox = ox0 + px, co = cout0 + pc * 8;
+            if (oy < p.Ho && ox < p.Wo && co < p.Cout) {
+                const raw16_t v = *reinterpret_cast<const raw16_t*>(stg + (size_t)row * CRS + pc * 8);
+                *reinterpret_cast<raw16_t*>(outp + (((long long)n * p.Ho + oy) * p.Wo + ox) * p.out_stride + co) = v;
+            }
+        }
+    }
+}
+
+template <int CH, int NTL, int MT, int NW = 4>
+static int launch_px(const NarrowArgs& a, hipStream_t st) {
+    using CFG = PxCfg<CH, NTL, MT, NW>;
+    auto kern = conv_px_kernel<CFG>;
+    static size_t lds_granted[kMaxDevices] = {};
+    if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "conv_narrow")) return 1;
+    const int tx = (a.Wo + CFG::PW - 1) / CFG::PW, ty = (a.Ho + CFG::PH - 1) / CFG::PH;
+    const long long nblk = (long long)a.N * tx * ty;
+    if (nblk >= (1LL << 31)) return set_error("conv_narrow: %lld blocks", nblk);
+    const int gy = (a.Cout + CFG::WN - 1) / CFG::WN;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, (unsigned)gy), dim3(CFG::NT), CFG::LDS_BYTES, st, a, tx, ty);
+    return check_launch("conv_narrow");
+}
+
 template <int KH, int KW, int S, int CIN, int MT, int NTL, int NWN>
 static int launch_narrow(const NarrowArgs& a, hipStream_t st) {
     using CFG = NarrowCfg<KH, KW, S, CIN, MT, NTL, NWN>;
@@ -244,6 +402,11 @@ extern "C" int s2m2_conv_narrow_supported(int KH, int KW, int stride, int Cin, i
     if (dtype != S2M2_F16 || Cout <= 0 || Cout % 8) return 0;
     if (KH == 3 && KW == 3 && stride == 1 && Cin == 8) return 1;
     if (KH == 5 && KW == 5 && stride == 2 && Cin == 16) return ((Cout + 31) / 32) % 2 == 0;          // two cout tiles per group
+    if (KH == 3 && KW == 3 && stride == 1) {                       // pixel-split form on wider inputs: few output channels
+        if (Cin == 48) return Cout <= 64;
+        if (Cin == 96) return Cout <= 96;
+        if (Cin == 128 || Cin == 256) return Cout <= 32;
+    }
     return 0;
 }
 
@@ -255,17 +418,30 @@ extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
     S2M2_REQUIRE(s2m2_conv_narrow_supported(d->KH, d->KW, d->stride, d->Cin, d->Cout, d->dtype),
                  "conv_narrow: %dx%d stride %d Cin=%d Cout=%d dtype=%d is not supported (ask s2m2_conv_narrow_supported)", d->KH, d->KW, d->stride,
                  d->Cin, d->Cout, d->dtype);
-    S2M2_REQUIRE(d->x_stride >= d->Cin && d->x_stride % 8 == 0 && d->out_stride >= d->Cout && d->out_stride % 8 == 0,
+    S2M2_REQUIRE(d->x_stride >= d->Cin - d->Cin1 && d->x_stride % 8 == 0 && d->out_stride >= d->Cout && d->out_stride % 8 == 0,
                  "conv_narrow: x_stride=%lld / out_stride=%lld must cover the channels and be multiples of 8", d->x_stride, d->out_stride);
     S2M2_REQUIRE(d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_GELU || d->act == S2M2_ACT_RELU, "conv_narrow: act=%d (NONE, GELU or RELU)", d->act);
+    S2M2_REQUIRE(d->Cin1 >= 0 && d->Cin1 < d->Cin && d->Cin1 % 8 == 0 && (d->Cin1 == 0 || (d->x1 && d->x1_stride >= d->Cin1 && d->x1_stride % 8 == 0)),
+                 "conv_narrow: the second source needs a pointer, Cin1=%d a multiple of 8 below Cin and a pixel stride that is a multiple of 8", d->Cin1);
+    S2M2_REQUIRE(d->Cin1 == 0 || d->Cin > 16, "conv_narrow: the 8- / 16-channel forms read one source");
     NarrowArgs a;
     a.x = d->x; a.xstride = d->x_stride; a.N = d->N; a.H = d->H; a.W = d->W;
+    a.c0 = d->Cin - d->Cin1; a.Cin = d->Cin;
+    a.x1 = d->Cin1 ? d->x1 : d->x; a.x1stride = d->Cin1 ? d->x1_stride : d->x_stride;
+    a.nchunk = d->Cin >= 128 ? d->Cin / 64 : 1;
     a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
     a.w = d->weight_frag; a.bias = d->bias; a.out = d->out; a.out_stride = d->out_stride; a.Cout = d->Cout; a.act = d->act;
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "conv_narrow: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tall = narrow_tall(a);
+    if (d->Cin == 48) return tall ? launch_px<48, 2, 2>(a, st) : launch_px<48, 2, 1>(a, st);
+    // measured (profiles/r04/narrowbench.txt, narrowbench_variants.txt): 96 -> 96 with ONE cout tile per block (grid.y = 3) 27.2 us against 27.9 for
+    // all three in one block; the 128- / 256-channel heads in chunks of 64 channels with 2 waves x 2 rows per block 22.7 / 12.5 us against
+    // 25.1 / 13.4 (4 waves x 1 row) and 27.4 / 14.3 (chunks of 128); 1-wave blocks 27 - 45 us.  Every wave streams the layer's whole weight
+    // set for its own 32 - 64 pixels: these launches are bound by that L2 -> CU traffic, not by MFMA or HBM.
+    if (d->Cin == 96) return launch_px<96, 1, 1>(a, st);
+    if (d->Cin >= 128) return launch_px<64, 1, 2, 2>(a, st);
     if (d->Cin == 8) return tall ? launch_narrow<3, 3, 1, 8, 2, 1, 1>(a, st) : launch_narrow<3, 3, 1, 8, 1, 1, 1>(a, st);
     // 5x5: wave pairs split the two cout tiles of a group and share 2 / 4 output rows (A/B switch S2M2_NARROW_NWN=1: every wave both tiles)
     static const bool split = !(getenv("S2M2_NARROW_NWN") && atoi(getenv("S2M2_NARROW_NWN")) == 1);

@@ -105,6 +105,9 @@ class Engine:
         #   hands out the full unmasked volume (the captured "cv" stage), and K1 is 0.2 % of a forward
         self.fuse_k1ln = os.environ.get("S2M2_FUSE_K1LN", "1") != "0"
         self.cv_band = 11 if (os.environ.get("S2M2_CV_BAND", "0") == "1" and self.use_positivity) else -1
+        # S2M2_K12=0: the narrow-input / few-cout 3x3 and 5x5 layers on K5's LDS-staged tiles instead of the pixel-split direct form
+        # (A/B switch: profiles/r04/ab_conv_narrow.txt)
+        self.use_k12 = os.environ.get("S2M2_K12", "1") != "0"
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -193,12 +196,14 @@ class Engine:
                 and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
                 and wp.shape[1] == sum(t.shape[-1] for t in srcs) and self.pw_ok(wp.shape[1], cout)):
             return hip.pw_direct(srcs, self.wpw(spec), bp, cout, act=kw.get("act", hip.ACT_NONE), shuffle2=kw.get("shuffle2", 0))
-        # a 3x3 (or 5x5 stride-2) layer on ONE 8- / 16-channel tensor (the (disp, rgb) / (disp, conf, occ) side inputs, the stem's output): K12,
-        # the direct form for narrow inputs (profiles/r04/narrowbench.txt)
-        if (kh > 1 and not ln and not getattr(spec, "korder", 0) and len(srcs) == 1 and srcs[0].dim() == 4 and set(kw) <= {"act", "stride"}
-                and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU) and wp.shape[1] == kh * kw_ * srcs[0].shape[-1]
-                and self.narrow_ok(kh, kw_, kw.get("stride", 1), srcs[0].shape[-1], cout)):
-            return hip.conv_narrow(srcs[0], self.wpw(spec), bp, kh, kw_, cout, stride=kw.get("stride", 1), act=kw.get("act", hip.ACT_NONE))
+        # spatial layers K5 would run on its LDS-staged tiles -- on an 8- / 16-channel tensor (the (disp, rgb) / (disp, conf, occ) side inputs,
+        # the stem's output), or with few output channels (the mask / update heads, disp_feat.2): K12, the pixel-split direct form
+        # (profiles/r04/narrowbench.txt)
+        if (kh > 1 and not ln and not getattr(spec, "korder", 0) and len(srcs) <= 2 and srcs[0].dim() == 4 and set(kw) <= {"act", "stride"}
+                and kw.get("act", hip.ACT_NONE) in (hip.ACT_NONE, hip.ACT_GELU, hip.ACT_RELU)
+                and wp.shape[1] == kh * kw_ * sum(t.shape[-1] for t in srcs)
+                and self.narrow_ok(kh, kw_, kw.get("stride", 1), sum(t.shape[-1] for t in srcs), cout)):
+            return hip.conv_narrow(srcs, self.wnarrow(spec, kh * kw_), bp, kh, kw_, cout, stride=kw.get("stride", 1), act=kw.get("act", hip.ACT_NONE))
         if ln:
             kw["ln_wsum"] = self.wsum(spec)
         if getattr(spec, "korder", 0):
@@ -425,8 +430,16 @@ class Engine:
         key = ("narrow", kh, kw, stride, cin, cout)
         ok = self._chain_ok.get(key)
         if ok is None:
-            ok = self._chain_ok[key] = hip.conv_narrow_supported(kh, kw, stride, cin, cout, self.dtype)
+            ok = self._chain_ok[key] = self.use_k12 and hip.conv_narrow_supported(kh, kw, stride, cin, cout, self.dtype)
         return ok
+
+    def wnarrow(self, spec: Spec, ntap: int) -> Tensor:
+        """a packed spatial weight in the fragment order of K12 (pack.narrow_frag), permuted once per layer"""
+        wp = spec[0]
+        wf = self._wfrag.get(("narrow", wp.data_ptr()))
+        if wf is None:
+            wf = self._wfrag[("narrow", wp.data_ptr())] = pack.narrow_frag(wp, ntap)
+        return wf
 
     def wpw(self, spec: Spec) -> Tensor:
         """a packed 1x1 weight in the fragment order of K11 (pack.pw_frag), permuted once per layer"""

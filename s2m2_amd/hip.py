@@ -53,8 +53,9 @@ class PwDesc(ctypes.Structure):
 
 class NarrowDesc(ctypes.Structure):
     """mirror of s2m2_narrow_desc (include/s2m2_hip.h)"""
-    _fields_ = [("x", _vp), ("x_stride", _ll), ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("weight_frag", _vp), ("bias", _vp), ("out", _vp),
-                ("out_stride", _ll), ("Cout", _i), ("KH", _i), ("KW", _i), ("stride", _i), ("act", _i), ("dtype", _i)]
+    _fields_ = [("x", _vp), ("x_stride", _ll), ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("x1", _vp), ("x1_stride", _ll), ("Cin1", _i),
+                ("weight_frag", _vp), ("bias", _vp), ("out", _vp), ("out_stride", _ll), ("Cout", _i), ("KH", _i), ("KW", _i), ("stride", _i),
+                ("act", _i), ("dtype", _i)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -535,26 +536,35 @@ def pw_direct(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], Cou
 
 
 def conv_narrow_supported(KH: int, KW: int, stride: int, Cin: int, Cout: int, dtype: torch.dtype) -> bool:
-    """K12 exists for this layer shape (Cin = the input tensor's channel count: exactly 8 or 16)"""
+    """K12 exists for this layer shape (Cin = ALL input channels of the one or two sources)"""
     return bool(load().s2m2_conv_narrow_supported(KH, KW, stride, Cin, Cout, _DT[dtype]))
 
 
-def conv_narrow(x: torch.Tensor, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, stride: int = 1,
+def conv_narrow(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, stride: int = 1,
                 act: int = ACT_NONE) -> torch.Tensor:
-    """K12: a KH x KW convolution (padding K // 2) on an (N,H,W,Cin) tensor of 8 / 16 channels, weight = pack.pw_frag of the K-order-0 matrix
-    (Cout, KH*KW*Cin), fp32 bias (Cout) or None -> (N, ceil(H/stride), ceil(W/stride), Cout)."""
+    """K12: a KH x KW convolution (padding K // 2) in the pixel-split direct form on one (N,H,W,Cin) tensor -- or the channel concatenation
+    of two -- weight = pack.narrow_frag of the K-order-0 matrix (Cout, KH*KW*Cin), fp32 bias (Cout) or None
+    -> (N, ceil(H/stride), ceil(W/stride), Cout).  Shapes: conv_narrow_supported."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    if not 1 <= len(srcs) <= 2 or any(t.shape[:3] != srcs[0].shape[:3] or t.dtype != srcs[0].dtype for t in srcs):
+        raise ValueError("conv_narrow: one or two (N,H,W,C) sources of the same grid and dtype")
+    x = srcs[0]
     xs = _nhwc(x)
-    n, h, w, cin = x.shape
+    n, h, w, _ = x.shape
+    cin = sum(t.shape[-1] for t in srcs)
     K = KH * KW * cin
     if weight_frag.dtype != x.dtype or not weight_frag.is_cuda or not weight_frag.is_contiguous() or weight_frag.dim() != 4 or \
             tuple(weight_frag.shape[2:]) != (64, 8) or weight_frag.shape[0] != (Cout + 31) // 32 or weight_frag.shape[1] != (K + 15) // 16:
-        raise ValueError(f"conv_narrow: weight must be pack.pw_frag of a ({Cout}, {K}) matrix, got {tuple(weight_frag.shape)} {weight_frag.dtype}")
+        raise ValueError(f"conv_narrow: weight must be pack.narrow_frag of a ({Cout}, {K}) matrix, got {tuple(weight_frag.shape)} {weight_frag.dtype}")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() < Cout or not bias.is_cuda):
         raise ValueError(f"conv_narrow: bias must be fp32 ({Cout}) on the device")
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
     out = torch.empty((n, ho, wo, Cout), device=x.device, dtype=x.dtype)
     d = NarrowDesc()
     d.x, d.x_stride, d.N, d.H, d.W, d.Cin = x.data_ptr(), xs, n, h, w, cin
+    if len(srcs) == 2:
+        d.x1, d.x1_stride, d.Cin1 = srcs[1].data_ptr(), _nhwc(srcs[1]), srcs[1].shape[-1]
     d.weight_frag, d.bias, d.out, d.out_stride = weight_frag.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), Cout
     d.Cout, d.KH, d.KW, d.stride, d.act, d.dtype = Cout, KH, KW, stride, act, _DT[x.dtype]
     _check(load().s2m2_conv_narrow(ctypes.byref(d), _stream()), "s2m2_conv_narrow")

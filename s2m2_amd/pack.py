@@ -109,6 +109,19 @@ def pw_frag(wp: torch.Tensor) -> torch.Tensor:
     return _frag_rows(full).contiguous()
 
 
+def narrow_frag(wp: torch.Tensor, ntap: int) -> torch.Tensor:
+    """packed spatial weight (Cout, ntap * Cin) in K order 0 (pack_conv: K = (tap, channel)) -> the fragment order of s2m2_conv_narrow.
+    Below 128 input channels that is pack.pw_frag of the matrix as it is; Cin = 128 / 256 run as chunks of 64 channels, whose K columns come
+    chunk-major: K = (chunk, tap, channel within the chunk)."""
+    cout, k = wp.shape
+    cin = k // ntap
+    assert cin * ntap == k
+    if cin >= 128:
+        assert cin % 64 == 0, cin
+        wp = wp.reshape(cout, ntap, cin // 64, 64).permute(0, 2, 1, 3).reshape(cout, k)
+    return pw_frag(wp)
+
+
 def _frag_rows(w: torch.Tensor) -> torch.Tensor:
     """(R, K) -> (R/32, K/16, 64, 8): per 32-row tile and k16 step the MFMA A-fragment (lane l: row 32t + l % 32, k 16*step + 8*(l // 32) + e)"""
     R, K = w.shape

@@ -49,7 +49,7 @@ def test_conv_narrow_vs_torch_and_k5(hip, k, stride, cin, cout, act, shp, has_bi
     b = torch.randn(cout, device="cuda", generator=g) * 0.5 if has_bias else None
     wp = pack.pack_conv(w, dtype, [(cin, cin)])
     bp = pack.pack_bias(b, cout) if has_bias else None
-    wf = pack.pw_frag(wp)
+    wf = pack.narrow_frag(wp, k * k)
     ref = ACT[act](F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, stride=stride, padding=k // 2)).permute(0, 2, 3, 1)
     if stride == 2:                                                    # Ho = ceil(H / 2) (torch gives floor((H - 1) / 2) + 1: the same)
         assert ref.shape[1] == (shp[1] + 1) // 2 and ref.shape[2] == (shp[2] + 1) // 2
@@ -64,13 +64,53 @@ def test_conv_narrow_vs_torch_and_k5(hip, k, stride, cin, cout, act, shp, has_bi
     assert float(d.max()) <= 2 ** -8 * scale and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
 
 
+# source channels, Cout, act, (N, H, W), bias        (second form: 3x3 layers with few output channels on wider inputs)
+PX_CASES = [
+    ((32, 16), 48, 2, (1, 64, 96), True),                 # mask1x conv_concat.0: cat(32, 16) -> 48, ReLU (4-row blocks)
+    ((32, 16), 48, 2, (1, 520, 544), True),               # ... on a grid large enough for the 8-row blocks
+    ((96,), 96, 0, (1, 64, 76), True),                    # disp_feat.2: 96 -> 96 (reads a channel slice of a wider tensor)
+    ((96,), 96, 1, (2, 37, 45), False),                   # ragged, two images, GELU, no bias
+    ((256,), 16, 0, (1, 64, 76), True),                   # disp_update.2 | conf_occ_update.2: four chunks of 64 channels, 16 couts
+    ((128,), 8, 0, (1, 33, 50), True),                    # GlobalRefiner out_feat: 128 -> 8
+    ((128, 128), 24, 2, (1, 20, 70), True),               # two sources meeting at a chunk boundary
+    ((16, 32), 64, 1, (2, 9, 11), True),                  # two full cout tiles, one ragged block
+]
+
+
+@pytest.mark.parametrize("cs,cout,act,shp,has_bias", PX_CASES)
+def test_conv_px_vs_torch_and_k5(hip, cs, cout, act, shp, has_bias):
+    dtype = torch.float16
+    cin = sum(cs)
+    assert hip.conv_narrow_supported(3, 3, 1, cin, cout, dtype)
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + shp[1])
+    srcs = []
+    for c in cs:
+        wide = (torch.randn(*shp, c + 16, device="cuda", generator=g) * 1.2 + 0.1).to(dtype)
+        srcs.append(wide[..., 8:8 + c])                               # channel slices: pixel stride != channel count
+    w = (torch.randn(cout, cin, 3, 3, device="cuda", generator=g) / math.sqrt(cin * 9)).to(dtype)
+    b = torch.randn(cout, device="cuda", generator=g) * 0.5 if has_bias else None
+    wp = pack.pack_conv(w, dtype, [(c, c) for c in cs])
+    bp = pack.pack_bias(b, cout) if has_bias else None
+    wf = pack.narrow_frag(wp, 9)
+    ref = ACT[act](F.conv2d(torch.cat([t.float() for t in srcs], -1).permute(0, 3, 1, 2), w.float(), b, padding=1)).permute(0, 2, 3, 1)
+    scale = max(1.0, float(ref.abs().max()))
+    for _ in range(3):
+        y = hip.conv_narrow(srcs, wf, bp, 3, 3, cout, act=act)
+        assert tuple(y.shape) == tuple(ref.shape) and y.dtype == dtype
+        assert float((y.float() - ref).abs().max()) < 2 ** -9 * scale * max(1.0, math.sqrt(cin / 128)), (float((y.float() - ref).abs().max()), scale)
+    k5 = hip.conv2d([t.contiguous() for t in srcs], wp, bp, 3, 3, (cout + 7) // 8 * 8, act=act)
+    d = (y.float() - k5.float()[..., :cout]).abs()
+    assert float(d.max()) <= 2 ** -8 * scale and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
+
+
 def test_conv_narrow_rejects_what_it_does_not_take(hip):
     dtype = torch.float16
     assert not hip.conv_narrow_supported(3, 3, 1, 16, 32, dtype) and not hip.conv_narrow_supported(3, 3, 2, 8, 32, dtype)
+    assert not hip.conv_narrow_supported(3, 3, 1, 128, 64, dtype) and not hip.conv_narrow_supported(3, 3, 1, 64, 32, dtype)
     assert not hip.conv_narrow_supported(5, 5, 2, 16, 32, dtype) and not hip.conv_narrow_supported(3, 3, 1, 8, 32, torch.float32)
     x = torch.randn(1, 8, 8, 8, device="cuda").half()
     wf = pack.pw_frag(torch.randn(32, 72, device="cuda").half())
-    with pytest.raises(ValueError, match="pack.pw_frag"):
+    with pytest.raises(ValueError, match="pack.narrow_frag"):
         hip.conv_narrow(x, wf, None, 3, 3, 64)                          # fragment tensor of another Cout
     with pytest.raises(RuntimeError, match="act"):
         hip.conv_narrow(x, wf, None, 3, 3, 32, act=hip.ACT_TANH)

@@ -87,13 +87,15 @@ def check_function(name: str, lines):
 def check_straight_line(name: str, lines, depth=None, min_mfma=16, exact=True):
     """feature_fusion_direct_kernel / conv_narrow_kernel: region = first MFMA .. last 16-byte global load of the kernel's instruction stream.
     depth: ring depth (default: parsed from FusionDirectCfg); exact: the counted waits inside the region are exactly {depth - 1}, else depth - 1
-    is the STRICTEST wait there (the compiler may add looser ones of its own for tracked loads)"""
+    is one of them (the unrolled tail of conv_narrow's rings counts down, and the compiler adds waits of its own for tracked loads)"""
     ins = [l.split(";")[0].strip() for l in lines if l.strip() and not l.strip().startswith((".", ";"))]
     mf = [i for i, l in enumerate(ins) if l.startswith("v_mfma")]
     ld = [i for i, l in enumerate(ins) if l.startswith("global_load_dwordx4")]
-    if len(mf) < min_mfma or not ld or ld[-1] < mf[0]:
+    if len(mf) < min_mfma or not ld or (ld[-1] < mf[0] and exact):
         return [f"{name}: no MFMA / fragment-load region found (the check no longer matches the generated code)"], 0
     lo, hi = mf[0], ld[-1]
+    if ld[-1] < mf[0]:                                            # a ring as deep as the whole K loop: every request precedes the first MFMA
+        lo, hi = ld[-1], mf[-1]
     # registers whose fragment request may still be in flight: set by a 16-byte load, cleared by the MFMA that consumes them (the allocator
     # moves a ring slot to other registers between refills, so the set is tracked instruction by instruction)
     flying = set()
@@ -101,6 +103,9 @@ def check_straight_line(name: str, lines, depth=None, min_mfma=16, exact=True):
     for idx, l in enumerate(ins[:hi + 1]):
         inside = idx >= lo
         m = re.search(r"s_waitcnt\b.*vmcnt\((\d+)\)", l)
+        if m and int(m.group(1)) == 0:
+            flying.clear()                                        # everything requested so far has landed (the drain after a K loop)
+            continue
         if m and inside:
             waits.add(int(m.group(1)))
         ops = [t.strip().rstrip(",") for t in l.split()[1:]]
@@ -133,8 +138,8 @@ def check_straight_line(name: str, lines, depth=None, min_mfma=16, exact=True):
         depth = int(m.group(4)) if m else 9
     if exact and waits != {depth - 1}:
         problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected exactly {depth - 1}: ring depth - 1)")
-    if not exact and (not waits or min(waits) != depth - 1):
-        problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected {depth - 1} = ring depth - 1 as the strictest)")
+    if not exact and depth - 1 not in waits:
+        problems.append(f"{name}: vmcnt waits inside the refill region are {sorted(waits)} (expected {depth - 1} = ring depth - 1 among them)")
     return problems, 1
 
 
@@ -251,6 +256,16 @@ def main() -> int:
         ns = (kh * kw * cin + 15) // 16
         problems, n = check_straight_line(name, lines, depth=min(ns * ntl, 8), min_mfma=ns * mt * ntl, exact=False)
         print(f"check_isa: conv_narrow_kernel<{kh}x{kw}, Cin {cin}, MT {mt}, NTL {ntl}>: {n} refill region(s), {len(problems)} problem(s)")
+        bad += problems
+    pfuncs = functions(ntext, "_ZN4s2m214conv_px_kernel")
+    if not pfuncs:
+        print("check_isa: no conv_px_kernel instantiation found in the assembly")
+        return 1
+    for name, lines in pfuncs.items():
+        m = re.search(r"PxCfgILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        ch, ntl, mt, nw = (int(g) for g in m.groups())
+        problems, n = check_straight_line(name, lines, depth=8, min_mfma=9 * (ch // 16) * ntl * mt, exact=False)
+        print(f"check_isa: conv_px_kernel<CH {ch}, NTL {ntl}, MT {mt}, NW {nw}>: {n} refill region(s), {len(problems)} problem(s)")
         bad += problems
     ffuncs = functions(ftext, "_ZN4s2m228feature_fusion_direct_kernel")
     if not ffuncs:
