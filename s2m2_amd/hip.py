@@ -531,7 +531,7 @@ def pw_direct(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], Cou
     d.rows, d.weight_frag, d.bias, d.out = rows, weight_frag.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr()
     d.Cout, d.act, d.dtype = Cout, act, _DT[x0.dtype]
     _check(load().s2m2_pw_direct(ctypes.byref(d), _stream()), "s2m2_pw_direct")
-    _meter("conv2d", 2.0 * rows * ((K + 15) // 16 * 16) * ((Cout + 31) // 32 * 32))
+    _meter("conv2d", 2.0 * rows * K * Cout)                          # (as K5 counts the same layer: no MFMA-tile padding)
     return out
 
 
@@ -568,7 +568,7 @@ def conv_narrow(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], K
     d.weight_frag, d.bias, d.out, d.out_stride = weight_frag.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), Cout
     d.Cout, d.KH, d.KW, d.stride, d.act, d.dtype = Cout, KH, KW, stride, act, _DT[x.dtype]
     _check(load().s2m2_conv_narrow(ctypes.byref(d), _stream()), "s2m2_conv_narrow")
-    _meter("conv2d", 2.0 * n * ho * wo * ((K + 15) // 16 * 16) * ((Cout + 31) // 32 * 32))
+    _meter("conv2d", 2.0 * n * ho * wo * K * Cout)                   # (as K5 counts the same layer: no MFMA-tile padding)
     return out
 
 
