@@ -41,6 +41,20 @@ lines = [f"bench.py line ({tag}/bench_N1.json): K1 avg {bench['roofline']['avg_l
 for r in k1:
     lines.append(f"rocprofv3 --kernel-trace --stats of the same command ({tag}/bench_c3_S_fp16_kernel_stats.csv): {r['Name'][:60]}... calls {r['Calls']} "
                  f"avg {float(r['AverageNs']) / 1e3:.2f} us min {float(r['MinNs']) / 1e3:.2f} max {float(r['MaxNs']) / 1e3:.2f}")
+# the stats average mixes the forward's launches with the back-to-back launches of the bench line's `both_variants` leg: split them by
+# what ran before (kernel trace of the same rocprofv3 run)
+trace = os.path.join(src, "prof_bench", "bench_kernel_trace.csv")
+if os.path.exists(trace):
+    tr = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+    infwd, b2b, prev = [], [], ""
+    for r in tr:
+        if "ln_corr" in r["Kernel_Name"]:
+            (b2b if "ln_corr" in prev else infwd).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        prev = r["Kernel_Name"]
+    if infwd:
+        lines.append(f"  same run, kernel trace: {len(infwd)} K1 launches INSIDE a forward (previous kernel is not K1) avg {sum(infwd) / len(infwd):.2f} us, "
+                     f"the last 20 (the timed steps) {sum(infwd[-20:]) / len(infwd[-20:]):.2f} us; {len(b2b)} back-to-back launches (both_variants leg) "
+                     f"avg {sum(b2b) / max(1, len(b2b)):.2f} us")
 lines.append(f"sum of all kernel durations in the rocprofv3 run: {tot / 1e6:.2f} ms")
 open(os.path.join(dst, "k1_bench_vs_rocprof.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
