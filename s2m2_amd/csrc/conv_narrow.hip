@@ -51,8 +51,7 @@ struct NarrowCfg {
     static constexpr int KH = KH_, KW = KW_, S = S_, CIN = CIN_, MT = MT_, NTL = NTL_;
     static constexpr int NW = 4, NT = 64 * NW;
     // NWN waves share a set of MT output rows and split the couts of a group (NWN * NTL tiles) between them: a wave's weight stream is then
-    // 1 / NWN of the layer's and feeds NWN times the pixel tiles -- the 5x5 layer (25 KB of fragments per cout tile) is bound by the
-    // L2 -> CU weight traffic, not by its LDS reads
+    // 1 / NWN of the layer's and feeds NWN times the pixel tiles (5x5 layer, 25 KB of fragments per cout tile: 67.1 -> 65.1 us)
     static constexpr int NWN = NWN_, NWM = NW / NWN_;
     static constexpr int PW = 32, PH = NWM * MT;                          // output patch
     static constexpr int HW = (PW - 1) * S + KW, HH = (PH - 1) * S + KH;  // input patch + halo
@@ -438,8 +437,9 @@ extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
     if (d->Cin == 48) return tall ? launch_px<48, 2, 2>(a, st) : launch_px<48, 2, 1>(a, st);
     // measured (profiles/r04/narrowbench.txt, narrowbench_variants.txt): 96 -> 96 with ONE cout tile per block (grid.y = 3) 27.2 us against 27.9 for
     // all three in one block; the 128- / 256-channel heads in chunks of 64 channels with 2 waves x 2 rows per block 22.7 / 12.5 us against
-    // 25.1 / 13.4 (4 waves x 1 row) and 27.4 / 14.3 (chunks of 128); 1-wave blocks 27 - 45 us.  Every wave streams the layer's whole weight
-    // set for its own 32 - 64 pixels: these launches are bound by that L2 -> CU traffic, not by MFMA or HBM.
+    // 25.1 / 13.4 (4 waves x 1 row) and 27.4 / 14.3 (chunks of 128); 1-wave blocks 27 - 45 us.  Counters (profiles/r04/narrow_pmc.txt): the
+    // TCP serves ~80 % of the fragment requests the waves of a block repeat; these launches are short chains of tile loads, barriers and K
+    // loops of 36 - 54 MFMAs on a chip their 640 blocks fill a quarter to a half -- not MFMA-, HBM- or L2-bound.
     if (d->Cin == 96) return launch_px<96, 1, 1>(a, st);
     if (d->Cin >= 128) return launch_px<64, 1, 2, 2>(a, st);
     if (d->Cin == 8) return tall ? launch_narrow<3, 3, 1, 8, 2, 1, 1>(a, st) : launch_narrow<3, 3, 1, 8, 1, 1, 1>(a, st);
