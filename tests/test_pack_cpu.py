@@ -80,3 +80,64 @@ def test_fusion_frag_stream_order():
     for t, s, step, lane in ((0, 0, 0, 0), (1, 1, 3, 40), (3, 2, 7, 63)):
         row, k = 32 * t + lane % 32, s * C + 16 * step + 8 * (lane // 32)
         assert torch.equal(f[t, s * per + 2 * C // 16 + step, lane], w2[row, k:k + 8])
+
+
+def test_pw_frag_layout_and_padding():
+    """pack.pw_frag (s2m2_pw_desc.weight_frag): 16-byte slot (t * steps + s) * 64 + l holds row 32 t + l % 32, columns 16 s + 8 (l // 32) .. + 7 of
+    the (Cout, K) matrix zero-padded to (32 * tiles, 16 * steps)"""
+    cout, k = 40, 72
+    w = torch.arange(cout * k, dtype=torch.float32).reshape(cout, k) + 1
+    f = pack.pw_frag(w)
+    assert tuple(f.shape) == (2, 5, 64, 8)
+    for t, s, l in ((0, 0, 0), (0, 4, 63), (1, 2, 7), (1, 4, 40), (0, 3, 32)):
+        row, col = 32 * t + l % 32, 16 * s + 8 * (l // 32)
+        want = torch.zeros(8)
+        if row < cout:
+            n = max(0, min(8, k - col))
+            want[:n] = w[row, col:col + n]
+        assert torch.equal(f[t, s, l], want), (t, s, l)
+    assert float(f.sum()) == float(w.sum())                                      # every weight once, zeros elsewhere
+
+
+def _conv_from_fragments(x, f, cout, ntap_w, cin, chunk):
+    """3x3 (or kxk) convolution evaluated the way conv_narrow.hip walks pack.narrow_frag: K index of slot (tile, kstep, lane, e) =
+    16 kstep + 8 (lane // 32) + e, read as (chunk, tap, channel within the chunk) for Cin >= 128 and as (tap, channel) below."""
+    n, h, wd, _ = x.shape
+    kk = ntap_w * ntap_w
+    xp = torch.nn.functional.pad(x, (0, 0, ntap_w // 2, ntap_w // 2, ntap_w // 2, ntap_w // 2))
+    out = torch.zeros(n, h, wd, cout, dtype=torch.float64)
+    tiles, steps = f.shape[:2]
+    for t in range(tiles):
+        for s in range(steps):
+            for half in range(2):
+                k0 = 16 * s + 8 * half
+                for e in range(8):
+                    k = k0 + e
+                    if k >= kk * cin:
+                        continue
+                    if chunk:
+                        c, rem = divmod(k, kk * chunk)
+                        tap, ch = divmod(rem, chunk)
+                        ch += c * chunk
+                    else:
+                        tap, ch = divmod(k, cin)
+                    ky, kx = divmod(tap, ntap_w)
+                    wv = f[t, s, half * 32:half * 32 + 32, e].double()          # 32 couts of this tile
+                    co = min(32, cout - 32 * t)
+                    if co > 0:
+                        out[..., 32 * t:32 * t + co] += xp[:, ky:ky + h, kx:kx + wd, ch, None].double() * wv[:co]
+    return out
+
+
+def test_narrow_frag_walked_like_the_kernel_is_the_convolution():
+    """pack.narrow_frag against F.conv2d: natural K order below 128 input channels, chunk-major (64 channels) from 128 on (include/s2m2_hip.h, K12)"""
+    torch.manual_seed(3)
+    for cin, cout, k in ((8, 40, 3), (16, 64, 5), (48, 48, 3), (128, 8, 3), (256, 16, 3)):
+        w = torch.randn(cout, cin, k, k)
+        x = torch.randn(1, 5, 6, cin)
+        wp = pack.pack_conv(w, torch.float32, [(cin, cin)])
+        f = pack.narrow_frag(wp, k * k)
+        assert tuple(f.shape) == ((wp.shape[0] + 31) // 32, (k * k * cin + 15) // 16, 64, 8)
+        got = _conv_from_fragments(x, f, cout, k, cin, 64 if cin >= 128 else 0)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=k // 2).permute(0, 2, 3, 1)
+        assert float((got - ref).abs().max()) < 1e-9, (cin, cout, k)
