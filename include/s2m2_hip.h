@@ -322,6 +322,15 @@ typedef struct s2m2_narrow_desc {
     int Cout, KH, KW, stride;
     int act;
     int dtype;
+    /* fused 1x1 head (Cin = 48 form only; UpsampleMask1x conv_concat.0 -> ReLU -> conv_concat.2, submodules.py:133-137,143-144):
+       head_cout > 0 (act NONE or RELU): out holds  W2 . act(conv3x3(x) + bias) + head_bias  with head_cout (multiple of 8, <= 32) channels instead of the Cout
+       channels of the 3x3 layer, which are rounded to fp16 as a store would round them and never leave the registers.  head_frag: the
+       (head_cout, Cout) matrix W2, rows zero-padded to 32, K columns zero-padded to 32-channel tiles and ordered to match the accumulator layout
+       of the 3x3 layer: k16 step (j, p), j = channel / 32, p < 2; 16-byte slot ((j * 2 + p) * 64 + l) holds row l % 32 and the channels
+       32 j + 8 (2 p + q) + 4 (l / 32) + e for q = 0, 1 and e = 0 .. 3, in that order (pack.head_frag). */
+    const void* head_frag;
+    const float* head_bias;
+    int head_cout;
 } s2m2_narrow_desc;
 int s2m2_conv_narrow_supported(int KH, int KW, int stride, int Cin, int Cout, int dtype);
 int s2m2_conv_narrow(const s2m2_narrow_desc* desc, void* stream);

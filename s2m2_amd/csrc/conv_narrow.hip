@@ -24,6 +24,11 @@
 // CH = 48 / 96 / 64 channels (row stride CH + 8 halfs), the K loop of a chunk = 9 taps x CH / 16 steps x NTL fragments through the same
 // register ring; further chunks (Cin = 128 / 256: 2 / 4 of 64 channels) re-load the tile behind a block barrier.  Fragment order per cout
 // tile: (chunk, tap, k16 step) = the K order 0 of K5 for one chunk, columns permuted chunk-major for several (pack.narrow_frag).
+// Fused 1x1 head (UpsampleMask1x: conv_concat.0 -> ReLU -> conv_concat.2, ConvTranspose2d(48 -> 9, k 1), submodules.py:133-137,143-144): in the
+// accumulator layout of D[cout][pixel], lane (pixel l % 32, half l / 32) of cout tile j holds channels 32 j + 8 g + 4 (l / 32) + e, g < 4, e < 4 --
+// for g = 2p, 2p + 1 that IS an MFMA pixel fragment of the 1x1 layer, provided that layer's K columns are packed in the same order (pack.head_frag:
+// k16 step (j, p), lane half, then (g parity, e)).  So the activated, fp16-rounded outputs of the 3x3 layer feed the head's MFMAs straight from
+// registers: the 48-channel tensor is never written, the head is three more MFMAs per 32 pixels.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -44,6 +49,9 @@ struct NarrowArgs {
     void* out;
     long long out_stride;
     int Cout, act;
+    const void* w2;                     // conv_px_kernel, fused 1x1 head: fragments of the (Cout2, Cout) matrix in accumulator order (pack.head_frag)
+    const float* bias2;
+    int Cout2;                          // 0: no head, out holds the Cout channels of the 3x3 layer; > 0: out holds the Cout2 channels of the head
 };
 
 template <int KH_, int KW_, int S_, int CIN_, int MT_, int NTL_, int NWN_ = 1>
@@ -239,6 +247,9 @@ struct PxCfg {
     struct Stage {
         static constexpr int MT = SM, NTL = NTL_, WM = 32 * SM, WN = 32 * NTL_, CRS = WN + 8;
     };
+    struct Stage2 {                                                       // the fused 1x1 head's tile: 32 couts per pixel
+        static constexpr int MT = SM, NTL = 1, WM = 32 * SM, WN = 32, CRS = 40;
+    };
     static constexpr int WN = Stage::WN, CRS = Stage::CRS, CPR = WN / 8, C_IT = Stage::WM * CPR / 64;
     static constexpr size_t A_BYTES = (size_t)HW * HH * RS * sizeof(half_t);
     static constexpr size_t STG_BYTES = (size_t)NW * Stage::WM * CRS * sizeof(half_t);
@@ -246,7 +257,7 @@ struct PxCfg {
     static_assert(CH % 16 == 0 && (Stage::WM * CPR) % 64 == 0 && MT % SM == 0 && LDS_BYTES <= 80 * 1024, "unsupported pixel-split tile");
 };
 
-template <typename CFG>
+template <typename CFG, bool HEAD = false>
 __global__ __launch_bounds__(CFG::NT) void conv_px_kernel(NarrowArgs p, int tiles_x, int tiles_y) {
     using T = half_t;
     constexpr int MT = CFG::MT, NTL = CFG::NTL, KS = CFG::KS, HW = CFG::HW, RS = CFG::RS, CRS = CFG::CRS, D = CFG::D, NF = CFG::NF;
@@ -332,6 +343,63 @@ __global__ __launch_bounds__(CFG::NT) void conv_px_kernel(NarrowArgs p, int tile
     // ---- epilogue per wave (wave-private staging tile, as above)
     using STG = typename CFG::Stage;
     T* outp = static_cast<T*>(p.out);
+    if constexpr (HEAD) {
+        // fused 1x1 head: activation of the 3x3 layer in registers, rounded to fp16 where the unfused pair of launches rounds it (its store),
+        // then D2[cout2][pixel] += W2 fragment (j, p) . {quads 2p, 2p + 1 of cout tile j}: the accumulator layout is the operand layout
+        using Stage2 = typename CFG::Stage2;
+        constexpr int KS2 = NTL * 2;                                // k16 steps of the head (zero weights beyond Cout)
+        const raw16_t* w2q = static_cast<const raw16_t*>(p.w2) + lane;
+        Frag<T> w2f[KS2];
+#pragma unroll
+        for (int s2 = 0; s2 < KS2; ++s2) w2f[s2].v = __builtin_bit_cast(half8_t, global_load16(w2q + s2 * 64));
+        CoutRegs<Stage2> bias2;
+        bias2.load(p.bias2, p.zero, p.Cout2, 0, 0, lane);
+        const bool relu = p.act == S2M2_ACT_RELU;
+#pragma unroll
+        for (int h = 0; h < MT / CFG::SM; ++h) {
+            float16_t acc2[CFG::SM][1];
+#pragma unroll
+            for (int i = 0; i < CFG::SM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][0][r] = 0.f;
+#pragma unroll
+                for (int j = 0; j < NTL; ++j)
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        Frag<T> yf;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int g = 2 * pp + q;
+                            const raw16_t bv = bias.v[j][g];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a = acc[h * CFG::SM + i][j][4 * g + e] + bv[e];
+                                yf.v[4 * q + e] = (half_t)(relu ? fmaxf(a, 0.f) : a);       // (NONE / RELU only: checked by the host entry)
+                            }
+                        }
+                        mma32(acc2[i][0], w2f[2 * j + pp], yf);
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            stage_tile<Stage2, T, S2M2_ACT_NONE>(acc2, stg, bias2, 1.0f, 0, 0, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr int CPR2 = 4, C_IT2 = Stage2::WM * CPR2 / 64;  // 32 staged couts = 4 pieces per pixel
+#pragma unroll
+            for (int it = 0; it < C_IT2; ++it) {
+                const int q = lane + 64 * it, row = q / CPR2, pc = q - row * CPR2;
+                const int i = h * CFG::SM + (row >> 5), px = row & 31;
+                const int oy = oy0 + wv * MT + i, ox = ox0 + px, co = pc * 8;
+                if (oy < p.Ho && ox < p.Wo && co < p.Cout2) {
+                    const raw16_t v = *reinterpret_cast<const raw16_t*>(stg + (size_t)row * Stage2::CRS + pc * 8);
+                    *reinterpret_cast<raw16_t*>(outp + (((long long)n * p.Ho + oy) * p.Wo + ox) * p.out_stride + co) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < MT / CFG::SM; ++h) {
         const float16_t (&sub)[CFG::SM][NTL] = *reinterpret_cast<const float16_t (*)[CFG::SM][NTL]>(&acc[h * CFG::SM]);
@@ -358,10 +426,10 @@ __global__ __launch_bounds__(CFG::NT) void conv_px_kernel(NarrowArgs p, int tile
     }
 }
 
-template <int CH, int NTL, int MT, int NW = 4>
+template <int CH, int NTL, int MT, int NW = 4, bool HEAD = false>
 static int launch_px(const NarrowArgs& a, hipStream_t st) {
     using CFG = PxCfg<CH, NTL, MT, NW>;
-    auto kern = conv_px_kernel<CFG>;
+    auto kern = conv_px_kernel<CFG, HEAD>;
     static size_t lds_granted[kMaxDevices] = {};
     if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "conv_narrow")) return 1;
     const int tx = (a.Wo + CFG::PW - 1) / CFG::PW, ty = (a.Ho + CFG::PH - 1) / CFG::PH;
@@ -417,7 +485,10 @@ extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
     S2M2_REQUIRE(s2m2_conv_narrow_supported(d->KH, d->KW, d->stride, d->Cin, d->Cout, d->dtype),
                  "conv_narrow: %dx%d stride %d Cin=%d Cout=%d dtype=%d is not supported (ask s2m2_conv_narrow_supported)", d->KH, d->KW, d->stride,
                  d->Cin, d->Cout, d->dtype);
-    S2M2_REQUIRE(d->x_stride >= d->Cin - d->Cin1 && d->x_stride % 8 == 0 && d->out_stride >= d->Cout && d->out_stride % 8 == 0,
+    S2M2_REQUIRE(d->head_cout >= 0 && (d->head_cout == 0 || (d->Cin == 48 && d->head_frag && d->head_cout % 8 == 0 && d->head_cout <= 32)),
+                 "conv_narrow: the fused 1x1 head (head_cout=%d) exists for the 48-channel form, with a fragment tensor and at most 32 output channels", d->head_cout);
+    S2M2_REQUIRE(d->head_cout == 0 || d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_RELU, "conv_narrow: the fused 1x1 head takes act NONE or RELU (act=%d)", d->act);
+    S2M2_REQUIRE(d->x_stride >= d->Cin - d->Cin1 && d->x_stride % 8 == 0 && d->out_stride >= (d->head_cout ? d->head_cout : d->Cout) && d->out_stride % 8 == 0,
                  "conv_narrow: x_stride=%lld / out_stride=%lld must cover the channels and be multiples of 8", d->x_stride, d->out_stride);
     S2M2_REQUIRE(d->act == S2M2_ACT_NONE || d->act == S2M2_ACT_GELU || d->act == S2M2_ACT_RELU, "conv_narrow: act=%d (NONE, GELU or RELU)", d->act);
     S2M2_REQUIRE(d->Cin1 >= 0 && d->Cin1 < d->Cin && d->Cin1 % 8 == 0 && (d->Cin1 == 0 || (d->x1 && d->x1_stride >= d->Cin1 && d->x1_stride % 8 == 0)),
@@ -430,10 +501,12 @@ extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
     a.nchunk = d->Cin >= 128 ? d->Cin / 64 : 1;
     a.Ho = (d->H + d->stride - 1) / d->stride; a.Wo = (d->W + d->stride - 1) / d->stride;
     a.w = d->weight_frag; a.bias = d->bias; a.out = d->out; a.out_stride = d->out_stride; a.Cout = d->Cout; a.act = d->act;
+    a.w2 = d->head_frag; a.bias2 = d->head_bias; a.Cout2 = d->head_cout;
     a.zero = zero_page();
     S2M2_REQUIRE(a.zero, "conv_narrow: cannot allocate the zero page");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool tall = narrow_tall(a);
+    if (d->Cin == 48 && a.Cout2) return tall ? launch_px<48, 2, 2, 4, true>(a, st) : launch_px<48, 2, 1, 4, true>(a, st);
     if (d->Cin == 48) return tall ? launch_px<48, 2, 2>(a, st) : launch_px<48, 2, 1>(a, st);
     // measured (profiles/r04/narrowbench.txt, narrowbench_variants.txt): 96 -> 96 with ONE cout tile per block (grid.y = 3) 27.2 us against 27.9 for
     // all three in one block; the 128- / 256-channel heads in chunks of 64 channels with 2 waves x 2 rows per block 22.7 / 12.5 us against

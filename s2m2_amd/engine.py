@@ -108,6 +108,8 @@ class Engine:
         # S2M2_K12=0: the narrow-input / few-cout 3x3 and 5x5 layers on K5's LDS-staged tiles instead of the pixel-split direct form
         # (A/B switch: profiles/r04/ab_conv_narrow.txt)
         self.use_k12 = os.environ.get("S2M2_K12", "1") != "0"
+        # S2M2_K12_HEAD=0: UpsampleMask1x's conv_concat.0 and conv_concat.2 as two launches (K12 + K11) instead of the fused head
+        self.use_k12_head = self.use_k12 and os.environ.get("S2M2_K12_HEAD", "1") != "0"
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -582,8 +584,19 @@ class Engine:
                         [rgb8], act=hip.ACT_RELU)
         sc, cc = self.convT2(p + ".conv_ctx")
         c = self.cconv(sc, [f2x], shuffle2=cc)
-        y = self.cconv(self.std(p + ".conv_concat.0"), [ab, c], act=hip.ACT_RELU)
-        return self.cconv(self.std(p + ".conv_concat.2", transposed=True), [y])
+        s0, s2 = self.std(p + ".conv_concat.0"), self.std(p + ".conv_concat.2", transposed=True)
+        cin = ab.shape[-1] + c.shape[-1]
+        if (self.use_k12_head and cin == 48 and s0[2] == 3 and s0[3] == 3 and not getattr(s0, "korder", 0) and s2[2] == 1 and s2[3] == 1
+                and tuple(s0[0].shape) == (s0[4], 9 * cin) and tuple(s2[0].shape) == (s2[4], s0[4]) and s2[4] <= 32
+                and self.narrow_ok(3, 3, 1, cin, s0[4])):
+            # conv_concat.0 -> ReLU -> conv_concat.2 (1x1) as ONE K12 launch: the head's MFMAs read the 3x3 layer's accumulators as they are
+            # (pack.head_frag); the 48-channel full-resolution tensor is never written
+            hf = self._wfrag.get(("head", s2[0].data_ptr()))
+            if hf is None:
+                hf = self._wfrag[("head", s2[0].data_ptr())] = pack.head_frag(s2[0])
+            return hip.conv_narrow([ab, c], self.wnarrow(s0, 9), s0[1], 3, 3, s0[4], act=hip.ACT_RELU, head=(hf, s2[1], s2[4]))
+        y = self.cconv(s0, [ab, c], act=hip.ACT_RELU)
+        return self.cconv(s2, [y])
 
     # ---- whole forward, in three stages (bench.py brackets the middle one, K1, with HIP events) ----------
     @torch.no_grad()

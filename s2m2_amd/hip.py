@@ -55,7 +55,7 @@ class NarrowDesc(ctypes.Structure):
     """mirror of s2m2_narrow_desc (include/s2m2_hip.h)"""
     _fields_ = [("x", _vp), ("x_stride", _ll), ("N", _i), ("H", _i), ("W", _i), ("Cin", _i), ("x1", _vp), ("x1_stride", _ll), ("Cin1", _i),
                 ("weight_frag", _vp), ("bias", _vp), ("out", _vp), ("out_stride", _ll), ("Cout", _i), ("KH", _i), ("KW", _i), ("stride", _i),
-                ("act", _i), ("dtype", _i)]
+                ("act", _i), ("dtype", _i), ("head_frag", _vp), ("head_bias", _vp), ("head_cout", _i)]
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
@@ -541,10 +541,12 @@ def conv_narrow_supported(KH: int, KW: int, stride: int, Cin: int, Cout: int, dt
 
 
 def conv_narrow(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW: int, Cout: int, stride: int = 1,
-                act: int = ACT_NONE) -> torch.Tensor:
+                act: int = ACT_NONE, head=None) -> torch.Tensor:
     """K12: a KH x KW convolution (padding K // 2) in the pixel-split direct form on one (N,H,W,Cin) tensor -- or the channel concatenation
     of two -- weight = pack.narrow_frag of the K-order-0 matrix (Cout, KH*KW*Cin), fp32 bias (Cout) or None
-    -> (N, ceil(H/stride), ceil(W/stride), Cout).  Shapes: conv_narrow_supported."""
+    -> (N, ceil(H/stride), ceil(W/stride), Cout).  Shapes: conv_narrow_supported.
+    head = (pack.head_frag of a (Cout2, Cout) 1x1 weight, fp32 bias (Cout2) or None, Cout2): that 1x1 layer applied to the activated output
+    inside the same launch (Cin = 48 form) -> (..., Cout2); the Cout-channel tensor is not produced."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     if not 1 <= len(srcs) <= 2 or any(t.shape[:3] != srcs[0].shape[:3] or t.dtype != srcs[0].dtype for t in srcs):
@@ -560,15 +562,24 @@ def conv_narrow(srcs, weight_frag: torch.Tensor, bias: Optional[torch.Tensor], K
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() < Cout or not bias.is_cuda):
         raise ValueError(f"conv_narrow: bias must be fp32 ({Cout}) on the device")
     ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
-    out = torch.empty((n, ho, wo, Cout), device=x.device, dtype=x.dtype)
+    cout_final = Cout
+    if head is not None:
+        hf, hb, cout_final = head
+        if hf.dtype != x.dtype or not hf.is_cuda or not hf.is_contiguous() or tuple(hf.shape) != (1, 2 * ((Cout + 31) // 32), 64, 8):
+            raise ValueError(f"conv_narrow: head weight must be pack.head_frag of a (Cout2, {Cout}) matrix, got {tuple(hf.shape)} {hf.dtype}")
+        if hb is not None and (hb.dtype != torch.float32 or hb.numel() < cout_final or not hb.is_cuda):
+            raise ValueError(f"conv_narrow: head bias must be fp32 ({cout_final}) on the device")
+    out = torch.empty((n, ho, wo, cout_final), device=x.device, dtype=x.dtype)
     d = NarrowDesc()
+    if head is not None:
+        d.head_frag, d.head_bias, d.head_cout = hf.data_ptr(), hb.data_ptr() if hb is not None else None, cout_final
     d.x, d.x_stride, d.N, d.H, d.W, d.Cin = x.data_ptr(), xs, n, h, w, cin
     if len(srcs) == 2:
         d.x1, d.x1_stride, d.Cin1 = srcs[1].data_ptr(), _nhwc(srcs[1]), srcs[1].shape[-1]
-    d.weight_frag, d.bias, d.out, d.out_stride = weight_frag.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), Cout
+    d.weight_frag, d.bias, d.out, d.out_stride = weight_frag.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), cout_final
     d.Cout, d.KH, d.KW, d.stride, d.act, d.dtype = Cout, KH, KW, stride, act, _DT[x.dtype]
     _check(load().s2m2_conv_narrow(ctypes.byref(d), _stream()), "s2m2_conv_narrow")
-    _meter("conv2d", 2.0 * n * ho * wo * K * Cout)                   # (as K5 counts the same layer: no MFMA-tile padding)
+    _meter("conv2d", 2.0 * n * ho * wo * (K * Cout + (Cout * cout_final if head is not None else 0)))   # (as K5 counts the same layers: no MFMA-tile padding)
     return out
 
 

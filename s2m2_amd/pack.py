@@ -122,6 +122,20 @@ def narrow_frag(wp: torch.Tensor, ntap: int) -> torch.Tensor:
     return pw_frag(wp)
 
 
+def head_frag(w2: torch.Tensor) -> torch.Tensor:
+    """packed 1x1 weight (Cout2 <= 32, K) of a layer fused behind a K12 3x3 layer (s2m2_narrow_desc.head_frag) -> (1, 2 * ceil(K / 32), 64, 8):
+    k16 step (j, p), lane l = 32 * half + row, element 4 q + e holds W2[row, 32 j + 8 (2 p + q) + 4 half + e] -- the channels lane (pixel, half)
+    of the 3x3 layer's accumulator tile j holds in its quads 2 p and 2 p + 1 (D[cout][pixel] of the 32x32 MFMA), so those registers are the
+    head's pixel fragments as they are."""
+    r, k = w2.shape
+    assert r <= 32, r
+    nj = (k + 31) // 32
+    full = w2.new_zeros((32, nj * 32))
+    full[:r, :k] = w2
+    t = full.reshape(32, nj, 2, 2, 2, 4)                          # row, j, p, q, half, e   (channel = 32 j + 8 (2 p + q) + 4 half + e)
+    return t.permute(1, 2, 4, 0, 3, 5).reshape(1, nj * 2, 64, 8).contiguous()   # (j, p), half, row, (q, e)
+
+
 def _frag_rows(w: torch.Tensor) -> torch.Tensor:
     """(R, K) -> (R/32, K/16, 64, 8): per 32-row tile and k16 step the MFMA A-fragment (lane l: row 32t + l % 32, k 16*step + 8*(l // 32) + e)"""
     R, K = w.shape

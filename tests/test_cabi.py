@@ -123,6 +123,8 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"out_stride" in lib.s2m2_last_error()          # narrower than Cout
     nd.out_stride, nd.act = 32, hip.ACT_TANH
     assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"act=" in lib.s2m2_last_error()
+    nd.act, nd.head_cout, nd.head_frag = hip.ACT_RELU, 16, 4096                                                  # the fused head: 48-channel form only
+    assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"fused 1x1 head" in lib.s2m2_last_error()
     assert lib.s2m2_feature_fusion_supported(128, hip.F16) == 1 and lib.s2m2_feature_fusion_supported(384, hip.F16) == 0
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 64, 192, 4096, 4096, 4096, 4096, 4096, 0, 0, hip.F16, None) != 0
     assert b"not supported" in lib.s2m2_last_error()

@@ -103,6 +103,38 @@ def test_conv_px_vs_torch_and_k5(hip, cs, cout, act, shp, has_bias):
     assert float(d.max()) <= 2 ** -8 * scale and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
 
 
+@pytest.mark.parametrize("shp", [(1, 64, 96), (2, 37, 45), (1, 520, 544)])
+def test_conv_px_fused_head_vs_two_launches_and_torch(hip, shp):
+    """UpsampleMask1x conv_concat.0 -> ReLU -> conv_concat.2 (1x1, 48 -> 9 padded to 16) as ONE K12 launch (head=...): equal to the K12 launch
+    followed by the K11 launch up to the fp32 summation order inside a k16 step (single fp16 ulps), and to fp32 math on the fp16 operands with the
+    intermediate rounded to fp16 where the two-launch path stores it."""
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(7 + shp[1])
+    a = (torch.randn(*shp, 32, device="cuda", generator=g) * 1.1).to(dtype)
+    b = (torch.randn(*shp, 16, device="cuda", generator=g) * 0.9 + 0.2).to(dtype)
+    w0 = (torch.randn(48, 48, 3, 3, device="cuda", generator=g) / math.sqrt(48 * 9)).to(dtype)
+    b0 = torch.randn(48, device="cuda", generator=g) * 0.3
+    w2 = (torch.randn(9, 48, 1, 1, device="cuda", generator=g) / math.sqrt(48)).to(dtype)
+    b2 = torch.randn(9, device="cuda", generator=g) * 0.2
+    wp0, bp0 = pack.pack_conv(w0, dtype, [(32, 32), (16, 16)]), pack.pack_bias(b0, 48)
+    wp2, bp2 = pack.pack_conv(w2, dtype), pack.pack_bias(b2, 9)              # (16, 48): Cout 9 padded to 16
+    assert tuple(wp2.shape) == (16, 48)
+    wf0 = pack.narrow_frag(wp0, 9)
+    y = hip.conv_narrow([a, b], wf0, bp0, 3, 3, 48, act=hip.ACT_RELU)
+    two = hip.pw_direct([y], pack.pw_frag(wp2), bp2, 16)
+    for _ in range(3):
+        one = hip.conv_narrow([a, b], wf0, bp0, 3, 3, 48, act=hip.ACT_RELU, head=(pack.head_frag(wp2), bp2, 16))
+        assert tuple(one.shape) == (*shp, 16) and one.dtype == dtype
+        d = (one.float() - two.float()).abs()
+        scale = max(1.0, float(two.float().abs().max()))
+        assert float(d.max()) <= 2 ** -8 * scale and float((d > 0).float().mean()) < 0.02, (float(d.max()), float((d > 0).float().mean()))
+    x = torch.cat([a, b], -1).float().permute(0, 3, 1, 2)
+    mid = F.relu(F.conv2d(x, w0.float(), b0, padding=1)).half().float()
+    ref = F.conv2d(mid, w2.float(), b2).permute(0, 2, 3, 1)
+    assert float((one.float()[..., :9] - ref).abs().max()) < 2 ** -8 * scale
+    assert bool((one[..., 9:] == 0).all())                                    # padding channels of the head: zero weight rows, zero bias
+
+
 def test_conv_narrow_rejects_what_it_does_not_take(hip):
     dtype = torch.float16
     assert not hip.conv_narrow_supported(3, 3, 1, 16, 32, dtype) and not hip.conv_narrow_supported(3, 3, 2, 8, 32, dtype)

@@ -141,3 +141,25 @@ def test_narrow_frag_walked_like_the_kernel_is_the_convolution():
         got = _conv_from_fragments(x, f, cout, k, cin, 64 if cin >= 128 else 0)
         ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=k // 2).permute(0, 2, 3, 1)
         assert float((got - ref).abs().max()) < 1e-9, (cin, cout, k)
+
+
+def test_head_frag_matches_the_accumulator_layout_of_a_32x32_mfma():
+    """pack.head_frag (s2m2_narrow_desc.head_frag): the 1x1 head's K order is the order in which lane (pixel, half) of the 3x3 layer's accumulator
+    tile j holds its channels -- 32 j + 8 g + 4 half + e in quad g -- so quads 2p, 2p + 1 are the head's pixel fragment of k16 step (j, p).  Emulates
+    D2[m][pixel] = sum_k A[m][k] B[k][pixel] with A lane (m, half) element e8 <-> k = 8 half + e8 on both operands."""
+    torch.manual_seed(0)
+    cout2, k = 16, 48
+    w2 = torch.randn(cout2, k)
+    hf = pack.head_frag(w2)
+    assert tuple(hf.shape) == (1, 4, 64, 8)
+    y = torch.randn(32, 64)
+    y[:, k:] = 0                                                              # channels beyond Cout: relu(0 + 0)
+    d2 = torch.zeros(32, 32)
+    for j in range(2):
+        for p in range(2):
+            for half in range(2):
+                for e8 in range(8):
+                    q, e = divmod(e8, 4)
+                    ch = 32 * j + 8 * (2 * p + q) + 4 * half + e              # what lane (pixel, half) holds in quad 2p + q, element e
+                    d2 += hf[0, 2 * j + p, 32 * half:32 * half + 32, e8][:, None] * y[:, ch][None, :]
+    assert float((d2[:cout2] - w2 @ y[:, :k].T).abs().max()) < 1e-5 and float(d2[cout2:].abs().max()) == 0
