@@ -153,3 +153,29 @@ def test_attention_planning_query_runs_without_a_device(lib):
     check_limits(2048, 2432, 384, 1, F32)
     with pytest.raises(ValueError, match="token grid"):
         check_limits(1600, 3200, 128, 1, F16)
+
+
+def test_descriptor_structs_have_the_layout_of_the_header(tmp_path):
+    """the ctypes mirrors of the descriptor structs (s2m2_amd/hip.py) against include/s2m2_hip.h compiled by gcc: sizes and the offsets of the
+    last fields -- a field added to one side only shifts everything behind it"""
+    import ctypes
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [("s2m2_conv_desc", hip.ConvDesc), ("s2m2_chain_desc", hip.ChainDesc), ("s2m2_pw_desc", hip.PwDesc), ("s2m2_narrow_desc", hip.NarrowDesc)]
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "s2m2_hip.h"', "int main(void) {"]
+    for cname, py in pairs:
+        last = py._fields_[-1][0]
+        lines.append(f'  printf("{cname} %zu %zu\\n", sizeof({cname}), offsetof({cname}, {last}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    for (cname, py), line in zip(pairs, out):
+        name, size, off = line.split()
+        assert name == cname and int(size) == ctypes.sizeof(py), (cname, size, ctypes.sizeof(py))
+        assert int(off) == getattr(py, py._fields_[-1][0]).offset, (cname, off)
