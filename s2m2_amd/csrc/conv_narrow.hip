@@ -28,7 +28,7 @@
 // accumulator layout of D[cout][pixel], lane (pixel l % 32, half l / 32) of cout tile j holds channels 32 j + 8 g + 4 (l / 32) + e, g < 4, e < 4 --
 // for g = 2p, 2p + 1 that IS an MFMA pixel fragment of the 1x1 layer, provided that layer's K columns are packed in the same order (pack.head_frag:
 // k16 step (j, p), lane half, then (g parity, e)).  So the activated, fp16-rounded outputs of the 3x3 layer feed the head's MFMAs straight from
-// registers: the 48-channel tensor is never written, the head is three more MFMAs per 32 pixels.
+// registers: the 48-channel tensor is never written, the head is four more MFMAs per 32 pixels (the fourth on the zero padding of cout tile 1).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
