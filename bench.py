@@ -145,6 +145,150 @@ def cpu_baseline(model_type, H, W, refine_iter):
                       f"1 warm-up, 1 run per thread count, median of 3 at the best count"}
 
 
+def k1_algorithmic(h, w, C, e, B=1):
+    """read both feature maps once + write the volume once (bytes), 2*h*w*w*C flops"""
+    return B * (2 * h * w * C * e + h * w * w * e), 2.0 * B * h * w * w * C
+
+
+def attention_and_work(eng, left, right, use_fp16, B, ms_per_pair):
+    """One instrumented EAGER forward (outside every timed region): the work meter of the binding (2 flops per multiply-accumulate of every
+    GEMM-shaped launch) and HIP events around every K4 launch -> (roofline_attention, forward) blocks of the JSON line."""
+    import torch
+    from s2m2_amd import hip
+    saved = eng.k1_events
+    eng.k1_events = None
+    hip.METER, hip.ATTN_EVENTS = {}, []
+    with torch.autocast("cuda", enabled=False):
+        eng.run(left, right, None)
+    torch.cuda.synchronize()
+    meter, attn_ev = hip.METER, hip.ATTN_EVENTS
+    hip.METER = hip.ATTN_EVENTS = None
+    eng.k1_events = saved
+    peak_tf = MFMA_F16_PEAK_TFLOPS if use_fp16 else MFMA_F32_PEAK_TFLOPS
+    a_us = sum(1e3 * s.elapsed_time(e_) for s, e_, _, _ in attn_ev)
+    a_fl = sum(f for _, _, f, _ in attn_ev)
+    by_shape = {}
+    for s, e_, f, tag in attn_ev:
+        d = by_shape.setdefault(tag, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += 1e3 * s.elapsed_time(e_)
+        d[2] += f
+    fwd_flops = sum(v[0] for v in meter.values()) / B
+    attn = {"kernel": "attention_kernel (K4: every QK^T / PV contraction of a forward)", "bound": "mfma",
+            "achieved": a_fl / (a_us * 1e-6) / 1e12 if a_us > 0 else 0.0, "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": (a_fl / (a_us * 1e-6) / 1e12 / peak_tf) if a_us > 0 else 0.0,
+            "flops_per_forward": a_fl, "us_per_forward": a_us, "launches": len(attn_ev),
+            "how": "HIP events around each K4 launch in one eager forward after the timed region (adds ~2 us of dispatch per launch)",
+            "by_shape(batch,heads,N,d)": {k: {"launches": v[0], "us": round(v[1], 1), "tflops": round(v[2] / (v[1] * 1e-6) / 1e12, 1)}
+                                          for k, v in by_shape.items()}}
+    fwd = {"flops_per_pair_executed": fwd_flops, "achieved_tflops": fwd_flops / (ms_per_pair * 1e-3) / 1e12,
+           "frac_of_mfma_peak": fwd_flops / (ms_per_pair * 1e-3) / 1e12 / peak_tf,
+           "flops_by_family": {k: v[0] / B for k, v in meter.items()}, "launches_by_family": {k: v[1] for k, v in meter.items()},
+           "note": "2 flops per multiply-accumulate of every GEMM-shaped launch, padded channel counts; per GPU"}
+    return attn, fwd
+
+
+def secondary_config(tag, model_type, H, W, positivity, dev, use_fp16, refine_iter, steps, warmup=2, detail=True):
+    """Another BASELINE.json configuration (c4: L 1216x1024 -- "stresses MFMA attn-aggregation path"; c5: XL 2432x2048 allow_negative; M) on
+    rank 0's GPU after the headline's timed region, one pair per step through the same drop-in module: hipGraph replay cut around K1, whose
+    dispatches carry start / stop HIP events; then one instrumented eager forward for the attention / whole-forward MFMA fractions.  Not
+    part of `value`.  The model is freed afterwards."""
+    import torch
+    from s2m2_amd.model import build_model
+    from s2m2_amd.weights import noise_pair
+    t_build = time.perf_counter()
+    model = build_model(model_type, use_positivity=positivity, refine_iter=refine_iter).to(dev).eval()
+    left, right = (t.to(dev) for t in noise_pair(H, W, 1, seed=3))
+    eng = model.engine(torch.float16 if use_fp16 else torch.float32)
+    eng.k1_events = []
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+            return model(left, right)
+
+    for _ in range(max(warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    eng.k1_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k1_us = [t.elapsed_us() for t in eng.k1_events]
+    finite = bool(all(torch.isfinite(o).all() for o in out))
+    h, w, C = H // 4, W // 4, model.feature_channels
+    k1_bytes, k1_flops = k1_algorithmic(h, w, C, 2 if use_fp16 else 4)
+    us = sum(k1_us) / max(1, len(k1_us))
+    gbs = k1_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    peak_tf = MFMA_F16_PEAK_TFLOPS if use_fp16 else MFMA_F32_PEAK_TFLOPS
+    ms_pair = 1e3 * dt / steps
+    res = {"config": tag, "workload": f"{model_type}-model {W}x{H} refine_iter={refine_iter} use_positivity={positivity}, 1 pair per step, n_gpus=1 (rank 0), "
+                                     f"random-init weights (seeded LeCun normal)",
+           "value": steps / dt, "unit": "pairs/s", "ms_per_pair": ms_pair, "steps": steps, "warmup": max(warmup, 2), "dtype": "f16" if use_fp16 else "f32",
+           "outputs_finite": finite, "setup_seconds": round(t_build, 1),
+           "roofline": {"kernel": "ln_corr_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "variant": "tokens normalised by the producing K9 launch (s2m2_corr)" if eng._tokens_normed is not None else "LayerNorm inside K1 (s2m2_ln_corr)",
+                        "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": us, "launches_timed": len(k1_us),
+                        "mfma_tflops": k1_flops / (us * 1e-6) / 1e12 if us > 0 else 0.0,
+                        "mfma_frac": (k1_flops / (us * 1e-6) / 1e12 / peak_tf) if us > 0 else 0.0}}
+    if detail:
+        attn, fwd = attention_and_work(eng, left, right, use_fp16, 1, ms_pair)
+        res["roofline_attention"] = {k: attn[k] for k in ("achieved", "peak", "unit", "frac", "flops_per_forward", "us_per_forward", "launches", "by_shape(batch,heads,N,d)")}
+        res["forward"] = {k: fwd[k] for k in ("flops_per_pair_executed", "achieved_tflops", "frac_of_mfma_peak")}
+    res["peak_mem_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)
+    eng.k1_events = None
+    del model, eng, left, right, out
+    torch.cuda.empty_cache()
+    return res
+
+
+def k1_ln_inside_in_forward(a, dev, use_fp16, steps=20):
+    """The OTHER form of the judged kernel inside a forward: a second module whose K1 normalises the tokens itself (S2M2_FUSE_K1LN=0: the
+    LayerNorm + correlation kernel SURVEY.md 8d names, s2m2_ln_corr, sc1 volume stores), warm graph, `steps` forwards with the same
+    dispatch-attached events as the headline's K1."""
+    import torch
+    from s2m2_amd.model import build_model
+    from s2m2_amd.weights import noise_pair
+    old = os.environ.get("S2M2_FUSE_K1LN")
+    os.environ["S2M2_FUSE_K1LN"] = "0"
+    try:
+        model = build_model(a.model, use_positivity=True, refine_iter=a.refine_iter).to(dev).eval()
+        eng = model.engine(torch.float16 if use_fp16 else torch.float32)
+    finally:
+        if old is None:
+            os.environ.pop("S2M2_FUSE_K1LN", None)
+        else:
+            os.environ["S2M2_FUSE_K1LN"] = old
+    left, right = (t.to(dev) for t in noise_pair(a.height, a.width, 1, seed=0))
+    eng.k1_events = []
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+            return model(left, right)
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    eng.k1_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    us = [t.elapsed_us() for t in eng.k1_events]
+    eng.k1_events = None
+    h, w, C = a.height // 4, a.width // 4, model.feature_channels
+    k1_bytes, _ = k1_algorithmic(h, w, C, 2 if use_fp16 else 4)
+    avg = sum(us) / max(1, len(us))
+    del model, eng
+    torch.cuda.empty_cache()
+    return {"kernel": "ln_corr_kernel with the LayerNorm inside (s2m2_ln_corr, S2M2_FUSE_K1LN=0), in-forward, dispatch-attached events",
+            "avg_launch_us": avg, "launches_timed": len(us), "frac": (k1_bytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS) if avg > 0 else 0.0,
+            "ms_per_pair_of_that_forward": 1e3 * dt / steps}
+
+
 def secondary_640x480(model, eng, dev, use_fp16, refine_iter, model_type, steps=50, warmup=3):
     """north_star's second size (BASELINE configs[1]: 640x480, refine_iter 3, one pair) measured in the SAME run on rank 0's GPU after
     the headline's timed region: hipGraph replay, K1 with its own start / stop events on the dispatch.  Not part of `value`."""
@@ -206,10 +350,21 @@ def secondary_batched(model, dev, use_fp16, a, pairs=2, steps=10, warmup=3):
             "value": steps * pairs / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / (steps * pairs), "steps": steps, "warmup": warmup}
 
 
+def k1_source_hash():
+    """sha256 over the sources K1 is compiled from -- what a PMC summary is valid for (tools/pmc_summary.py stores it)"""
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in ("ln_corr.hip", "common.h"):
+        hsh.update(open(os.path.join(ROOT, "s2m2_amd", "csrc", f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def pmc_traffic(model_type, H, W, use_fp16, B):
     """HBM bytes per K1 launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs of
     tools/k1_only.py, corrected as MI355X_MICROARCH.md prescribes -> profiles/rNN/k1_<case>_<dtype>_pmc.json).  PMC collection
-    serialises kernels and cannot run inside the timed bench, so the newest committed summary for this exact K1 shape is quoted."""
+    serialises kernels and cannot run inside the timed bench, so the newest committed summary for this exact K1 shape is quoted --
+    and ONLY if it was measured on the kernel source of this checkout (`k1_source_sha256_16` in the summary): a summary of an older
+    ln_corr.hip is refused (traffic null, the reason in traffic_source)."""
     import glob
     case = {("S", 1024, 1216): "c3", ("S", 480, 640): "c2", ("L", 1024, 1216): "c4", ("XL", 2048, 2432): "c5"}.get((model_type, H, W))
     if case is None or B != 1:
@@ -218,7 +373,10 @@ def pmc_traffic(model_type, H, W, use_fp16, B):
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    return d.get("traffic_bytes"), os.path.relpath(files[-1], ROOT)
+    rel = os.path.relpath(files[-1], ROOT)
+    if d.get("k1_source_sha256_16") != k1_source_hash():
+        return None, f"{rel}: REFUSED (measured on another ln_corr.hip / common.h: {d.get('k1_source_sha256_16')} vs {k1_source_hash()} here)"
+    return d.get("traffic_bytes"), rel
 
 
 def _quiet_init(dist, backend, rank, world, dev):
@@ -376,6 +534,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    devices = None
+    if dist is not None:
+        # which physical device every rank ran on: a scaling record then proves N distinct GPUs took part
+        me = str(getattr(torch.cuda.get_device_properties(dev), "uuid", f"{socket.gethostname()}:{local_rank}"))
+        devices = [None] * world
+        dist.all_gather_object(devices, me)
+
     if rank == 0:
         h, w, C = a.height // 4, a.width // 4, model.feature_channels
         e = 2 if use_fp16 else 4
@@ -419,23 +584,8 @@ def main():
         except Exception as e:  # noqa: BLE001  (an extra, never the line)
             k1_both = {"error": str(e)[:200]}
         # ---- after the timed region: one instrumented eager forward (work meter + HIP events around every K4 launch)
+        attn_block, fwd_block = attention_and_work(eng, left, right, use_fp16, B, ms_per_pair_gpu)
         eng.k1_events = None
-        hip.METER, hip.ATTN_EVENTS = {}, []
-        with torch.autocast("cuda", enabled=False):
-            eng.run(left, right, None)
-        torch.cuda.synchronize()
-        meter, attn_ev = hip.METER, hip.ATTN_EVENTS
-        hip.METER = hip.ATTN_EVENTS = None
-        peak_tf = MFMA_F16_PEAK_TFLOPS if use_fp16 else MFMA_F32_PEAK_TFLOPS
-        a_us = sum(1e3 * s.elapsed_time(e_) for s, e_, _, _ in attn_ev)
-        a_fl = sum(f for _, _, f, _ in attn_ev)
-        by_shape = {}
-        for s, e_, f, tag in attn_ev:
-            d = by_shape.setdefault(tag, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += 1e3 * s.elapsed_time(e_)
-            d[2] += f
-        fwd_flops = sum(v[0] for v in meter.values()) / B
         line = {
             "metric": "stereo pairs/sec, S-model 1216x1024 fp16 refine_iter=3 (ms/pair = 1000*n_gpus/value)",
             "value": pairs / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -450,24 +600,28 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": k1_bytes, "avg_launch_us": k1_us,
                          "launches_timed": len(k1_ms), "store_policy": "sc1 write-through (S2M2_K1_NT=%s)" % os.environ.get("S2M2_K1_NT", "2"),
                          "both_variants": k1_both},
-            "roofline_attention": {
-                "kernel": "attention_kernel (K4: every QK^T / PV contraction of a forward)", "bound": "mfma",
-                "achieved": a_fl / (a_us * 1e-6) / 1e12 if a_us > 0 else 0.0, "peak": peak_tf, "unit": "TFLOP/s",
-                "frac": (a_fl / (a_us * 1e-6) / 1e12 / peak_tf) if a_us > 0 else 0.0,
-                "flops_per_forward": a_fl, "us_per_forward": a_us, "launches": len(attn_ev),
-                "how": "HIP events around each K4 launch in one eager forward after the timed region (adds ~2 us of dispatch per launch)",
-                "by_shape(batch,heads,N,d)": {k: {"launches": v[0], "us": round(v[1], 1), "tflops": round(v[2] / (v[1] * 1e-6) / 1e12, 1)}
-                                              for k, v in by_shape.items()}},
-            "forward": {"flops_per_pair_executed": fwd_flops, "achieved_tflops": fwd_flops / (ms_per_pair_gpu * 1e-3) / 1e12,
-                        "frac_of_mfma_peak": fwd_flops / (ms_per_pair_gpu * 1e-3) / 1e12 / peak_tf,
-                        "flops_by_family": {k: v[0] / B for k, v in meter.items()}, "launches_by_family": {k: v[1] for k, v in meter.items()},
-                        "note": "2 flops per multiply-accumulate of every GEMM-shaped launch, padded channel counts; per GPU"},
+            "roofline_attention": attn_block,
+            "forward": fwd_block,
         }
         line["per_rank_ms_per_step"] = [round(x, 4) for x in per_rank_ms]
         if not a.no_secondary and (a.height, a.width) != (480, 640):
             line["secondary"] = secondary_640x480(model, eng, dev, use_fp16, a.refine_iter, a.model)
             if B == 1:
                 line["secondary_batched"] = secondary_batched(model, dev, use_fp16, a, pairs=2)
+        if devices is not None:
+            line["rccl_ranks"], line["distinct_gpus"], line["gpu_uuids"] = world, len(set(devices)), devices
+        if not a.no_secondary and world == 1 and (a.model, a.height, a.width, B) == ("S", 1024, 1216, 1) and use_fp16:
+            # the judged kernel's other form inside a forward, and the other BASELINE configurations (driver-run record of c4 / c5 / M)
+            try:
+                line["roofline"]["ln_inside_k1_in_forward"] = k1_ln_inside_in_forward(a, dev, use_fp16)
+            except Exception as e:  # noqa: BLE001  (an extra, never the line)
+                line["roofline"]["ln_inside_k1_in_forward"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+            for key, (tag, mt, H2, W2, pos, st) in (("secondary_L", ("c4", "L", 1024, 1216, True, 10)), ("secondary_M", ("M", "M", 1024, 1216, True, 10)),
+                                                    ("secondary_XL", ("c5", "XL", 2048, 2432, False, 3))):
+                try:
+                    line[key] = secondary_config(tag, mt, H2, W2, pos, dev, use_fp16, a.refine_iter, st)
+                except Exception as e:  # noqa: BLE001
+                    line[key] = {"config": tag, "error": f"{type(e).__name__}: {str(e)[:300]}"}
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.model, a.height, a.width, a.refine_iter)
         print(json.dumps(line), flush=True)

@@ -1085,11 +1085,21 @@ __global__ __launch_bounds__(CFG::NT) void conv_halo_kernel(ConvArgs p, int tile
 #define S2M2_FRAG_TRACE 0
 #endif
 #if S2M2_FRAG_TRACE
-__device__ unsigned long long g_frag_trace[4096 * 4 * 8];
+// slots 0..6: shader-clock stamps (s_memtime) of the kernel's phases; 7 / 8: the 100 MHz real-time counter (one clock for the whole chip) at entry / exit;
+// 9: HW_ID (CU / SE / wave slot) | XCC_ID << 32
+__device__ unsigned long long g_frag_trace[4096 * 4 * 10];
 #define FRAG_T(slot)                                                                                                          \
     do {                                                                                                                      \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && blockIdx.y == 0)                                                  \
-            g_frag_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();          \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {                                                \
+            unsigned long long* tr_ = g_frag_trace + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 10;                     \
+            tr_[(slot)] = __builtin_amdgcn_s_memtime();                                                                       \
+            if ((slot) == 0) {                                                                                                \
+                tr_[7] = __builtin_amdgcn_s_memrealtime();                                                                    \
+                tr_[9] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |                    \
+                         ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);             \
+            }                                                                                                                 \
+            if ((slot) == 6) tr_[8] = __builtin_amdgcn_s_memrealtime();                                                       \
+        }                                                                                                                     \
     } while (0)
 #else
 #define FRAG_T(slot)
@@ -1147,7 +1157,6 @@ __global__ __launch_bounds__(CFG::NT) void conv_frag_kernel(ConvArgs p, int tile
     const int nchunk = (p.Cin + CH - 1) / CH;
     const int nfrag = nchunk * ntap * KS;                         // fragments of this wave's stream
     FRAG_T(0);
-
     // ---- halo loader state (as in v3, CH channels per pixel)
     const int pc = tid % CFG::PPX, prow = tid / CFG::PPX;
     int apix[CFG::A_IT];

@@ -7,8 +7,20 @@ MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE 
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def k1_source_hash():
+    """the sources K1 is compiled from (bench.py quotes a summary only while this still matches: bench.k1_source_hash)"""
+    h = hashlib.sha256()
+    for f in ("ln_corr.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "s2m2_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
@@ -38,6 +50,8 @@ def main():
             out["fetch_bytes"] = v * 1024 * 2
             out["write_bytes"] = w * 1024
             out["traffic_bytes"] = v * 1024 * 2 + w * 1024
+    if pat == "ln_corr":
+        out["k1_source_sha256_16"] = k1_source_hash()
     print(json.dumps(out, indent=1))
 
 
