@@ -116,6 +116,9 @@ def cpu_baseline(model_type, H, W, refine_iter):
             with torch.no_grad():
                 return ref(l, r)
     else:
+        if os.environ.get("S2M2_REQUIRE_REF") == "1":
+            raise RuntimeError(f"S2M2_REQUIRE_REF=1 but oracle/_ref is not usable: {why}")
+        sys.stderr.write(f"bench.py: WARNING: oracle/_ref is not usable ({why}): the CPU baseline is the repo's restatement (kind 'port'), NOT the reference\n")
         kind = "port"
         from oracle import s2m2_oracle as O
         what = f"oracle/s2m2_oracle.py (torch CPU restatement; the reference itself is not on this box: {why})"

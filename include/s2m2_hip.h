@@ -28,12 +28,15 @@ extern "C" {
 enum { S2M2_F32 = 0, S2M2_F16 = 1 };
 
 /* ABI version of THIS header (major*10000 + minor*100 + patch).  s2m2_version() returns the value the library was built with: a caller
- * compares the two before its first call (s2m2_amd/hip.py: load() refuses a library whose major.minor differs from the binding's).
+ * compares the two before its first call (s2m2_amd/hip.py: load() refuses a library whose value differs from the binding's: descriptor
+ * layouts change IN PLACE between patch versions too, and a stale git-ignored .so would read pointers at shifted offsets).  The value is
+ * bumped with EVERY change of a signature or descriptor layout.
  * History: 100 = rounds 1-2; 300 = round 3 changed signatures IN PLACE (cv_pitch inserted into s2m2_sinkhorn_regress / s2m2_cv_lookup,
  * s2m2_conv_desc / s2m2_chain_desc grew epi_cout0, ln_out*, fan_*, weight_frag, pool_h / pool_w) -- a caller built against 100 must be
  * rebuilt; 400 = round 4 (s2m2_pw_direct, s2m2_conv_narrow, s2m2_ln_corr_pitched added; the round-3 experiment entry
- * points s2m2_corr_tiled / s2m2_corr_hybrid / s2m2_debug_store_pattern and the ln_out_tile* fields of s2m2_chain_desc removed). */
-#define S2M2_ABI_VERSION 400
+ * points s2m2_corr_tiled / s2m2_corr_hybrid / s2m2_debug_store_pattern and the ln_out_tile* fields of s2m2_chain_desc removed;
+ * head_* appended to s2m2_narrow_desc without a bump -- the reason for the exact comparison since 500); 500 = round 5. */
+#define S2M2_ABI_VERSION 500
 int s2m2_version(void);
 const char* s2m2_last_error(void);
 /* test aid (not part of the path): fills the LDS of every CU with quiet-NaN patterns, so that a kernel launched next that reads an LDS word it

@@ -39,13 +39,31 @@ def _deps_mtime():
     return m
 
 
-def _compile(src: str, force: bool, hdr_mtime: float, extra=()) -> str:
+def _defines_file() -> str:
+    return os.path.join(OBJ, "defines.txt")
+
+
+def effective_defines(extra=()) -> list:
+    """S2M2_BUILD_DEFINES + `extra` + what an earlier build of this object directory persisted (the tracked-loads fallback of
+    __graft_entry__.build(): once taken, every later incremental compile of a single file must use it too -- objects with and without
+    -DS2M2_UNTRACKED_LOADS=0 must never be linked together)."""
+    keep = []
+    if os.path.exists(_defines_file()):
+        keep = [d for d in open(_defines_file()).read().split() if d.startswith("-DS2M2_UNTRACKED_LOADS=")]
+    out = list(DEFINES)
+    for d in list(extra) + keep:
+        if d not in out:
+            out.append(d)
+    return out
+
+
+def _compile(src: str, force: bool, hdr_mtime: float, defines=()) -> str:
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
     spath = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(spath)
             and os.path.getmtime(obj) > hdr_mtime):
         return obj
-    cmd = [HIPCC, *FLAGS, *DEFINES, *extra, "-c", spath, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *defines, "-c", spath, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
@@ -61,18 +79,25 @@ def config_key() -> str:
         ver = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
     except OSError:
         ver = "?"
-    return hashlib.sha256((SUFFIX + "|" + " ".join(DEFINES) + "|" + ver).encode()).hexdigest()[:12]
+    return hashlib.sha256((SUFFIX + "|" + " ".join(effective_defines()) + "|" + ver).encode()).hexdigest()[:12]
 
 
 def build(force: bool = False, verbose: bool = True, extra_defines=()) -> str:
-    """extra_defines: appended to S2M2_BUILD_DEFINES for this call (forces a full rebuild when given)"""
-    force = force or bool(extra_defines)
+    """extra_defines: appended to S2M2_BUILD_DEFINES for this call and PERSISTED next to the objects (a change of the effective defines
+    forces a full rebuild)"""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    defines = effective_defines(extra_defines)
+    before = open(_defines_file()).read().split() if os.path.exists(_defines_file()) else None
+    if before is not None and before != defines:
+        force = True                                               # objects of another configuration: never mix
+    if before is None and extra_defines:
+        force = True
+    open(_defines_file(), "w").write(" ".join(defines) + "\n")
     srcs = sources()
     hdr = _deps_mtime()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, hdr, tuple(extra_defines)), srcs))
+        objs = list(ex.map(lambda s: _compile(s, force, hdr, tuple(defines)), srcs))
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]

@@ -467,7 +467,7 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;
     const int pitch = g_pitch > 0 ? g_pitch : w;
-    // cache policy of the volume stores (store_cv): sc1 write-through by default -- measured (profiles/r04/k1_store_modes.txt, ab_k1_store.txt)
+    // cache policy of the volume stores (store_cv): sc1 write-through by default -- measured (profiles/r04/k1_store_modes.txt, ab_k1_store_sc1lib_overlap.txt)
     // 19.2 -> 16.8 us back to back and 19.7-20.7 -> 17.7 us inside the forward against the write-back default of rounds 1-3; S2M2_K1_NT=0..4 A/B
     // (only for volume rows on 128-byte lines: a write-through store of a PARTIAL line is a read-modify-write at the memory side -- dense 608-byte
     // rows measured 25.0 us with sc1 against 21.8 with plain stores, profiles/r04/kbench.txt; the engine always allocates aligned rows)

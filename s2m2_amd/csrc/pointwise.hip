@@ -165,6 +165,7 @@ extern "C" int s2m2_refine_update_to(const void* dco, int dco_stride, const floa
     using namespace s2m2;
     S2M2_REQUIRE(dco && disp && conf && occ && disp_out && conf_out && occ_out && npix > 0 && w > 0 && dco_stride >= 10,
                  "refine_update: bad arguments");
+    S2M2_REQUIRE(npix < (1LL << 31), "refine_update: 2^31 or more pixels (the column index is decoded in 32 bits)");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == S2M2_F16)
         hipLaunchKernelGGL((refine_update_kernel<half_t>), grid1(npix), dim3(256), 0, st, (const half_t*)dco, dco_stride, disp, conf, occ,

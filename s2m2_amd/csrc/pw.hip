@@ -144,6 +144,7 @@ static int launch_pw(const PwArgs& a, hipStream_t st) {
     static size_t lds_granted[kMaxDevices] = {};
     if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::LDS_BYTES, lds_granted, "pw_direct")) return 1;
     const long long nblk = (a.rows + CFG::BM - 1) / CFG::BM;
+    if (nblk >= (1LL << 31)) return set_error("pw_direct: %lld row tiles do not fit a grid dimension", nblk);
     hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(CFG::NT), CFG::LDS_BYTES, st, a);
     return check_launch("pw_direct");
 }

@@ -673,7 +673,7 @@ class Engine:
         disp = self.global_refiner("global_refiner", tr0, disp, conf)
         if cap is not None:
             cap["disp_g"] = disp
-        # (measured and dropped, profiles/r04/ab_overlap.txt: this branch -- and the f2x layers of the two mask heads -- on a second stream as
+        # (measured and dropped, profiles/r04/ab_k1_store_sc1lib_overlap.txt: this branch -- and the f2x layers of the two mask heads -- on a second stream as
         # parallel branches of the captured hipGraph: 8.95 vs 8.83 ms per pair and K1 19.4 vs 17.7 us, the side kernels evict K1's tokens)
         fus = self.fusion("feat_fusion_layer", tr0, py0[:B])
         ctx = self.cconv(self.std("ctx_feat.2"), [self.cconv(self.std("ctx_feat.0"), [fus], act=hip.ACT_GELU)])

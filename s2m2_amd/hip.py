@@ -59,7 +59,7 @@ class NarrowDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
-ABI_VERSION = 400                     # include/s2m2_hip.h: S2M2_ABI_VERSION (checked in load())
+ABI_VERSION = 500                     # include/s2m2_hip.h: S2M2_ABI_VERSION (checked in load())
 
 SIGNATURES = {
     "s2m2_version": (_i, []),
@@ -123,7 +123,7 @@ def load() -> ctypes.CDLL:
             fn.restype = res
             fn.argtypes = args
         ver = lib.s2m2_version()
-        if ver // 100 != ABI_VERSION // 100:          # the signatures in SIGNATURES are those of include/s2m2_hip.h at ABI_VERSION
+        if ver != ABI_VERSION:                        # exact: descriptor layouts change in place between patch versions as well
             raise RuntimeError(f"{LIB_PATH} reports ABI version {ver}, this binding was written against {ABI_VERSION} "
                                "(include/s2m2_hip.h: S2M2_ABI_VERSION): rebuild the library with `python -m s2m2_amd.build`")
         _lib = lib

@@ -37,3 +37,14 @@ def T(a, device="cpu"):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(autouse=True)
+def _seeded(request):
+    """Every test starts from its own torch / numpy seed (a hash of its node id): outcomes do not depend on which tests ran before or on
+    how many random numbers they drew (test_transposed_conv_packings failed in full-suite order only)."""
+    import zlib
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    yield

@@ -43,7 +43,7 @@ def test_transposed_conv_packings():
     c = pack.convT_s1_as_conv(w)
     x = torch.randn(1, 6, 7, 9)
     ref = torch.nn.functional.conv_transpose2d(x, w, padding=1)
-    assert float((torch.nn.functional.conv2d(x, c, padding=1) - ref).abs().max()) < 1e-5
+    assert float((torch.nn.functional.conv2d(x, c, padding=1) - ref).abs().max()) < 2e-6 * float(ref.abs().max()) + 1e-6   # fp32 round-off of two summation orders
     w2 = torch.randn(8, 5, 2, 2)                                                 # ConvTranspose2d(k=2, s=2)
     g, cp = pack.pack_convT_2x2s2(w2, torch.float32)
     assert cp == 8 and tuple(g.shape) == (32, 8)
@@ -53,7 +53,7 @@ def test_transposed_conv_packings():
     y = torch.nn.functional.conv_transpose2d(xin, w2, stride=2)
     z = torch.einsum("rk,nkyx->nryx", g, xin).reshape(1, 2, 2, 8, 3, 4)          # rows ordered (dy, dx, c')
     z = z.permute(0, 3, 4, 1, 5, 2).reshape(1, 8, 6, 8)[:, :5]
-    assert float((z - y).abs().max()) < 1e-5
+    assert float((z - y).abs().max()) < 2e-6 * float(y.abs().max()) + 1e-6
 
 
 def test_chain_frag_is_a_permutation():
