@@ -28,6 +28,10 @@
 // fp16: v_mfma_f32_32x32x16_f16 with fp32 softmax/accumulators;  fp32 (parity mode): exact v_mfma_f32_32x32x2_f32.
 #include "common.h"
 
+#ifndef S2M2_ATTN_DBG
+#define S2M2_ATTN_DBG 0          // ablation builds (timing only, wrong results): 1 no K/V refetch after stage 0, 2 no softmax math, 4 no MFMA, 8 no stage barriers
+#endif
+
 namespace s2m2 {
 
 constexpr size_t kLdsBytes = 160 * 1024;
@@ -40,6 +44,8 @@ struct AttnArgs {
     // positional encoding (PE variant only)
     const float* px; const float* py; void* pe_out; long long spe; int gw, gh;
     int dry;                            // host side only: plan the launch (tile variant, waves, LDS) and return without launching
+    int nblk;                           // query blocks per (batch, head): the grid is 1-D, nblk * nb * heads blocks
+    int xcd;                            // 1: XCD-aware block order (see attention_kernel)
 };
 
 template <typename T, int DP_, bool PE_, int MINW_ = 4, bool KSPLIT_ = false, int NXT_ = 2, int NYT_ = 1>
@@ -118,10 +124,15 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     const int nthr = blockDim.x;
     const int NW = nthr >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int bh = blockIdx.y;
+    // Block order: the query blocks of one (batch, head) -- and the heads of one batch row, whose Q / K / V share cache lines -- re-read the SAME
+    // K / V rows.  Hardware places block i on XCD i % 8 (speed assumption only), so in plain dispatch order the 2-3 query blocks of a row
+    // land on different XCDs and every one of them pulls the row's K / V through the fabric into its own L2 (d = 128, N = 304: 240 MB instead
+    // of 80).  xcd_remap hands each XCD a contiguous range of logical ids: blocks that share K / V run on one XCD at about the same time.
+    const int lid = a.xcd ? xcd_remap((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const int bh = lid / a.nblk, qblk = lid - bh * a.nblk;
     const int b = bh / a.heads, hd = bh - b * a.heads;
     const int bkv = a.swap ? (b + a.nb / 2) % a.nb : b;
-    const int q0 = CFG::KSPLIT ? blockIdx.x * 32 : (blockIdx.x * NW + wv) * 32;
+    const int q0 = CFG::KSPLIT ? qblk * 32 : (qblk * NW + wv) * 32;
     const bool wave_active = q0 < a.Nq;
 
     const T* qb = static_cast<const T*>(a.q) + (long long)b * a.Nq * a.sq + hd * a.D;
@@ -245,10 +256,10 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     const int nstage = (a.Nk + KVT - 1) / KVT;
     fetch(0);
     for (int t = 0; t < nstage; ++t) {
-        __syncthreads();                                          // previous stage fully consumed (also covers the PE table fill)
-        stash();
-        __syncthreads();
-        if (t + 1 < nstage) fetch((t + 1) * KVT);                 // in flight under this stage's MFMAs
+        if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();      // previous stage fully consumed (also covers the PE table fill)
+        if (!(S2M2_ATTN_DBG & 1) || t == 0) stash();
+        if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();
+        if (t + 1 < nstage && !(S2M2_ATTN_DBG & 1)) fetch((t + 1) * KVT);   // in flight under this stage's MFMAs
         if (wave_active) {
 #pragma unroll 1
             for (int sub = CFG::KSPLIT ? wv : 0; sub < CFG::KT; sub += CFG::KSPLIT ? 4 : 1) {
@@ -263,6 +274,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
                     Frag<T> kf;
                     load_frag(kf, kp + kk * 16);
+                    if (S2M2_ATTN_DBG & 4) { sacc[kk & 15] += (float)kf.v[0] * (float)qf[kk].v[0]; } else
                     mma32(sacc, kf, qf[kk]);
                 }
                 // ---- online softmax (lane: one query, keys crow(r, hi) of this sub-tile)
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 2^(-inf) = 0 on the first tile
                 float lsum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(p[r] - m_new); lsum += p[r]; }
+                for (int r = 0; r < 16; ++r) { p[r] = (S2M2_ATTN_DBG & 2) ? p[r] : __builtin_amdgcn_exp2f(p[r] - m_new); lsum += p[r]; }
                 l_run = l_run * alpha + lsum;
                 m_run = m_new;
                 if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {                 // the running maximum rarely moves after the first tiles
@@ -300,6 +312,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                     for (int s = 0; s < 2; ++s) {
                         Frag<T> vf;
                         load_vfrag<T>(vf, vp + 16 * s, vp + 16 * s + 8);
+                        if (S2M2_ATTN_DBG & 4) { oacc[dt][s] += (float)vf.v[0] * (float)pf[s].v[0]; } else
                         mma32(oacc[dt], vf, pf[s]);
                     }
                 }
@@ -483,7 +496,12 @@ static int launch_attn_t(const AttnArgs& a, int nw, hipStream_t st) {
     if (reserve_lds(reinterpret_cast<const void*>(kern), lds, lds_granted, "attention")) return 1;
     const int ntq = (a.Nq + 31) / 32;
     const int nblk = KSPLIT ? ntq : (ntq + nw - 1) / nw;
-    hipLaunchKernelGGL(kern, dim3(nblk, a.nb * a.heads), dim3(nw * 64), lds, st, a);
+    if ((long long)nblk * a.nb * a.heads >= (1LL << 31)) return set_error("attention: %lld blocks do not fit a grid dimension", (long long)nblk * a.nb * a.heads);
+    AttnArgs b = a;
+    b.nblk = nblk;
+    static const bool xcd_off = [] { const char* e = getenv("S2M2_ATTN_XCD"); return e && e[0] == '0'; }();   // A/B switch (profiles/r05/ab_attn_xcd.txt)
+    b.xcd = xcd_off ? 0 : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nblk * a.nb * a.heads)), dim3(nw * 64), lds, st, b);
     return check_launch("attention");
 }
 
@@ -516,7 +534,9 @@ static int launch_attn(const AttnArgs& a, hipStream_t st) {
     const int ntq = (a.Nq + 31) / 32;
     const int bh = a.nb * a.heads;
     // register-heavy head dims (d >= 96: ~190-250 VGPRs = 8 waves per CU): blocks of at most 4 waves so that two are co-resident
-    const int maxw = (DP >= 96 && MAXW > 4) ? 4 : MAXW;
+    int maxw = (DP >= 96 && MAXW > 4) ? 4 : MAXW;
+    static const int maxw_env = [] { const char* e = getenv("S2M2_ATTN_MAXW"); return e ? atoi(e) : 0; }();   // experiment switch
+    if (maxw_env > 0 && maxw_env <= MAXW) maxw = maxw_env;
     int nblk = (ntq + maxw - 1) / maxw;
     int nw = (ntq + nblk - 1) / nblk;                              // <= maxw waves per block, minimal idle tail
     if constexpr (DP <= 64) {
