@@ -77,7 +77,9 @@ struct ChainCfg {
 #ifndef S2M2_CHAIN_DEPTH8
 #define S2M2_CHAIN_DEPTH8 1
 #endif
-    static constexpr int D = DIRECT ? CPS : WP == 8 ? 2 : (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;   // weight chunks in flight
+    // weight chunks in flight.  Direct form: a whole stage (C / 16 fragments) up to C = 256; at C = 384 half a stage -- 12 waves per block are
+    // three per SIMD, 168 registers each: 24 fragments in flight spilled (tools/kernel_resources.py)
+    static constexpr int D = DIRECT ? (CPS > 16 ? CPS / 2 : CPS) : WP == 8 ? 2 : (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;
     static constexpr int WROWS = NT / WP;                 // weight rows covered by one pass of the loader threads (WP pieces per row)
     static constexpr int B_IT = DIRECT ? WN / 32 : C / WROWS;   // 16-byte weight pieces per thread and chunk (direct: one per 32-cout tile)
     static constexpr int PPR = C / VEC;                   // 16-byte pieces per activation row
@@ -85,7 +87,10 @@ struct ChainCfg {
     static constexpr size_t A_BYTES = (size_t)BM * ARS * sizeof(T);
     static constexpr size_t W_BYTES = DIRECT ? 0 : (size_t)C * RS * sizeof(T);
     static constexpr size_t LDS_BYTES = 2 * A_BYTES + 2 * W_BYTES;
-    static_assert(C % 128 == 0 && CPS % D == 0 && (BM * PPR) % NT == 0 && BM % 32 == 0 && WN % 32 == 0 && C % WROWS == 0, "unsupported chain tile");
+    // power-of-two rows of 16-byte pieces: the LayerNorm output reduces a row with lane shuffles inside the store pass; other widths (C = 192,
+    // 384: 24 / 48 pieces) take a second pass over the staged tile
+    static constexpr bool PPR_POW2 = (PPR & (PPR - 1)) == 0;
+    static_assert(C % (DIRECT ? 64 : 128) == 0 && CPS % D == 0 && (BM * PPR) % NT == 0 && BM % 32 == 0 && WN % 32 == 0 && C % WROWS == 0, "unsupported chain tile");
     static_assert(!DIRECT || (sizeof(T) == 2 && D * B_IT <= 24), "direct chain: fp16, at most 24 fragments (96 registers) in flight");
     static_assert(LDS_BYTES <= 160 * 1024, "chain tile does not fit the 160 KB LDS");
 };
@@ -194,15 +199,16 @@ struct ChainStage {
             // no LDS weight tile, no barrier: step f multiplies the fragments of ring slot f (requested a whole stage ago), then refills the
             // slot with the same step of the next stage (unconditionally -- after the last stage this stage's fragments are read again and
             // never used: a branch around a load would cost a full `s_waitcnt vmcnt(0)`)
+            const T* cur = static_cast<const T*>(p.w[S]);
             const T* nxt = S + 1 < CFG::NST ? static_cast<const T*>(p.w[S + 1 < CFG::NST ? S + 1 : S])
                                             : (p.nfan > 0 ? static_cast<const T*>(p.fan_w) : static_cast<const T*>(p.w[S]));
 #pragma unroll
-            for (int f = 0; f < D; ++f) {
+            for (int f = 0; f < CPS; ++f) {                        // ring slot f % D holds step f; it is refilled with the step D ahead in the stream
                 Frag<T> xf[CFG::MT], wfr[CFG::NTL];
 #pragma unroll
                 for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], arow + (size_t)i * 32 * ARS + f * 16);
 #pragma unroll
-                for (int jn = 0; jn < CFG::NTL; ++jn) wfr[jn].v = __builtin_bit_cast(decltype(wfr[jn].v), ws.r[f][jn]);
+                for (int jn = 0; jn < CFG::NTL; ++jn) wfr[jn].v = __builtin_bit_cast(decltype(wfr[jn].v), ws.r[f % D][jn]);
                 if (ln_on) {
 #pragma unroll
                     for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
@@ -211,7 +217,8 @@ struct ChainStage {
                 for (int i = 0; i < CFG::MT; ++i)
 #pragma unroll
                     for (int jn = 0; jn < CFG::NTL; ++jn) mma32(acc[i][jn], wfr[jn], xf[i]);   // D[cout][row]
-                ws.fetch_direct(nxt, f, f);
+                if (f + D < CPS) ws.fetch_direct(cur, f + D, f % D);
+                else ws.fetch_direct(nxt, f + D - CPS, f % D);
             }
         } else
 #pragma unroll 1
@@ -284,8 +291,9 @@ struct ChainStage {
             // LayerNorm output: a row's PPR pieces sit in PPR consecutive lanes of one wave (NT % PPR == 0, PPR in {16, 32, 64}:
             // checked on the host), and a thread's piece column is the same for every `it`
             const bool ln2 = p.ln_out != nullptr;
+            const bool ln2_rows = ln2 && CFG::PPR_POW2;              // statistics by lane shuffles inside this pass (PPR lanes share a row)
             float g2[VEC], b2[VEC];
-            if (ln2) {
+            if (ln2_rows) {
                 const int pcx = tid % CFG::PPR;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) { g2[e] = p.ln_gamma[pcx * VEC + e]; b2[e] = p.ln_beta[pcx * VEC + e]; }
@@ -306,8 +314,10 @@ struct ChainStage {
                     for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(to_f32(v.v[e]) + to_f32(u.v[e]));
                 }
                 if (m < p.rows) *reinterpret_cast<Vec16<T>*>(outp + m * p.out_stride + pcx * VEC) = v;
-                if (p.nfan > 0) *reinterpret_cast<Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC) = v;   // the stored rows: A operand of the fan-out stages
-                if (ln2) {                                         // block-uniform
+                // the stored rows go back into the tile: A operand of the fan-out stages / input of the second LayerNorm pass
+                if (p.nfan > 0 || (ln2 && !CFG::PPR_POW2)) *reinterpret_cast<Vec16<T>*>(Aout + (size_t)row * ARS + pcx * VEC) = v;
+                if constexpr (CFG::PPR_POW2) {
+                if (ln2_rows) {                                    // block-uniform
                     // statistics of the STORED (rounded) row, two passes in fp32 like K1 / nn.LayerNorm: biased variance, eps inside
                     float x[VEC], sum = 0.f;
 #pragma unroll
@@ -326,6 +336,43 @@ struct ChainStage {
                     for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[e] * rstd, g2[e], b2[e]));
                     if (m < p.rows) {
                         *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + pcx * VEC) = o;
+                    }
+                }
+                }
+            }
+            if constexpr (!CFG::PPR_POW2) {
+                if (ln2) {                                         // block-uniform
+                    // rows of 24 / 48 pieces do not line up with the lanes of the store pass: second pass over the stored tile, 8 lanes per row
+                    // (piece q of a row on lane q % 8 -- 128 contiguous bytes per 8 lanes in every read and store), two-pass fp32 statistics
+                    // with the 8-lane DPP sum, as K1's own LayerNorm takes them
+                    __syncthreads();
+                    constexpr int PPL = CFG::PPR / 8;               // pieces per lane
+                    static_assert(CFG::PPR % 8 == 0, "a row is a whole number of 8-piece rounds");
+                    const int sub = tid & 7;
+                    for (int row = tid >> 3; row < CFG::BM; row += CFG::NT / 8) {
+                        const long long m = m0 + row;
+                        float x[PPL][VEC], sum = 0.f;
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) {
+                            const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(Aout + (size_t)row * ARS + (sub + 8 * q) * VEC);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) { x[q][e] = to_f32(v.v[e]); sum += x[q][e]; }
+                        }
+                        const float mean = group8_sum(sum) * (1.0f / (float)C);
+                        float sq = 0.f;
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q)
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) { x[q][e] -= mean; sq = __builtin_fmaf(x[q][e], x[q][e], sq); }
+                        const float rstd = rsqrtf(group8_sum(sq) * (1.0f / (float)C) + p.ln_out_eps);
+#pragma unroll
+                        for (int q = 0; q < PPL; ++q) {
+                            const int c0 = (sub + 8 * q) * VEC;
+                            Vec16<T> o;
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) o.v[e] = from_f32<T>(__builtin_fmaf(x[q][e] * rstd, p.ln_gamma[c0 + e], p.ln_beta[c0 + e]));
+                            if (m < p.rows) *reinterpret_cast<Vec16<T>*>(static_cast<T*>(p.ln_out) + m * p.ln_out_stride + c0) = o;
+                        }
                     }
                 }
             }
@@ -367,14 +414,15 @@ __device__ __forceinline__ void chain_fan(const ChainArgs& p, ChainStream<CFG, T
         }
         const bool stats = ln_on && F == 0;
         if constexpr (CFG::DIRECT) {
+            const T* cur = static_cast<const T*>(p.fan_w) + (size_t)F * C * C;
             const T* nxt = static_cast<const T*>(p.fan_w) + (size_t)(F + 1 < p.nfan ? F + 1 : F) * C * C;
 #pragma unroll
-            for (int f = 0; f < D; ++f) {
+            for (int f = 0; f < CPS; ++f) {
                 Frag<T> xf[CFG::MT], wfr[CFG::NTL];
 #pragma unroll
                 for (int i = 0; i < CFG::MT; ++i) load_frag(xf[i], arow + (size_t)i * 32 * ARS + f * 16);
 #pragma unroll
-                for (int jn = 0; jn < CFG::NTL; ++jn) wfr[jn].v = __builtin_bit_cast(decltype(wfr[jn].v), ws.r[f][jn]);
+                for (int jn = 0; jn < CFG::NTL; ++jn) wfr[jn].v = __builtin_bit_cast(decltype(wfr[jn].v), ws.r[f % D][jn]);
                 if (stats) {
 #pragma unroll
                     for (int i = 0; i < CFG::MT; ++i) ln_accumulate(xf[i], ln_s[i], ln_q[i], ln_shift[i]);
@@ -383,7 +431,8 @@ __device__ __forceinline__ void chain_fan(const ChainArgs& p, ChainStream<CFG, T
                 for (int i = 0; i < CFG::MT; ++i)
 #pragma unroll
                     for (int jn = 0; jn < CFG::NTL; ++jn) mma32(acc[i][jn], wfr[jn], xf[i]);
-                ws.fetch_direct(nxt, f, f);
+                if (f + D < CPS) ws.fetch_direct(cur, f + D, f % D);
+                else ws.fetch_direct(nxt, f + D - CPS, f % D);
             }
         } else
 #pragma unroll 1
@@ -547,7 +596,26 @@ extern "C" int s2m2_mlp_chain_supported(int C, int dtype) {
     return 0;
 }
 
-extern "C" int s2m2_mlp_chain_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 256); }
+// direct form: one wave per 32 couts (C / 32 waves per block: 4, 6, 8, 12), a whole stage of C / 16 fragments in flight per wave
+extern "C" int s2m2_mlp_chain_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 192 || C == 256 || C == 384); }
+
+namespace s2m2 {
+// direct form, by width: 32-row tiles while they fit the chip in about one round, else 64-row tiles (half the weight traffic per row)
+template <int NST>
+static int launch_chain_direct(const ChainArgs& a, int C, bool tall, hipStream_t st) {
+    switch (C) {
+        case 128: return tall ? launch_chain<half_t, 128, 64, NST, 4, 0>(a, st) : launch_chain<half_t, 128, 32, NST, 4, 0>(a, st);
+        case 192: return tall ? launch_chain<half_t, 192, 64, NST, 6, 0>(a, st) : launch_chain<half_t, 192, 32, NST, 6, 0>(a, st);
+        case 256: return tall ? launch_chain<half_t, 256, 64, NST, 8, 0>(a, st) : launch_chain<half_t, 256, 32, NST, 8, 0>(a, st);
+        default: return tall ? launch_chain<half_t, 384, 64, NST, 12, 0>(a, st) : launch_chain<half_t, 384, 32, NST, 12, 0>(a, st);
+    }
+}
+static bool chain_direct_tall(int C, long long rows) {
+    static const int force_bm = getenv("S2M2_CHAIN_DIRECT_BM") ? atoi(getenv("S2M2_CHAIN_DIRECT_BM")) : 0;      // 32 / 64 forces one (tuning)
+    if (C == 384) return false;                                    // (64-row tiles at 12 waves per block spill: 55 - 88 registers)
+    return force_bm ? force_bm == 64 : rows > (C == 128 ? 24576 : C == 192 ? 16384 : 8192);
+}
+}  // namespace s2m2
 
 extern "C" int s2m2_mlp_fan_supported(int C, int nfan, int dtype) { return s2m2_mlp_chain_frag_supported(C, dtype) && nfan >= 1 && nfan <= 4; }
 
@@ -556,7 +624,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     S2M2_REQUIRE(d, "mlp_chain: null descriptor");
     S2M2_REQUIRE(d->x, "mlp_chain: null x");
     S2M2_REQUIRE(d->weight_frag == 0 || (d->weight_frag == 1 && (d->nstage > 0 || d->nfan > 0) && s2m2_mlp_chain_frag_supported(d->C, d->dtype)),
-                 "mlp_chain: weight_frag=%d needs fp16 and C = 128 / 256", d->weight_frag);
+                 "mlp_chain: weight_frag=%d needs fp16 and C = 128 / 192 / 256 / 384", d->weight_frag);
     S2M2_REQUIRE((d->pool_h == 0 && d->pool_w == 0) ||
                  (d->weight_frag && d->pool_h >= 2 && d->pool_w >= 2 && d->rows % ((long long)(d->pool_h / 2) * (d->pool_w / 2)) == 0),
                  "mlp_chain: pool_h / pool_w need weight_frag, an input of at least 2x2 pixels and rows = N * (pool_h/2) * (pool_w/2)");
@@ -577,15 +645,12 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
         f.zero = zero_page();
         S2M2_REQUIRE(f.zero, "mlp_chain: cannot allocate the zero page");
         hipStream_t fst = static_cast<hipStream_t>(stream);
-        static const int force_bm0 = getenv("S2M2_CHAIN_DIRECT_BM") ? atoi(getenv("S2M2_CHAIN_DIRECT_BM")) : 0;
-        const bool tall0 = force_bm0 ? force_bm0 == 64 : d->rows > (d->C == 128 ? 24576 : 8192);
-        if (d->C == 128) return tall0 ? launch_chain<half_t, 128, 64, 0, 4, 0>(f, fst) : launch_chain<half_t, 128, 32, 0, 4, 0>(f, fst);
-        return tall0 ? launch_chain<half_t, 256, 64, 0, 8, 0>(f, fst) : launch_chain<half_t, 256, 32, 0, 8, 0>(f, fst);
+        return launch_chain_direct<0>(f, d->C, chain_direct_tall(d->C, d->rows), fst);
     }
-    S2M2_REQUIRE(d->nstage != 0, "mlp_chain: fan-out only (nstage = 0) exists in the direct form: weight_frag = 1, fp16, C = 128 / 256");
+    S2M2_REQUIRE(d->nstage != 0, "mlp_chain: fan-out only (nstage = 0) exists in the direct form: weight_frag = 1, fp16, C = 128 / 192 / 256 / 384");
     S2M2_REQUIRE(d->out, "mlp_chain: null out");
     S2M2_REQUIRE(d->nstage >= 1 && d->nstage <= 3, "mlp_chain: nstage=%d (0..3)", d->nstage);
-    S2M2_REQUIRE(s2m2_mlp_chain_supported(d->C, d->dtype), "mlp_chain: C=%d dtype=%d is not supported (fp16: 128/256/384/512, fp32: 128/256)", d->C, d->dtype);
+    S2M2_REQUIRE(d->weight_frag || s2m2_mlp_chain_supported(d->C, d->dtype), "mlp_chain: C=%d dtype=%d is not supported (fp16: 128/256/384/512, fp32: 128/256; direct form fp16: 128/192/256/384)", d->C, d->dtype);
     S2M2_REQUIRE(d->rows > 0 && d->rows < (1LL << 31), "mlp_chain: rows=%lld", d->rows);
     S2M2_REQUIRE(d->x_stride >= d->C && d->x_stride % 8 == 0 && d->out_stride >= d->C && d->out_stride % 8 == 0,
                  "mlp_chain: row strides %lld/%lld must be multiples of 8 and at least C", d->x_stride, d->out_stride);
@@ -621,7 +686,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     }
     if (d->ln_out) {
         const int ppr = d->C * (d->dtype == S2M2_F16 ? 2 : 4) / 16;      // 16-byte pieces per row = lanes that share a row in the store pass
-        S2M2_REQUIRE(ppr == 16 || ppr == 32 || ppr == 64, "mlp_chain: ln_out needs a row of 16, 32 or 64 pieces (C=%d has %d)", d->C, ppr);
+        S2M2_REQUIRE(ppr % 8 == 0 && ppr <= 64, "mlp_chain: ln_out needs a row of 8 k <= 64 16-byte pieces (C=%d has %d)", d->C, ppr);
         S2M2_REQUIRE(d->ln_gamma && d->ln_beta && d->ln_out_eps > 0.f && d->ln_out_stride >= d->C && d->ln_out_stride % 8 == 0,
                      "mlp_chain: ln_out needs gamma, beta, a positive eps and a row stride that is a multiple of 8");
     }
@@ -636,15 +701,11 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     const char cfg = d->rows <= 8192 ? 's' : 'm';                 // at most one 32-row tile per CU: short tiles, more CUs busy (measured: tools/chainbench.py)
     if (d->weight_frag) {                                         // direct form: 32-row tiles, one wave per 32 couts
         a.xcd_tiles = (d->xcd_group_rows > 0 && !xcd_off && d->xcd_group_rows % 32 == 0 && d->rows % (8LL * d->xcd_group_rows) == 0) ? (int)(d->xcd_group_rows / 32) : 0;
-        // 32-row tiles while they fit the chip in one round (C = 256: one block per CU, C = 128: three), else 64-row tiles (half the weight
-        // traffic per row); S2M2_CHAIN_DIRECT_BM = 32 / 64 forces one (tuning)
-        static const int force_bm = getenv("S2M2_CHAIN_DIRECT_BM") ? atoi(getenv("S2M2_CHAIN_DIRECT_BM")) : 0;
-        const bool tall = force_bm ? force_bm == 64 : d->rows > (d->C == 128 ? 24576 : 8192);
-        if (tall) {
-            a.xcd_tiles = a.xcd_tiles % 2 == 0 ? a.xcd_tiles / 2 : 0;
-            return d->C == 128 ? launch_chain_n<half_t, 128, 64, 4, 0>(a, d->nstage, st) : launch_chain_n<half_t, 256, 64, 8, 0>(a, d->nstage, st);
-        }
-        return d->C == 128 ? launch_chain_n<half_t, 128, 32, 4, 0>(a, d->nstage, st) : launch_chain_n<half_t, 256, 32, 8, 0>(a, d->nstage, st);
+        const bool tall = chain_direct_tall(d->C, d->rows);
+        if (tall) a.xcd_tiles = a.xcd_tiles % 2 == 0 ? a.xcd_tiles / 2 : 0;
+        if (d->nstage == 1) return launch_chain_direct<1>(a, d->C, tall, st);
+        if (d->nstage == 2) return launch_chain_direct<2>(a, d->C, tall, st);
+        return launch_chain_direct<3>(a, d->C, tall, st);
     }
     if (d->dtype == S2M2_F16) {
         switch (d->C) {

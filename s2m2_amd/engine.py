@@ -273,9 +273,10 @@ class Engine:
         return dual
 
     def fusion_ok(self, c: int) -> bool:
+        """K10 exists for this width in one of its forms (LDS-staged: 128 / 256 in both dtypes; direct: fp16 128 / 192 / 256 / 384)"""
         ok = self._fusion_ok.get(c)
         if ok is None:
-            ok = self._fusion_ok[c] = hip.feature_fusion_supported(c, self.dtype)
+            ok = self._fusion_ok[c] = hip.feature_fusion_supported(c, self.dtype) or self.fusion_frag_ok(c)
         return ok
 
     def k10(self, p: str, z0: Tensor, z1: Tensor, first: Spec, z1_coarse: bool = False) -> Tensor:

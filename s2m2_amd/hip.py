@@ -418,8 +418,9 @@ def mlp_chain_frag_supported(C: int, dtype: torch.dtype) -> bool:
 
 
 def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
-    """the optional LayerNorm output of mlp_chain needs a row of 16 / 32 / 64 16-byte pieces"""
-    return mlp_chain_supported(C, dtype) and C * (2 if dtype == torch.float16 else 4) // 16 in (16, 32, 64)
+    """the optional LayerNorm output of mlp_chain needs a row of 8 k <= 64 16-byte pieces, in either form of the kernel"""
+    ppr = C * (2 if dtype == torch.float16 else 4) // 16
+    return (mlp_chain_supported(C, dtype) or mlp_chain_frag_supported(C, dtype)) and ppr % 8 == 0 and ppr <= 64
 
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,

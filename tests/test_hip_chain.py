@@ -143,7 +143,8 @@ def test_chain_layernorm_second_output(hip, C, dtype, shp, nst):
     err = float((yn.float() - ref).abs().max())
     # fp32: summation order of the statistics only;  fp16: one rounding of an O(1..4) value
     assert err < (2e-5 if dtype == torch.float32 else 4e-3), err
-    assert not hip.mlp_chain_ln_out_supported(384, torch.float16)
+    assert hip.mlp_chain_ln_out_supported(384, torch.float16) and hip.mlp_chain_ln_out_supported(192, torch.float16)
+    assert not hip.mlp_chain_ln_out_supported(192, torch.float32)
 
 
 def test_chain_xcd_placement_hint_changes_nothing_but_the_block_order(hip):
@@ -258,12 +259,109 @@ def test_chain_direct_form_layernorm_output_and_strided_rows(hip):
 
 
 def test_chain_direct_form_rejects_unsupported(hip):
-    assert hip.mlp_chain_frag_supported(128, torch.float16) and hip.mlp_chain_frag_supported(256, torch.float16)
-    assert not hip.mlp_chain_frag_supported(384, torch.float16) and not hip.mlp_chain_frag_supported(128, torch.float32)
-    x = torch.randn(4, 384, device="cuda").half()
-    w = torch.randn(384, 384, device="cuda").half()
+    assert all(hip.mlp_chain_frag_supported(c, torch.float16) for c in (128, 192, 256, 384))
+    assert not hip.mlp_chain_frag_supported(512, torch.float16) and not hip.mlp_chain_frag_supported(128, torch.float32)
+    x = torch.randn(4, 512, device="cuda").half()
+    w = torch.randn(512, 512, device="cuda").half()
     with pytest.raises(RuntimeError, match="weight_frag"):
         hip.mlp_chain(x, [(w, None, 0, None)], frag=True)
+
+
+# ---- the widths of the M and XL models (C = 192 / 384: six / twelve waves per block, rows of 24 / 48 16-byte pieces) ---------------------------
+@pytest.mark.parametrize("C,shp,nst,res_stage,carry,ln_stage,acts,nfan,fan_ln", [
+    (384, (2, 16, 19), 3, 0, True, 1, (0, 1, 0), 3, True),          # the 1/32 attention block of the M model with the next Q|K|V
+    (384, (1, 64, 76), 3, 0, True, 1, (0, 1, 0), 0, False),
+    (384, (1, 5, 7), 2, 1, False, 0, (1, 2), 2, True),
+    (384, (1, 1, 1), 1, 0, False, 0, (1,), 1, False),
+])
+def test_chain_direct_form_c384_equals_row_major_form_bit_for_bit(hip, C, shp, nst, res_stage, carry, ln_stage, acts, nfan, fan_ln):
+    """C = 384 has both forms: the direct form (half a stage of fragments in flight, 12 waves) reproduces the LDS-staged one bit for bit"""
+    test_chain_direct_form_equals_row_major_form_bit_for_bit(hip, C, shp, nst, res_stage, carry, ln_stage, acts, nfan, fan_ln)
+
+
+@pytest.mark.parametrize("C,shp,nst,ln_stage,acts,res_stage,carry", [
+    (192, (2, 50, 61), 3, 1, (0, 1, 0), 0, True),                    # proj + residual + pre-LN FFN (32-row tiles)
+    (192, (2, 128, 152), 3, 1, (0, 1, 0), 0, True),                  # 38912 rows: 64-row tiles
+    (192, (1, 37, 41), 2, -1, (2, 0), -1, False),                    # ConvBlock2D 1x1 branch
+    (192, (1, 9, 30), 2, 0, (1, 0), 1, False),
+    (192, (1, 1, 1), 1, 0, (1,), 0, False),
+    (384, (2, 256, 304), 2, -1, (2, 0), -1, False),                  # the XL model's 1/4 level: 155648 rows
+])
+def test_chain_direct_form_m_xl_widths_vs_torch_and_k5(hip, C, shp, nst, ln_stage, acts, res_stage, carry):
+    """C = 192 exists in the direct form only: against the fp32 reference of the same layers (every stage rounded where the kernel rounds) and
+    against the separate K5 launches it replaces; repeated (no barrier inside a stage: a race would be a flaky mismatch)"""
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(C + nst + shp[1])
+    x = torch.randn(*shp, C, device="cuda", generator=g).to(dtype)
+    res = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 1).to(dtype) if res_stage >= 0 else None
+    raw, packed = _make(C, nst, dtype, ln_stage, acts, 7 * C + nst)
+    ref = _ref(x, raw, res, res_stage, carry, dtype)
+    first = None
+    for _ in range(4):
+        y = hip.mlp_chain(x, _frag(packed), res=res, res_stage=res_stage, carry=carry, frag=True)
+        assert y.shape == x.shape and y.dtype == dtype
+        assert float((y.float() - ref).abs().max()) < 1.5e-2
+        first = y if first is None else first
+        assert torch.equal(y, first)
+    t, outs = x, []
+    for s, (wp, bp, act, ws) in enumerate(packed):                   # the K5 launches: same operands, same rounding points
+        kw = {}
+        if ws is not None:
+            kw["ln_wsum"] = ws
+        if s == res_stage:
+            kw.update(epi=hip.EPI_ADD, aux0=res)
+        t = hip.conv2d([t], wp, bp, 1, 1, C, act=act, **kw)
+        if carry and s == 2:
+            t = (t.float() + outs[0].float()).to(dtype)
+        outs.append(t)
+    assert float((y.float() - t.float()).abs().max()) < 1.5e-2
+
+
+@pytest.mark.parametrize("C,shp,nst,frag", [(192, (2, 50, 61), 3, True), (192, (2, 128, 152), 3, True), (192, (1, 1, 1), 1, True),
+                                            (384, (2, 32, 38), 3, True), (384, (2, 32, 38), 3, False), (384, (1, 5, 7), 2, True)])
+def test_chain_layernorm_second_output_m_xl_widths(hip, C, shp, nst, frag):
+    """rows of 24 / 48 pieces: the LayerNorm output takes its statistics in a second pass over the stored tile (8 lanes per row)"""
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(C + nst)
+    x = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 0.3).to(dtype)
+    res = (torch.randn(*shp, C, device="cuda", generator=g) * 2 + 1).to(dtype)
+    acts = (0, 1, 0)[:nst] if nst == 3 else ((2, 0) if nst == 2 else (1,))
+    raw, packed = _make(C, nst, dtype, 1 if nst == 3 else -1, acts, 3 * C + nst)
+    st = _frag(packed) if frag else packed
+    gam = 1 + 0.1 * torch.randn(C, device="cuda", generator=g)
+    bet = 0.05 * torch.randn(C, device="cuda", generator=g)
+    plain = hip.mlp_chain(x, st, res=res, res_stage=0, carry=nst == 3, frag=frag)
+    for _ in range(3):
+        y, yn = hip.mlp_chain(x, st, res=res, res_stage=0, carry=nst == 3, ln_out=(gam, bet, 1e-5), frag=frag)
+        assert torch.equal(y, plain)
+        ref = F.layer_norm(y.float(), (C,), gam, bet, 1e-5)
+        assert float((yn.float() - ref).abs().max()) < 4e-3
+
+
+@pytest.mark.parametrize("C,shp,nfan,ln,pool", [(192, (2, 128, 152), 3, True, False), (192, (1, 7, 9), 1, False, False), (384, (2, 32, 38), 3, True, False),
+                                                (192, (2, 64, 76), 2, False, True), (384, (1, 9, 7), 1, False, True)])
+def test_fan_only_direct_form_m_xl_widths(hip, C, shp, nfan, ln, pool):
+    dtype = torch.float16
+    g = torch.Generator(device="cuda").manual_seed(C + nfan)
+    wide = (torch.randn(*shp, C + 8, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
+    x = wide[..., :C]
+    wq = (torch.randn(nfan * C, C, 1, 1, device="cuda", generator=g) / math.sqrt(C)).to(dtype)
+    wp = pack.pack_conv(wq, dtype)
+    bp = pack.pack_bias(torch.randn(nfan * C, device="cuda", generator=g) * 0.3, nfan * C)
+    ws = wp.float().sum(1).contiguous() if ln else None
+    assert hip.mlp_fan_supported(C, nfan, dtype)
+    if pool:
+        ref = hip.conv2d([x.contiguous()], wp, bp, 1, 1, nfan * C, pool2=True)
+        y = hip.mlp_fan(x, pack.chain_frag(wp), bp, None, frag=True, pool2=True)
+        assert ref.shape == y.shape and float((y.float() - ref.float()).abs().max()) < 1.5e-2
+        return
+    ref = hip.conv2d([x.contiguous()], wp, bp, 1, 1, nfan * C, **({"ln_wsum": ws} if ln else {}))
+    for _ in range(3):
+        y = hip.mlp_fan(x, pack.chain_frag(wp), bp, ws, frag=True)
+        assert y.shape == ref.shape and float((y.float() - ref.float()).abs().max()) < 1.5e-2
+    t = F.layer_norm(x.float(), (C,)) if ln else x.float()
+    full = F.linear(t, wq.float().reshape(nfan * C, C), bp[:nfan * C])
+    assert float((y.float() - full).abs().max()) < 2e-2
 
 
 @pytest.mark.parametrize("C,shp,nfan,ln", [(256, (2, 32, 38), 3, True), (256, (2, 64, 76), 3, True), (128, (2, 128, 152), 3, True),
@@ -285,7 +383,7 @@ def test_fan_only_direct_form(hip, C, shp, nfan, ln):
         y = hip.mlp_fan(x, wf, bp, ws, frag=True)
         assert y.shape == ref.shape
         assert float((y.float() - ref.float()).abs().max()) < 1.5e-2
-    assert hip.mlp_fan_supported(C, nfan, dtype) and not hip.mlp_fan_supported(384, nfan, dtype) and not hip.mlp_fan_supported(C, nfan, torch.float32)
+    assert hip.mlp_fan_supported(C, nfan, dtype) and not hip.mlp_fan_supported(512, nfan, dtype) and not hip.mlp_fan_supported(C, nfan, torch.float32)
     with pytest.raises(ValueError, match="direct form"):
         hip.mlp_fan(x, wp, bp, ws, frag=False)
     t = F.layer_norm(x.float(), (C,)) if ln else x.float()

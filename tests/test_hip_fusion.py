@@ -30,6 +30,17 @@ def _weights(C, dtype, seed):
     return w1, wg, wf, b1, bg, bf
 
 
+def _fusion_ref(z0, z1, w1, wg, wf, b1, bg, bf, dtype):
+    """feature_fusion.py:24-31 in fp32, every intermediate rounded to the I/O dtype where the kernel rounds it"""
+    C = z0.shape[-1]
+
+    def rd(t):
+        return t.to(dtype).float()
+    h = rd(F.gelu(F.linear(torch.cat([z0.float(), z1.float()], -1), w1.float().reshape(3 * C, 2 * C), b1)))
+    gate = rd(torch.sigmoid(F.linear(h[..., :C], wg.float().reshape(C, C), bg))).clamp(0.01, 0.99)
+    return rd(rd(F.linear(h[..., C:], wf.float().reshape(C, 2 * C), bf)) + rd(gate * z0.float() + (1 - gate) * z1.float()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
 @pytest.mark.parametrize("shape", [(128, (2, 50, 61)), (128, (1, 256, 40)), (128, (1, 1, 1)), (256, (2, 32, 38)), (256, (1, 9, 7)), (256, (2, 64, 76))])
 def test_feature_fusion_vs_torch_and_k5(hip, dtype, shape):
@@ -120,7 +131,38 @@ def test_feature_fusion_direct_form_equals_lds_form_bit_for_bit(hip, C, shp, coa
 
 
 def test_feature_fusion_direct_form_rejects_unsupported(hip):
-    z = torch.zeros(4, 384, device="cuda").half()
+    z = torch.zeros(4, 512, device="cuda").half()
     with pytest.raises(RuntimeError, match="not supported"):
-        hip.feature_fusion(z, z, torch.zeros(9 * 384 * 384, device="cuda").half(), torch.zeros(3 * 384, device="cuda"), None,
-                           torch.zeros(384, device="cuda"), torch.zeros(384, device="cuda"), frag=True)
+        hip.feature_fusion(z, z, torch.zeros(9 * 512 * 512, device="cuda").half(), torch.zeros(3 * 512, device="cuda"), None,
+                           torch.zeros(512, device="cuda"), torch.zeros(512, device="cuda"), frag=True)
+
+
+@pytest.mark.parametrize("C,shp,coarse", [(192, (2, 50, 61), False), (192, (1, 128, 152), True), (192, (2, 128, 152), False), (192, (1, 1, 1), False),
+                                          (384, (2, 32, 38), True), (384, (1, 64, 76), False), (384, (1, 9, 7), True)])
+def test_feature_fusion_direct_form_m_xl_widths(hip, C, shp, coarse):
+    """C = 192 / 384 (the M and XL models) exist in the direct form only: against the fp32 reference of the block (rounded where the kernel
+    rounds) and against the K5 launches it replaces; repeated launches must be bit-identical to each other."""
+    dtype = torch.float16
+    assert hip.feature_fusion_frag_supported(C, dtype) and not hip.feature_fusion_supported(C, dtype)
+    g = torch.Generator(device="cuda").manual_seed(C + shp[1] + 5)
+    n, h, w = shp
+    if coarse:
+        wide = torch.randn(n, 2 * h, 2 * w, C + 8, device="cuda", generator=g).to(dtype)
+        zc = (torch.randn(n, h, w, C, device="cuda", generator=g) * 1.5).to(dtype)
+        z1_full = hip.resample2x(zc, 1)
+    else:
+        wide = torch.randn(n, h, w, C + 8, device="cuda", generator=g).to(dtype)
+        zc = z1_full = (torch.randn(n, h, w, C, device="cuda", generator=g) * 1.5).to(dtype)
+    z0 = wide[..., :C]
+    w1, wg, wf, b1, bg, bf = _weights(C, dtype, 7 * C)
+    p1 = pack.pack_conv(w1, dtype)
+    p2 = torch.cat([pack.pack_conv(wg, dtype), pack.pack_conv(wf, dtype)], dim=1).contiguous()
+    bs = (pack.pack_bias(b1, 3 * C), pack.pack_bias(bg, C), pack.pack_bias(bf, C))
+    stream = pack.fusion_frag(p1, p2)
+    first = None
+    for _ in range(4):
+        y = hip.feature_fusion(z0, zc, stream, bs[0], None, bs[1], bs[2], z1_coarse=coarse, frag=True)
+        first = y if first is None else first
+        assert torch.equal(y, first)
+    ref = _fusion_ref(z0, z1_full, w1, wg, wf, b1, bg, bf, dtype)
+    assert y.shape == ref.shape and float((y.float() - ref).abs().max()) < 2e-2
