@@ -46,52 +46,57 @@ int s2m2_debug_poison_lds(void* stream);
  * uint64 to device memory `out`; two probes around a region of a stream give the average engine clock it ran at (tools/clock_probe.py) */
 int s2m2_debug_clock_probe(void* out, void* stream);
 
-/* Name of the device kernel s2m2_ln_corr dispatches to for this configuration (for rocprof matching). */
+/* Name of the device kernel s2m2_cost_volume dispatches to for this configuration (for rocprof matching). */
 const char* s2m2_ln_corr_kernel_name(int C, int feat_dtype, int cv_dtype);
 
 /*
- * [A4] LayerNorm + all-pairs epipolar correlation  (DispInit.forward, submodules.py:216-217; LayerNorm :165)
- *   feat   (2B, h, w, C) NHWC, left images = batch entries [0,B), right = [B,2B)   dtype feat_dtype
- *   ln_w, ln_b  (C) fp32   LayerNorm affine (eps 1e-5, biased variance)
- *   cv     (B, h, w, w)  cv[b,y,i,j] = < LN(feat[b,y,i,:]), LN(feat[B+b,y,j,:]) >   dtype cv_dtype, j fastest
- *   C in {64,128,192,256,384}; w % 8 == 0.  F16: LN in fp32, operands rounded to fp16, fp32 accumulate (MFMA);
- *   F32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * [A4] K1: (LayerNorm +) all-pairs epipolar correlation = the cost volume  (DispInit.forward, submodules.py:216-217; LayerNorm :165)
+ *   ONE descriptor for every form of the kernel (ABI 500; the five entry points of ABI 400 below are shims over it, kept for one version):
+ *   tokens  (2B, h, w, C) NHWC, left images = batch entries [0,B), right = [B,2B)            dtype token_dtype
+ *   ln_weight, ln_bias  (C) fp32: LayerNorm affine (eps 1e-5, biased variance), applied INSIDE the kernel.  Both NULL: the tokens are
+ *           normalised already (DispInit's layer_norm folded into the launch that produced them: the ln_out rows of s2m2_mlp_chain) and
+ *           the kernel is the batched product R . L^T and its stores alone -- the shipped path at C = 128 / 192 / 256 / 384 in fp16
+ *   cv      cv[b,y,i,j] = < LN(tokens[b,y,i,:]), LN(tokens[B+b,y,j,:]) >  at  cv + ((b*h + y)*w + i)*cv_pitch + j       dtype cv_dtype
+ *   cv_pitch  elements between volume rows, >= w, a multiple of 8 (0 = w).  A multiple of 64 fp16 / 32 fp32 elements (w = 304 -> 320) makes
+ *           every 64-column store granule a whole 128-byte line (then the stores are write-through, sc1); s2m2_sinkhorn_regress and
+ *           s2m2_cv_lookup read the same pitch
+ *   band    -1: the full volume.  >= 0 (use_positivity models): only columns j <= i + band are written (rounded up to the
+ *           64-column store granule), the rest of the buffer is left untouched -- nothing downstream reads beyond band = 11: the Sinkhorn
+ *           mask removes j > i (submodules.py:211-214), the +-4 tap lookups at both pyramid levels reach column i + 11 (submodules.py:39-60)
+ *   start_event, stop_event  optional hipEvent_t (s2m2_event_create): recorded on the kernel dispatch itself (hipExtLaunchKernel), i.e. they
+ *           bracket the kernel's execution like a rocprofv3 kernel trace does, not the gaps around it (bench.py `roofline`); elapsed time
+ *           is valid once the stream has been synchronised
+ *   C in {64,128,192,256,384}; w % 8 == 0.  F16: LN in fp32, operands rounded to fp16, fp32 accumulate (MFMA); F32: exact fp32 MFMA
+ *   (v_mfma_f32_32x32x2_f32).  Pairs (token_dtype, cv_dtype): (F16,F16), (F16,F32), (F32,F32).
  */
+typedef struct s2m2_corr_desc {
+    const void* tokens;
+    const float* ln_weight;
+    const float* ln_bias;
+    void* cv;
+    int B, h, w, C;
+    int cv_pitch;
+    int band;
+    int token_dtype, cv_dtype;
+    void* start_event;
+    void* stop_event;
+} s2m2_corr_desc;
+int s2m2_cost_volume(const s2m2_corr_desc* desc, void* stream);
+
+/* ABI 400 entry points of K1 (shims over s2m2_cost_volume; to be removed with the next ABI version):
+ *   s2m2_ln_corr          LayerNorm inside, dense rows, full volume            s2m2_ln_corr_timed   + events
+ *   s2m2_ln_corr_banded   + band >= 0 + events                                  s2m2_ln_corr_pitched every option
+ *   s2m2_corr             tokens normalised already, every option */
 int s2m2_ln_corr(const void* feat, const float* ln_w, const float* ln_b, void* cv,
                  int B, int h, int w, int C, int feat_dtype, int cv_dtype, void* stream);
-
-/*
- * Measurement support (bench.py `roofline`): the same launch with a start / stop HIP event attached to the kernel dispatch itself
- * (hipExtLaunchKernel), i.e. the events bracket the kernel's execution like a rocprofv3 kernel trace does, not the gaps around it.
- * Events are opaque hipEvent_t handles owned by the caller: create / destroy / read them with the three helpers below
- * (elapsed time is valid once the stream has been synchronised).
- */
 int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, void* cv,
                        int B, int h, int w, int C, int feat_dtype, int cv_dtype, void* stream,
                        void* start_event, void* stop_event);
-/*
- * Banded cost volume for use_positivity models: writes cv[b,y,i,j] only for j <= i + band (rounded up to
- * the kernel's 64-column store granule); the rest of the buffer is left untouched.  With non-negative disparities nothing downstream
- * reads beyond band = 11: the Sinkhorn mask removes j > i (submodules.py:211-214) and the +-4 tap lookups at both pyramid levels
- * reach column i + 11 at most (submodules.py:39-60).  start_event / stop_event may be NULL.
- */
 int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, void* cv,
                         int B, int h, int w, int C, int feat_dtype, int cv_dtype, int band, void* stream,
                         void* start_event, void* stop_event);
-/*
- * [A4] the correlation alone, on tokens that are ALREADY LayerNorm'ed (DispInit's layer_norm folded into the launch that produced them:
- *   the ln_out rows of s2m2_mlp_chain) -- K1 without statistics and affine, the batched product R . L^T and its stores:
- *   tokens (2B, h, w, C) NHWC dtype token_dtype;  cv[b,y,i,j] = < tokens[b,y,i,:], tokens[B+b,y,j,:] > at
- *       cv + ((b*h + y)*w + i)*cv_pitch + j,   cv_pitch >= w, a multiple of 8 (0 = w).  A pitch that is a multiple of 64 fp16 / 32
- *   fp32 elements (w = 304 -> 320) makes every 64-column store granule a whole 128-byte line; s2m2_sinkhorn_regress and
- *   s2m2_cv_lookup read the same pitch.  band >= 0: as s2m2_ln_corr_banded (-1: full volume); start / stop events as
- *   s2m2_ln_corr_timed (may be NULL).
- */
 int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
               void* stream, void* start_event, void* stop_event);
-/* [A4] s2m2_ln_corr (LayerNorm inside K1) with every option of s2m2_corr: cv_pitch (0 = dense rows), band (-1 = full volume) and the
- * start / stop events on the dispatch (may be NULL).  What the engine launches for widths whose producing K9 launch has no LayerNorm
- * output (C = 192, 384) and under S2M2_FUSE_K1LN=0, on the same 128-byte-aligned volume as s2m2_corr. */
 int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
                          int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event);
 int s2m2_event_create(void** event);

@@ -440,14 +440,15 @@ __global__ __launch_bounds__(CFG::NWMAX * 64) void ln_corr_kernel(const T* __res
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
-// s2m2_ln_corr_timed: events attached to the next launch of the calling thread (hipExtLaunchKernel records them at the start and
-// at the end of the kernel's execution)
-static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-static thread_local int g_band = -1;                 // s2m2_ln_corr_banded: columns right of the diagonal that must be valid (-1: all)
-static thread_local int g_pitch = 0;                 // s2m2_corr: elements between volume rows (0: w)
+// options of one launch (s2m2_corr_desc): nothing is passed through globals -- every entry point fills this struct
+struct K1Opt {
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // recorded on the dispatch itself (hipExtLaunchKernel): at the start / end of the kernel's execution
+    int band = -1;                                      // columns right of the diagonal that must be valid (-1: all)
+    int pitch = 0;                                      // elements between volume rows (0: w)
+};
 
 template <typename CFG, typename T, typename TO>
-static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st);
+static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, const K1Opt& o, hipStream_t st);
 
 // normalised-input variant of a configuration (same tiling)
 template <typename CFG> struct PrenormOf;
@@ -455,30 +456,32 @@ template <typename T, typename TO, int C, int NWCAP, int RIF, bool EB, int TPW>
 struct PrenormOf<LnCorrCfg<T, TO, C, NWCAP, RIF, EB, TPW, false>> { using type = LnCorrCfg<T, TO, C, NWCAP, RIF, EB, TPW, true>; };
 
 template <typename CFG, typename T, typename TO>
-static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, hipStream_t st) {
+static int launch_ln_corr(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, const K1Opt& o, hipStream_t st) {
     auto kern = ln_corr_kernel<CFG, T, TO>;
     static size_t lds_granted[kMaxDevices] = {};                     // per instantiation
     if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::lds_bytes(CFG::NWMAX), lds_granted, "ln_corr")) return 1;
     const int tiles = (w + 31) / 32;                     // 32-pixel row tiles = waves needed per image row
     int nstrip = (tiles + CFG::NWMAX - 1) / CFG::NWMAX;
-    // small problems: split rows into strips until the grid covers the chip (each strip re-normalises the right row)
-    while (B * h * nstrip < 200 && nstrip < tiles && (tiles + nstrip) / (nstrip + 1) >= 2) ++nstrip;
+    // small problems: split rows into strips until the grid covers the chip (each strip re-reads / re-normalises the right row).
+    // S2M2_K1_MINBLOCKS (experiment switch): the block count below which a row is split further
+    static const int minblocks = getenv("S2M2_K1_MINBLOCKS") ? atoi(getenv("S2M2_K1_MINBLOCKS")) : 200;
+    while (B * h * nstrip < minblocks && nstrip < tiles && (tiles + nstrip) / (nstrip + 1) >= (minblocks > 200 ? 1 : 2)) ++nstrip;
     int nw = (tiles + nstrip - 1) / nstrip;
     nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;
-    const int pitch = g_pitch > 0 ? g_pitch : w;
+    const int pitch = o.pitch > 0 ? o.pitch : w;
     // cache policy of the volume stores (store_cv): sc1 write-through by default -- measured (profiles/r04/k1_store_modes.txt, ab_k1_store_sc1lib_overlap.txt)
     // 19.2 -> 16.8 us back to back and 19.7-20.7 -> 17.7 us inside the forward against the write-back default of rounds 1-3; S2M2_K1_NT=0..4 A/B
     // (only for volume rows on 128-byte lines: a write-through store of a PARTIAL line is a read-modify-write at the memory side -- dense 608-byte
     // rows measured 25.0 us with sc1 against 21.8 with plain stores, profiles/r04/kbench.txt; the engine always allocates aligned rows)
     static const int k1_env = getenv("S2M2_K1_NT") ? atoi(getenv("S2M2_K1_NT")) : -1;
     const int k1_flags = k1_env >= 0 ? k1_env : ((pitch * (int)sizeof(TO)) % 128 == 0 ? 2 : 0);
-    if (g_ev_start || g_ev_stop)
-        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, g_ev_start, g_ev_stop, 0,
-                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
+    if (o.ev_start || o.ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st, o.ev_start, o.ev_stop, 0,
+                              static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, o.band, pitch, k1_flags);
     else
         hipLaunchKernelGGL(kern, dim3(nblocks), dim3(nw * 64), CFG::lds_bytes(nw), st,
-                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, g_band, pitch, k1_flags);
+                           static_cast<const T*>(feat), g, bta, static_cast<TO*>(cv), B, h, w, nstrip, o.band, pitch, k1_flags);
     return check_launch("ln_corr");
 }
 
@@ -497,13 +500,13 @@ template <> struct LnCorrPick<float, 256>  { template <typename TO> using cfg = 
 template <> struct LnCorrPick<float, 384>  { template <typename TO> using cfg = LnCorrCfg<float, TO, 384, 4, 1, false>; };
 
 template <typename T, typename TO, bool PRENORM = false>
-static int dispatch_c(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, int C, hipStream_t st) {
+static int dispatch_c(const void* feat, const float* g, const float* bta, void* cv, int B, int h, int w, int C, const K1Opt& o, hipStream_t st) {
     switch (C) {
 #define S2M2_CASE(CC)                                                                                                        \
     case CC: {                                                                                                               \
         using BASE = typename LnCorrPick<T, CC>::template cfg<TO>;                                                           \
         using CFG = typename std::conditional<PRENORM, typename PrenormOf<BASE>::type, BASE>::type;                          \
-        return launch_ln_corr<CFG, T, TO>(feat, g, bta, cv, B, h, w, st);                                                    \
+        return launch_ln_corr<CFG, T, TO>(feat, g, bta, cv, B, h, w, o, st);                                                 \
     }
         S2M2_CASE(64) S2M2_CASE(128) S2M2_CASE(192) S2M2_CASE(256) S2M2_CASE(384)
 #undef S2M2_CASE
@@ -513,70 +516,73 @@ static int dispatch_c(const void* feat, const float* g, const float* bta, void* 
 
 }  // namespace s2m2
 
+extern "C" int s2m2_cost_volume(const s2m2_corr_desc* d, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(d, "cost_volume: null descriptor");
+    S2M2_REQUIRE(d->tokens && d->cv, "cost_volume: null pointer");
+    S2M2_REQUIRE((d->ln_weight == nullptr) == (d->ln_bias == nullptr), "cost_volume: ln_weight and ln_bias come together (both null: the tokens are normalised already)");
+    S2M2_REQUIRE(d->B > 0 && d->h > 0 && d->w > 0, "cost_volume: bad shape B=%d h=%d w=%d", d->B, d->h, d->w);
+    S2M2_REQUIRE(d->w % 8 == 0, "cost_volume: w=%d must be a multiple of 8 (image width multiple of 32)", d->w);
+    const int pitch = d->cv_pitch == 0 ? d->w : d->cv_pitch;
+    S2M2_REQUIRE(pitch >= d->w && pitch % 8 == 0, "cost_volume: cv_pitch=%d must be a multiple of 8 and at least w=%d", d->cv_pitch, d->w);
+    S2M2_REQUIRE(d->band >= -1, "cost_volume: band=%d (-1: the full volume, >= 0: columns j <= i + band)", d->band);
+    K1Opt o;
+    o.ev_start = static_cast<hipEvent_t>(d->start_event);
+    o.ev_stop = static_cast<hipEvent_t>(d->stop_event);
+    o.band = d->band;
+    o.pitch = pitch;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int td = d->token_dtype, cd = d->cv_dtype;
+    if (d->ln_weight) {
+        if (td == S2M2_F16 && cd == S2M2_F16) return dispatch_c<half_t, half_t>(d->tokens, d->ln_weight, d->ln_bias, d->cv, d->B, d->h, d->w, d->C, o, st);
+        if (td == S2M2_F16 && cd == S2M2_F32) return dispatch_c<half_t, float>(d->tokens, d->ln_weight, d->ln_bias, d->cv, d->B, d->h, d->w, d->C, o, st);
+        if (td == S2M2_F32 && cd == S2M2_F32) return dispatch_c<float, float>(d->tokens, d->ln_weight, d->ln_bias, d->cv, d->B, d->h, d->w, d->C, o, st);
+    } else {
+        if (td == S2M2_F16 && cd == S2M2_F16) return dispatch_c<half_t, half_t, true>(d->tokens, nullptr, nullptr, d->cv, d->B, d->h, d->w, d->C, o, st);
+        if (td == S2M2_F16 && cd == S2M2_F32) return dispatch_c<half_t, float, true>(d->tokens, nullptr, nullptr, d->cv, d->B, d->h, d->w, d->C, o, st);
+        if (td == S2M2_F32 && cd == S2M2_F32) return dispatch_c<float, float, true>(d->tokens, nullptr, nullptr, d->cv, d->B, d->h, d->w, d->C, o, st);
+    }
+    return set_error("cost_volume: unsupported dtype pair tokens=%d cv=%d", td, cd);
+}
+
+// ---- the entry points of ABI versions up to 400: shims over s2m2_cost_volume, kept for one ABI version -------------------------------
+static int k1_shim(const void* tokens, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
+                   int token_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
+    s2m2_corr_desc d = {};
+    d.tokens = tokens; d.ln_weight = ln_w; d.ln_bias = ln_b; d.cv = cv;
+    d.B = B; d.h = h; d.w = w; d.C = C; d.cv_pitch = cv_pitch; d.band = band < 0 ? -1 : band;
+    d.token_dtype = token_dtype; d.cv_dtype = cv_dtype; d.start_event = start_event; d.stop_event = stop_event;
+    return s2m2_cost_volume(&d, stream);
+}
+
 extern "C" int s2m2_ln_corr(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
                             int feat_dtype, int cv_dtype, void* stream) {
-    using namespace s2m2;
-    S2M2_REQUIRE(feat && ln_w && ln_b && cv, "ln_corr: null pointer");
-    S2M2_REQUIRE(B > 0 && h > 0 && w > 0, "ln_corr: bad shape B=%d h=%d w=%d", B, h, w);
-    S2M2_REQUIRE(w % 8 == 0, "ln_corr: w=%d must be a multiple of 8 (image width multiple of 32)", w);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (feat_dtype == S2M2_F16 && cv_dtype == S2M2_F16) return dispatch_c<half_t, half_t>(feat, ln_w, ln_b, cv, B, h, w, C, st);
-    if (feat_dtype == S2M2_F16 && cv_dtype == S2M2_F32) return dispatch_c<half_t, float>(feat, ln_w, ln_b, cv, B, h, w, C, st);
-    if (feat_dtype == S2M2_F32 && cv_dtype == S2M2_F32) return dispatch_c<float, float>(feat, ln_w, ln_b, cv, B, h, w, C, st);
-    return set_error("ln_corr: unsupported dtype pair feat=%d cv=%d", feat_dtype, cv_dtype);
+    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
+    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, 0, feat_dtype, cv_dtype, -1, stream, nullptr, nullptr);
 }
 
 extern "C" int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
                                   int feat_dtype, int cv_dtype, void* stream, void* start_event, void* stop_event) {
-    s2m2::g_ev_start = static_cast<hipEvent_t>(start_event);
-    s2m2::g_ev_stop = static_cast<hipEvent_t>(stop_event);
-    const int rc = s2m2_ln_corr(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream);
-    s2m2::g_ev_start = s2m2::g_ev_stop = nullptr;
-    return rc;
+    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
+    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, 0, feat_dtype, cv_dtype, -1, stream, start_event, stop_event);
 }
 
 extern "C" int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
                                    int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
     S2M2_REQUIRE(band >= 0, "ln_corr_banded: band=%d must be >= 0 (use s2m2_ln_corr for the full volume)", band);
-    s2m2::g_band = band;
-    const int rc = s2m2_ln_corr_timed(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream, start_event, stop_event);
-    s2m2::g_band = -1;
-    return rc;
+    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
+    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, 0, feat_dtype, cv_dtype, band, stream, start_event, stop_event);
 }
 
 extern "C" int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
                                     int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
-    if (cv_pitch == 0) cv_pitch = w;
-    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "ln_corr_pitched: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
-    s2m2::g_pitch = cv_pitch;
-    s2m2::g_band = band >= 0 ? band : -1;
-    const int rc = s2m2_ln_corr_timed(feat, ln_w, ln_b, cv, B, h, w, C, feat_dtype, cv_dtype, stream, start_event, stop_event);
-    s2m2::g_band = -1;
-    s2m2::g_pitch = 0;
-    return rc;
+    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
+    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, cv_pitch, feat_dtype, cv_dtype, band, stream, start_event, stop_event);
 }
 
 extern "C" int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
                          void* stream, void* start_event, void* stop_event) {
-    using namespace s2m2;
-    S2M2_REQUIRE(tokens && cv, "corr: null pointer");
-    S2M2_REQUIRE(B > 0 && h > 0 && w > 0 && w % 8 == 0, "corr: bad shape B=%d h=%d w=%d (w a multiple of 8)", B, h, w);
-    if (cv_pitch == 0) cv_pitch = w;
-    S2M2_REQUIRE(cv_pitch >= w && cv_pitch % 8 == 0, "corr: cv_pitch=%d must be a multiple of 8 and at least w=%d", cv_pitch, w);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    g_ev_start = static_cast<hipEvent_t>(start_event);
-    g_ev_stop = static_cast<hipEvent_t>(stop_event);
-    g_band = band >= 0 ? band : -1;
-    g_pitch = cv_pitch;
-    int rc;
-    if (token_dtype == S2M2_F16 && cv_dtype == S2M2_F16) rc = dispatch_c<half_t, half_t, true>(tokens, nullptr, nullptr, cv, B, h, w, C, st);
-    else if (token_dtype == S2M2_F16 && cv_dtype == S2M2_F32) rc = dispatch_c<half_t, float, true>(tokens, nullptr, nullptr, cv, B, h, w, C, st);
-    else if (token_dtype == S2M2_F32 && cv_dtype == S2M2_F32) rc = dispatch_c<float, float, true>(tokens, nullptr, nullptr, cv, B, h, w, C, st);
-    else rc = set_error("corr: unsupported dtype pair tokens=%d cv=%d", token_dtype, cv_dtype);
-    g_ev_start = g_ev_stop = nullptr;
-    g_band = -1;
-    g_pitch = 0;
-    return rc;
+    return k1_shim(tokens, nullptr, nullptr, cv, B, h, w, C, cv_pitch, token_dtype, cv_dtype, band, stream, start_event, stop_event);
 }
 
 extern "C" int s2m2_event_create(void** event) {

@@ -58,6 +58,12 @@ class NarrowDesc(ctypes.Structure):
                 ("act", _i), ("dtype", _i), ("head_frag", _vp), ("head_bias", _vp), ("head_cout", _i)]
 
 
+class CorrDesc(ctypes.Structure):
+    """mirror of s2m2_corr_desc (include/s2m2_hip.h): every form of K1"""
+    _fields_ = [("tokens", _vp), ("ln_weight", _vp), ("ln_bias", _vp), ("cv", _vp), ("B", _i), ("h", _i), ("w", _i), ("C", _i),
+                ("cv_pitch", _i), ("band", _i), ("token_dtype", _i), ("cv_dtype", _i), ("start_event", _vp), ("stop_event", _vp)]
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
 ABI_VERSION = 500                     # include/s2m2_hip.h: S2M2_ABI_VERSION (checked in load())
 
@@ -65,6 +71,7 @@ SIGNATURES = {
     "s2m2_version": (_i, []),
     "s2m2_last_error": (ctypes.c_char_p, []),
     "s2m2_ln_corr_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
+    "s2m2_cost_volume": (_i, [ctypes.POINTER(CorrDesc), _vp]),
     "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "s2m2_ln_corr_timed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_ln_corr_banded": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -180,10 +187,28 @@ class KernelTimer:
             pass
 
 
+def _cost_volume(tokens: torch.Tensor, ln, cv: torch.Tensor, timer, band: int, what: str) -> None:
+    """one launch of K1 through its descriptor (s2m2_cost_volume); ln = (weight, bias) fp32 or None (tokens normalised already)"""
+    twoB, h, w, C = tokens.shape
+    d = CorrDesc()
+    d.tokens, d.cv = tokens.data_ptr(), cv.data_ptr()
+    keep = None
+    if ln is not None:
+        keep = (ln[0].float().contiguous(), ln[1].float().contiguous())
+        d.ln_weight, d.ln_bias = keep[0].data_ptr(), keep[1].data_ptr()
+    d.B, d.h, d.w, d.C = twoB // 2, h, w, C
+    d.cv_pitch, d.band = _cv_pitch(cv, what), band if band >= 0 else -1
+    d.token_dtype, d.cv_dtype = _DT[tokens.dtype], _DT[cv.dtype]
+    if timer is not None:
+        d.start_event, d.stop_event = timer.start, timer.stop
+    _check(load().s2m2_cost_volume(ctypes.byref(d), _stream()), "s2m2_cost_volume")
+    _meter("ln_corr", 2.0 * (twoB // 2) * h * w * w * C)
+
+
 def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype: Optional[torch.dtype] = None,
             out: Optional[torch.Tensor] = None, timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
-    """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w).  [A4]   timer: see KernelTimer.  band >= 0: only
-    columns j <= i + band are written, the rest of ``cv`` keeps whatever it held.  ``out`` may be a row-padded view (cv_alloc)."""
+    """feat (2B,h,w,C) channels-last tokens (left = first B) -> cv (B,h,w,w), LayerNorm inside the kernel.  [A4]   timer: see KernelTimer.
+    band >= 0: only columns j <= i + band are written, the rest of ``cv`` keeps whatever it held.  ``out`` may be a row-padded view (cv_alloc)."""
     _dev(feat, ln_w, ln_b)
     twoB, h, w, C = feat.shape
     B = twoB // 2
@@ -191,11 +216,7 @@ def ln_corr(feat: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, cv_dtype
     cv = out if out is not None else torch.empty((B, h, w, w), device=feat.device, dtype=cv_dtype)
     if tuple(cv.shape) != (B, h, w, w):
         raise ValueError("ln_corr: out must be a (B,h,w,w) tensor")
-    pitch = _cv_pitch(cv, "ln_corr")
-    _check(load().s2m2_ln_corr_pitched(feat.data_ptr(), ln_w.float().data_ptr(), ln_b.float().data_ptr(), cv.data_ptr(), B, h, w, C, pitch,
-                                       _DT[feat.dtype], _DT[cv.dtype], band, _stream(),
-                                       timer.start if timer is not None else None, timer.stop if timer is not None else None), "s2m2_ln_corr_pitched")
-    _meter("ln_corr", 2.0 * B * h * w * w * C)
+    _cost_volume(feat, (ln_w, ln_b), cv, timer, band, "ln_corr")
     return cv
 
 
@@ -222,17 +243,14 @@ def cv_alloc(B: int, h: int, w: int, dtype: torch.dtype, device, aligned: bool =
 def corr(tokens: torch.Tensor, cv_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None,
          timer: Optional[KernelTimer] = None, band: int = -1) -> torch.Tensor:
     """tokens (2B,h,w,C) ALREADY LayerNorm'ed (left = first B) -> cv (B,h,w,w), a row-padded view (cv_alloc) unless ``out`` is given.
-    [A4 without the LayerNorm: s2m2_corr]"""
+    [A4 without the LayerNorm: s2m2_cost_volume with ln_weight = NULL]"""
     _dev(tokens)
     twoB, h, w, C = tokens.shape
     B = twoB // 2
     cv = out if out is not None else cv_alloc(B, h, w, cv_dtype or tokens.dtype, tokens.device)
     if tuple(cv.shape) != (B, h, w, w):
         raise ValueError("corr: out must be a (B,h,w,w) tensor")
-    pitch = _cv_pitch(cv, "corr")
-    _check(load().s2m2_corr(tokens.data_ptr(), cv.data_ptr(), B, h, w, C, pitch, _DT[tokens.dtype], _DT[cv.dtype], band, _stream(),
-                            timer.start if timer is not None else None, timer.stop if timer is not None else None), "s2m2_corr")
-    _meter("ln_corr", 2.0 * B * h * w * w * C)
+    _cost_volume(tokens, None, cv, timer, band, "corr")
     return cv
 
 

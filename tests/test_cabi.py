@@ -74,9 +74,9 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     c.C, c.carry, c.res_stage = 128, 1, -1
     c.weight[0] = c.weight[1] = 4096
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"carry" in lib.s2m2_last_error()
-    # round 3: the direct form (weight_frag) exists for fp16 C = 128 / 256 only; the pooled tile load needs it and whole pooled images
+    # the direct form (weight_frag) exists for fp16 C = 128 / 192 / 256 / 384 only; the pooled tile load needs it and whole pooled images
     c = hip.ChainDesc()
-    c.x, c.out, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.out_stride, c.res_stage = 4096, 4096, 384, 1, hip.F16, 8, 384, 384, -1
+    c.x, c.out, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.out_stride, c.res_stage = 4096, 4096, 512, 1, hip.F16, 8, 512, 512, -1
     c.weight[0], c.weight_frag = 4096, 1
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"weight_frag" in lib.s2m2_last_error()
     c.C, c.x_stride, c.out_stride, c.dtype = 128, 128, 128, hip.F32
@@ -125,6 +125,20 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"act=" in lib.s2m2_last_error()
     nd.act, nd.head_cout, nd.head_frag = hip.ACT_RELU, 16, 4096                                                  # the fused head: 48-channel form only
     assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"fused 1x1 head" in lib.s2m2_last_error()
+    # round 5: K1 through one descriptor; the ABI 400 entry points are shims over it
+    assert lib.s2m2_cost_volume(None, None) != 0 and b"null descriptor" in lib.s2m2_last_error()
+    kd = hip.CorrDesc()
+    kd.tokens, kd.cv, kd.B, kd.h, kd.w, kd.C, kd.band, kd.token_dtype, kd.cv_dtype = 4096, 4096, 1, 2, 12, 128, -1, hip.F16, hip.F16
+    assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0 and b"multiple of 8" in lib.s2m2_last_error()
+    kd.w, kd.cv_pitch = 16, 12
+    assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0 and b"cv_pitch" in lib.s2m2_last_error()
+    kd.cv_pitch, kd.ln_weight = 0, 4096
+    assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0 and b"come together" in lib.s2m2_last_error()
+    kd.ln_weight, kd.band = None, -2
+    assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0 and b"band" in lib.s2m2_last_error()
+    kd.band, kd.token_dtype = -1, hip.F32
+    assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0 and b"dtype pair" in lib.s2m2_last_error()
+    assert lib.s2m2_corr(None, None, 1, 2, 16, 128, 0, hip.F16, hip.F16, -1, None, None, None) != 0 and b"null pointer" in lib.s2m2_last_error()
     assert lib.s2m2_feature_fusion_supported(128, hip.F16) == 1 and lib.s2m2_feature_fusion_supported(384, hip.F16) == 0
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 64, 192, 4096, 4096, 4096, 4096, 4096, 0, 0, hip.F16, None) != 0
     assert b"not supported" in lib.s2m2_last_error()
@@ -133,7 +147,7 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_feature_fusion_frag_supported(256, hip.F16) == 1 and lib.s2m2_feature_fusion_frag_supported(128, hip.F32) == 0
     assert lib.s2m2_feature_fusion_frag(4096, 4096, 4096, 128, 128, 128, 64, 128, 4096, 4096, 4096, 4096, 0, 0, hip.F32, None) != 0
     assert b"not supported" in lib.s2m2_last_error()
-    assert lib.s2m2_mlp_chain_frag_supported(128, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(512, hip.F16) == 0
+    assert lib.s2m2_mlp_chain_frag_supported(128, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(384, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(512, hip.F16) == 0
     assert lib.s2m2_stem_mlp(None, None, None, None, None, None, 8, hip.F16, None) != 0
 
 
@@ -164,7 +178,8 @@ def test_descriptor_structs_have_the_layout_of_the_header(tmp_path):
     if shutil.which("gcc") is None:
         pytest.skip("no gcc")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    pairs = [("s2m2_conv_desc", hip.ConvDesc), ("s2m2_chain_desc", hip.ChainDesc), ("s2m2_pw_desc", hip.PwDesc), ("s2m2_narrow_desc", hip.NarrowDesc)]
+    pairs = [("s2m2_conv_desc", hip.ConvDesc), ("s2m2_chain_desc", hip.ChainDesc), ("s2m2_pw_desc", hip.PwDesc), ("s2m2_narrow_desc", hip.NarrowDesc),
+             ("s2m2_corr_desc", hip.CorrDesc)]
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "s2m2_hip.h"', "int main(void) {"]
     for cname, py in pairs:
         last = py._fields_[-1][0]
