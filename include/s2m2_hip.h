@@ -99,6 +99,35 @@ int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_p
               void* stream, void* start_event, void* stop_event);
 int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
                          int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event);
+/*
+ * Weight packing into the MFMA-fragment orders of the direct-form kernels (ABI 500; up to ABI 400 these permutations lived in the Python
+ * binding, s2m2_amd/pack.py, and a C caller had to re-derive them).  Input: the PLAIN packing of a layer -- (rows = Cout padded to 8, cols = K)
+ * row-major fp16 with K = (tap, channel), channel fastest, every source's channel count padded to 8 (what
+ * conv.weight.permute(0, 2, 3, 1).reshape(Cout, -1) gives for an unpadded layer; ld = elements between rows, 0 = cols).  Output: the stream the
+ * kernel consumes, s2m2_pack_frag_elems() fp16 elements (-1: bad descriptor):
+ *   S2M2_PACK_ROWS       s2m2_chain_desc.weight / fan_weight with weight_frag = 1 (K9; stack the layers of fan_weight along rows),
+ *                        s2m2_pw_desc.weight_frag (K11): [row tile of 32][k16 step][lane][8], zero padded to whole tiles / steps
+ *   S2M2_PACK_NARROW     s2m2_narrow_desc.weight_frag (K12), ntap = KH * KW: as ROWS; layers on >= 128 input channels in chunks of 64
+ *   S2M2_PACK_CONV_FRAG  s2m2_conv_desc.weight with korder = 2 (K5 v5), ntap = KH * KW: [cout tile][128-channel chunk][tap][k16 step]
+ *   S2M2_PACK_FUSION     s2m2_feature_fusion_frag's stream (K10): w = the first layers [feature_gate.0 ; feature_fusion.0] (3C, 2C) given as
+ *                        rows = C, cols = 2C, w2 = [feature_gate.2 | feature_fusion.2] (C, 3C) (ld2: its row stride, 0 = 3C)
+ *   S2M2_PACK_HEAD       s2m2_narrow_desc.head_frag: the 1x1 layer (rows <= 32 couts, cols = the 3x3 layer's couts) fused behind a K12 layer
+ * One-time synchronous set-up (allocates and frees a small index map, waits for the stream): not for use under stream capture.
+ */
+enum { S2M2_PACK_ROWS = 0, S2M2_PACK_NARROW = 1, S2M2_PACK_CONV_FRAG = 2, S2M2_PACK_FUSION = 3, S2M2_PACK_HEAD = 4 };
+typedef struct s2m2_pack_desc {
+    int kind;
+    const void* w;
+    const void* w2;
+    int rows, cols;
+    int ld, ld2;
+    int ntap;
+    void* out;
+    long long out_elems;
+} s2m2_pack_desc;
+long long s2m2_pack_frag_elems(const s2m2_pack_desc* desc);
+int s2m2_pack_frag(const s2m2_pack_desc* desc, void* stream);
+
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);

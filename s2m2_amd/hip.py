@@ -64,6 +64,15 @@ class CorrDesc(ctypes.Structure):
                 ("cv_pitch", _i), ("band", _i), ("token_dtype", _i), ("cv_dtype", _i), ("start_event", _vp), ("stop_event", _vp)]
 
 
+class PackDesc(ctypes.Structure):
+    """mirror of s2m2_pack_desc (include/s2m2_hip.h): weight packing into the fragment orders of the direct-form kernels"""
+    _fields_ = [("kind", _i), ("w", _vp), ("w2", _vp), ("rows", _i), ("cols", _i), ("ld", _i), ("ld2", _i), ("ntap", _i), ("out", _vp),
+                ("out_elems", _ll)]
+
+
+PACK_ROWS, PACK_NARROW, PACK_CONV_FRAG, PACK_FUSION, PACK_HEAD = range(5)
+
+
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
 ABI_VERSION = 500                     # include/s2m2_hip.h: S2M2_ABI_VERSION (checked in load())
 
@@ -72,6 +81,8 @@ SIGNATURES = {
     "s2m2_last_error": (ctypes.c_char_p, []),
     "s2m2_ln_corr_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
     "s2m2_cost_volume": (_i, [ctypes.POINTER(CorrDesc), _vp]),
+    "s2m2_pack_frag_elems": (_ll, [ctypes.POINTER(PackDesc)]),
+    "s2m2_pack_frag": (_i, [ctypes.POINTER(PackDesc), _vp]),
     "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "s2m2_ln_corr_timed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_ln_corr_banded": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -163,6 +174,28 @@ def _dev(*ts: torch.Tensor) -> None:
     for t in ts:
         if t is not None and (not t.is_cuda or not t.is_contiguous()):
             raise ValueError("s2m2_amd.hip: tensors must be contiguous device tensors")
+
+
+def pack_frag(kind: int, w: torch.Tensor, w2: Optional[torch.Tensor] = None, ntap: int = 1, rows: Optional[int] = None) -> torch.Tensor:
+    """s2m2_pack_frag: the plain packing ``w`` (rows, K) fp16 on the device -> flat fp16 tensor holding the fragment stream of the direct-form
+    kernel named by ``kind`` (PACK_ROWS / PACK_NARROW / PACK_CONV_FRAG / PACK_FUSION / PACK_HEAD; include/s2m2_hip.h).  One-time set-up."""
+    if w.dtype != torch.float16 or not w.is_cuda or w.dim() != 2 or w.stride(1) != 1:
+        raise ValueError("pack_frag: w must be a 2-D fp16 device tensor with contiguous rows")
+    d = PackDesc()
+    d.kind, d.w, d.rows, d.cols, d.ld, d.ntap = kind, w.data_ptr(), rows if rows is not None else w.shape[0], w.shape[1], w.stride(0), ntap
+    if w2 is not None:
+        if w2.dtype != torch.float16 or not w2.is_cuda or w2.dim() != 2 or w2.stride(1) != 1:
+            raise ValueError("pack_frag: w2 must be a 2-D fp16 device tensor with contiguous rows")
+        d.w2, d.ld2 = w2.data_ptr(), w2.stride(0)
+    lib = load()
+    n = lib.s2m2_pack_frag_elems(ctypes.byref(d))
+    if n < 0:
+        raise RuntimeError(f"s2m2_pack_frag_elems failed: {lib.s2m2_last_error().decode()}")
+    out = torch.empty(n, device=w.device, dtype=torch.float16)
+    d.out, d.out_elems = out.data_ptr(), n
+    with torch.cuda.device(w.device):
+        _check(lib.s2m2_pack_frag(ctypes.byref(d), _stream()), "s2m2_pack_frag")
+    return out
 
 
 class KernelTimer:

@@ -2,12 +2,23 @@
 
 All layouts are (Cout_padded, KH*KW*Cin_padded), K = (tap, channel) with channel fastest.  Channel counts are padded to
 multiples of 8 with zero weights so that every activation row is made of whole 16-byte pieces.
+
+The MFMA-fragment orders of the direct-form kernels (chain_frag, pw_frag, narrow_frag, head_frag, fusion_frag, the K order 2 of
+pack_conv_frag) are produced by the LIBRARY (s2m2_pack_frag, csrc/pack.hip) whenever the plain packing sits on the device: a caller of the
+C ABI gets the same streams without this module.  The torch formulas below remain for CPU tensors; tests/test_hip_pack.py holds the two
+bit for bit against each other.
 """
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
 import torch
+
+
+def _native(w: torch.Tensor) -> bool:
+    """the library packs: fp16 plain packing on a GPU (S2M2_PACK_TORCH=1 forces the torch formulas: A/B and tests)"""
+    import os
+    return w.is_cuda and w.dtype == torch.float16 and os.environ.get("S2M2_PACK_TORCH") != "1"
 
 
 def pad8(c: int) -> int:
@@ -74,9 +85,14 @@ def pack_conv_frag(w: torch.Tensor, dtype: torch.dtype, splits: Optional[Sequenc
     [Cout/32][chunk][tap][k16 step][lane][8] with lane l holding cout 32t + l % 32, channels 128*chunk + 16*step + 8*(l // 32) + e
     (zero beyond Cin).  Returned as (Cout, KH*KW*nchunk*128): same row count as K order 0, K padded to whole chunks."""
     assert dtype == torch.float16
-    wp = pack_conv(w, torch.float32, splits)                      # (Cout_p, KH*KW*Cin_p), K = (tap, channel)
     kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
     ntap = kh * kw
+    if w.is_cuda and _native(w.new_empty(0, dtype=dtype)):
+        from . import hip
+        plain = pack_conv(w, dtype, splits)                       # rounded to fp16 first: the same values the torch formula rounds last
+        assert plain.shape[0] % 32 == 0, plain.shape
+        return hip.pack_frag(hip.PACK_CONV_FRAG, plain, ntap=ntap).reshape(plain.shape[0], -1)
+    wp = pack_conv(w, torch.float32, splits)                      # (Cout_p, KH*KW*Cin_p), K = (tap, channel)
     cop, cin = wp.shape[0], wp.shape[1] // ntap
     assert cop % 32 == 0, cop
     nchunk = (cin + FRAG_CH - 1) // FRAG_CH
@@ -95,6 +111,9 @@ def chain_frag(wp: torch.Tensor) -> torch.Tensor:
     shape and values, permuted."""
     rows, C = wp.shape
     assert rows % C == 0 and C % 32 == 0, (rows, C)
+    if _native(wp):
+        from . import hip
+        return hip.pack_frag(hip.PACK_ROWS, wp).reshape(rows, C)
     t = wp.reshape(rows // C, C // 32, 32, C // 16, 2, 8).permute(0, 1, 3, 4, 2, 5)       # (layer, tile, step, half, l % 32, e)
     return t.contiguous().reshape(rows, C)
 
@@ -104,6 +123,9 @@ def pw_frag(wp: torch.Tensor) -> torch.Tensor:
     s2m2_pw_direct: zero-padded to (32 * tiles, 16 * steps), then [tile][step][lane][8] with lane l holding row 32 t + l % 32, columns
     16 s + 8 (l // 32) + e."""
     cout, k = wp.shape
+    if _native(wp):
+        from . import hip
+        return hip.pack_frag(hip.PACK_ROWS, wp).reshape((cout + 31) // 32, (k + 15) // 16, 64, 8)
     full = wp.new_zeros(((cout + 31) // 32 * 32, (k + 15) // 16 * 16))
     full[:cout, :k] = wp
     return _frag_rows(full).contiguous()
@@ -116,6 +138,10 @@ def narrow_frag(wp: torch.Tensor, ntap: int) -> torch.Tensor:
     cout, k = wp.shape
     cin = k // ntap
     assert cin * ntap == k
+    if _native(wp):
+        from . import hip
+        assert cin < 128 or cin % 64 == 0, cin
+        return hip.pack_frag(hip.PACK_NARROW, wp, ntap=ntap).reshape((cout + 31) // 32, (k + 15) // 16, 64, 8)
     if cin >= 128:
         assert cin % 64 == 0, cin
         wp = wp.reshape(cout, ntap, cin // 64, 64).permute(0, 2, 1, 3).reshape(cout, k)
@@ -130,6 +156,9 @@ def head_frag(w2: torch.Tensor) -> torch.Tensor:
     r, k = w2.shape
     assert r <= 32, r
     nj = (k + 31) // 32
+    if _native(w2):
+        from . import hip
+        return hip.pack_frag(hip.PACK_HEAD, w2).reshape(1, nj * 2, 64, 8)
     full = w2.new_zeros((32, nj * 32))
     full[:r, :k] = w2
     t = full.reshape(32, nj, 2, 2, 2, 4)                          # row, j, p, q, half, e   (channel = 32 j + 8 (2 p + q) + 4 half + e)
@@ -148,6 +177,9 @@ def fusion_frag(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     Flat tensor of 9*C*C values."""
     C = w2.shape[0]
     assert tuple(w1.shape) == (3 * C, 2 * C) and tuple(w2.shape) == (C, 3 * C) and C % 32 == 0
+    if _native(w1) and _native(w2):
+        from . import hip
+        return hip.pack_frag(hip.PACK_FUSION, w1, w2=w2, rows=C)
     parts = []
     for s in range(3):
         parts.append(_frag_rows(w1[s * C:(s + 1) * C]))                          # (C/32, 2C/16, 64, 8)
