@@ -128,6 +128,35 @@ typedef struct s2m2_pack_desc {
 long long s2m2_pack_frag_elems(const s2m2_pack_desc* desc);
 int s2m2_pack_frag(const s2m2_pack_desc* desc, void* stream);
 
+/*
+ * Recorded launch plans (ABI 500): a sequence of library calls replayed from C.  Between s2m2_plan_begin and s2m2_plan_end every launch-type entry
+ * point the CALLING THREAD invokes is executed as always AND appended to the plan (arguments by value, descriptors copied).  s2m2_plan_end
+ * declares the plan's EXTERNAL buffers -- next ranges [ext_base[i], ext_base[i] + ext_bytes[i]) of device memory: every recorded pointer into
+ * range i is stored relative to it -- and s2m2_plan_run re-issues the whole sequence on `stream` with the externals at ext_ptrs[i] (same count
+ * and order; a NULL external is accepted if no recorded call points into it).  All other pointers (weights, scratch, the intermediate tensors
+ * of the recorded run) are replayed as recorded: the owner of the plan keeps those allocations alive and unshared for the life of the plan.
+ * A plan is immutable once sealed; concurrent runs on different streams are safe when their externals differ and the caller accepts that the
+ * internal intermediates are shared (i.e. in practice: one run at a time per plan).  Recording does not synchronise and may itself run under
+ * stream capture; s2m2_plan_run may too.  s2m2_plan_abort ends a recording whose owner failed half way (the plan can only be destroyed then).
+ *
+ * s2m2_refine_step: ONE refinement iteration -- LocalRefiner.forward + the loop epilogue of S2M2.forward (refinenet.py:126-154, s2m2.py:175-180):
+ * cost-volume lookup, the correlation / disparity / confidence feature layers, the refinement U-Net with its attention blocks, the ConvGRU, the
+ * update heads, refine_update; about 55 launches -- as one native call: a plan recorded around that iteration whose seven externals are, in this
+ * order, hidden (B,h,w,C), ctx (B,h,w,C), disp, conf, occ (B,1,h,w fp32), cv (B,h,w,cv_pitch) and the (B,h,w,8) side input written by the previous
+ * iteration's epilogue (NULL for the first iteration, which builds its own).  The iteration's outputs are the tensors of the recorded run
+ * (s2m2_amd/engine.py keeps them; a C caller records its own plan around its own launch sequence the same way).
+ */
+typedef struct s2m2_plan s2m2_plan;
+int s2m2_plan_begin(s2m2_plan** plan);
+int s2m2_plan_end(s2m2_plan* plan, const void* const* ext_base, const size_t* ext_bytes, int next);
+int s2m2_plan_abort(s2m2_plan* plan);
+int s2m2_plan_launches(const s2m2_plan* plan);
+int s2m2_plan_patches(const s2m2_plan* plan, int slot);   /* recorded pointers that follow external `slot` (< 0: all): diagnostics */
+int s2m2_plan_run(const s2m2_plan* plan, const void* const* ext_ptrs, int next, void* stream);
+int s2m2_plan_destroy(s2m2_plan* plan);
+int s2m2_refine_step(const s2m2_plan* step, const void* hidden, const void* ctx, const void* disp, const void* conf, const void* occ,
+                     const void* cv, const void* side_input, void* stream);
+
 int s2m2_event_create(void** event);
 int s2m2_event_destroy(void* event);
 int s2m2_event_elapsed_us(void* start_event, void* stop_event, float* microseconds);
@@ -224,7 +253,8 @@ typedef struct s2m2_conv_desc {
     int epi_cout0;          /* > 0 (korder 2, one-operand epilogues ADD / MUL, a multiple of 128): the epilogue applies to couts >= epi_cout0
                                only, couts below it are stored after bias + activation -- two layers that read the same input stacked along
                                Cout with different epilogues in ONE launch (ConvGRU: z = sigmoid(convz(hx)) | r*h = sigmoid(convr(hx)) * h,
-                               refinenet.py:24-29).  aux0 is indexed with the cout itself: aux0[pixel * aux0_stride + cout]. */
+                               refinenet.py:24-29).  aux0 then has Cout - epi_cout0 channels: aux0[pixel * aux0_stride + (cout - epi_cout0)]
+                               (ABI 500: the tensor's own base pointer; up to ABI 400 the caller passed it shifted by -epi_cout0 elements). */
 } s2m2_conv_desc;
 int s2m2_conv2d(const s2m2_conv_desc* desc, void* stream);
 

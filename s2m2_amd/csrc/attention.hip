@@ -27,6 +27,7 @@
 //           runs once per query after the key loop.  (A first version binned with ds_add_f32: twice SLOWER than the VALU loop.)
 // fp16: v_mfma_f32_32x32x16_f16 with fp32 softmax/accumulators;  fp32 (parity mode): exact v_mfma_f32_32x32x2_f32.
 #include "common.h"
+#include "plan.h"
 
 #ifndef S2M2_ATTN_DBG
 #define S2M2_ATTN_DBG 0          // ablation builds (timing only, wrong results): 1 no K/V refetch after stage 0, 2 no softmax math, 4 no MFMA, 8 no stage barriers
@@ -608,13 +609,20 @@ static int attention_entry(const void* q, const void* k, const void* v, void* ou
     return set_error("attention: unsupported dtype %d", dtype);
 }
 
-extern "C" int s2m2_attention(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
+static int attention_impl(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
                               long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
                               int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
                               int grid_w, int grid_h, int dtype, void* stream) {
     return attention_entry(q, k, v, out, q_stride, k_stride, v_stride, out_stride, nb, heads, Nq, Nk, D, scale, swap_halves, pe_x, pe_y,
                            pe_out, pe_stride, grid_w, grid_h, dtype, stream, 0);
 }
+extern "C" int s2m2_attention(const void* q, const void* k, const void* v, void* out, long long q_stride, long long k_stride,
+                              long long v_stride, long long out_stride, int nb, int heads, int Nq, int Nk, int D, float scale,
+                              int swap_halves, const float* pe_x, const float* pe_y, void* pe_out, long long pe_stride,
+                              int grid_w, int grid_h, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_attention", &attention_impl, stream, q, k, v, out, q_stride, k_stride, v_stride, out_stride, nb, heads, Nq, Nk, D, scale, swap_halves, pe_x, pe_y, pe_out, pe_stride, grid_w, grid_h, dtype);
+}
+
 
 extern "C" int s2m2_attention_supported(int nb, int heads, int N, int D, int grid_w, int grid_h, int dtype) {
     // the same planning code as the launch (head-dim instantiation, PE bin tiles, waves per block, LDS budget) without the launch;

@@ -18,6 +18,7 @@
 //     K loop; `carry` adds the output of stage 0 (still in the other LDS buffer) to the last stage of a 3-stage chain.
 // Every intermediate is rounded to the I/O dtype exactly where the separate launches round it (tile in LDS instead of HBM).
 #include "common.h"
+#include "plan.h"
 #include "epilogue.h"
 #include <stdlib.h>
 
@@ -619,7 +620,7 @@ static bool chain_direct_tall(int C, long long rows) {
 
 extern "C" int s2m2_mlp_fan_supported(int C, int nfan, int dtype) { return s2m2_mlp_chain_frag_supported(C, dtype) && nfan >= 1 && nfan <= 4; }
 
-extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
+static int mlp_chain_impl(const s2m2_chain_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "mlp_chain: null descriptor");
     S2M2_REQUIRE(d->x, "mlp_chain: null x");
@@ -720,3 +721,7 @@ extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
     if (d->C == 128) return launch_chain_n<float, 128, 32, 4>(a, d->nstage, st);
     return launch_chain_n<float, 256, 32, 8>(a, d->nstage, st);
 }
+extern "C" int s2m2_mlp_chain(const s2m2_chain_desc* d, void* stream) {
+    return s2m2::plan_dispatch_desc<s2m2_chain_desc>("s2m2_mlp_chain", &mlp_chain_impl, d, stream);
+}
+

@@ -17,6 +17,7 @@
 //            pieces of whole pixel rows (NHWC: channels contiguous) for the aux epilogue and fully coalesced stores.
 // fp16: v_mfma_f32_32x32x16_f16, fp32 accumulate.  fp32 (parity mode): exact v_mfma_f32_32x32x2_f32.
 #include "common.h"
+#include "plan.h"
 #include <stdlib.h>
 
 // compile-time ablation switches (tools/conv_ablate.py; never set in the shipped library):
@@ -1665,7 +1666,7 @@ extern "C" int s2m2_debug_frag_trace(void* host, size_t bytes) {
 }
 #endif
 
-extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
+static int conv2d_impl(const s2m2_conv_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "conv2d: null descriptor");
     S2M2_REQUIRE(d->nsrc >= 1 && d->nsrc <= 4, "conv2d: nsrc=%d (1..4)", d->nsrc);
@@ -1703,6 +1704,11 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     a.nsrc = d->nsrc; a.weight = d->weight; a.bias = d->bias; a.out = d->out; a.out_stride = d->out_stride;
     a.N = d->N; a.H = d->H; a.W = d->W; a.KH = d->KH; a.KW = d->KW; a.Cout = d->Cout;
     a.act = d->act; a.epi = d->epi; a.aux0 = d->aux0; a.aux1 = d->aux1;
+    // epi_cout0: aux0 covers couts >= epi_cout0 only and the kernel indexes it with the cout -- its rows start epi_cout0 elements "before" the
+    // tensor (never dereferenced there).  ABI 500: the descriptor carries the tensor's own base (up to 400 the caller passed the shifted
+    // pointer: a pointer outside its buffer cannot follow the buffer in a recorded plan, s2m2_plan_end)
+    if (d->epi_cout0 > 0 && d->aux0)
+        a.aux0 = static_cast<const char*>(d->aux0) - (size_t)d->epi_cout0 * (d->dtype == S2M2_F16 ? 2 : 4);
     a.aux0_stride = d->aux0_stride; a.aux1_stride = d->aux1_stride;
     a.out_scale = d->out_scale; a.shuffle2 = d->shuffle2; a.korder = d->korder;
     a.ln_wsum = d->ln_wsum; a.ln_eps = d->ln_eps;
@@ -1738,3 +1744,7 @@ extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
     if (d->dtype == S2M2_F32) return dispatch_conv<float>(a, d->tile, st);
     return set_error("conv2d: unsupported dtype %d", d->dtype);
 }
+extern "C" int s2m2_conv2d(const s2m2_conv_desc* d, void* stream) {
+    return s2m2::plan_dispatch_desc<s2m2_conv_desc>("s2m2_conv2d", &conv2d_impl, d, stream);
+}
+

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "plan.h"
 #include "epilogue.h"
 
 namespace s2m2 {
@@ -477,7 +478,7 @@ extern "C" int s2m2_conv_narrow_supported(int KH, int KW, int stride, int Cin, i
     return 0;
 }
 
-extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
+static int conv_narrow_impl(const s2m2_narrow_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "conv_narrow: null descriptor");
     S2M2_REQUIRE(d->x && d->weight_frag && d->out, "conv_narrow: null pointer");
@@ -521,3 +522,7 @@ extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
     if (split) return tall ? launch_narrow<5, 5, 2, 16, 4, 1, 2>(a, st) : launch_narrow<5, 5, 2, 16, 2, 1, 2>(a, st);
     return tall ? launch_narrow<5, 5, 2, 16, 2, 2, 1>(a, st) : launch_narrow<5, 5, 2, 16, 1, 2, 1>(a, st);
 }
+extern "C" int s2m2_conv_narrow(const s2m2_narrow_desc* d, void* stream) {
+    return s2m2::plan_dispatch_desc<s2m2_narrow_desc>("s2m2_conv_narrow", &conv_narrow_impl, d, stream);
+}
+

@@ -7,6 +7,7 @@
 // so the effective coordinate is off by ~1 ulp and a vanishing weight can land on the neighbouring row;
 // that arithmetic is reproduced here with contraction disabled.
 #include "common.h"
+#include "plan.h"
 #include "cv_lookup.h"
 
 namespace s2m2 {
@@ -45,7 +46,7 @@ static int launch_lookup(const void* cv, const float* disp, void* c1, void* c2, 
 
 }  // namespace s2m2
 
-extern "C" int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2, int B, int h, int w, int radius,
+static int cv_lookup_impl(const void* cv, const float* disp, void* corr1, void* corr2, int B, int h, int w, int radius,
                               int cv_dtype, int out_dtype, long long batch_stride, long long pix_stride, long long tap_stride,
                               int cv_pitch, void* stream) {
     using namespace s2m2;
@@ -61,3 +62,9 @@ extern "C" int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, vo
     if (cv_dtype == S2M2_F32 && out_dtype == S2M2_F16) return launch_lookup<float, half_t>(cv, disp, corr1, corr2, B, h, w, radius, batch_stride, pix_stride, tap_stride, cv_pitch, st);
     return set_error("cv_lookup: unsupported dtypes cv=%d out=%d", cv_dtype, out_dtype);
 }
+extern "C" int s2m2_cv_lookup(const void* cv, const float* disp, void* corr1, void* corr2, int B, int h, int w, int radius,
+                              int cv_dtype, int out_dtype, long long batch_stride, long long pix_stride, long long tap_stride,
+                              int cv_pitch, void* stream) {
+    return s2m2::plan_dispatch("s2m2_cv_lookup", &cv_lookup_impl, stream, cv, disp, corr1, corr2, B, h, w, radius, cv_dtype, out_dtype, batch_stride, pix_stride, tap_stride, cv_pitch);
+}
+

@@ -15,6 +15,7 @@
 //   * MFMA roles, staging and rounding points as in K5 / K9: h, g, the mix and the fusion term are each rounded to the I/O dtype
 //     where the separate launches stored them.
 #include "common.h"
+#include "plan.h"
 #include "epilogue.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -445,7 +446,7 @@ extern "C" int s2m2_feature_fusion_supported(int C, int dtype) {
 
 extern "C" int s2m2_feature_fusion_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 192 || C == 256 || C == 384); }
 
-extern "C" int s2m2_feature_fusion_frag(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+static int feature_fusion_frag_impl(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
                                         long long rows, int C, const void* w_stream, const float* b1, const float* bg, const float* bf,
                                         int z1_coarse_h, int z1_coarse_w, int dtype, void* stream) {
     using namespace s2m2;
@@ -471,8 +472,14 @@ extern "C" int s2m2_feature_fusion_frag(const void* z0, const void* z1, void* ou
     if (C == 384) return launch_fusion_direct<384, 32, 12, 16>(a, st);   // 12 waves: three per SIMD, <= 168 registers (64-row tiles spill)
     return tall ? launch_fusion_direct<256, 64, 8, 16>(a, st) : launch_fusion_direct<256, 32, 8, 24>(a, st);
 }
+extern "C" int s2m2_feature_fusion_frag(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+                                        long long rows, int C, const void* w_stream, const float* b1, const float* bg, const float* bf,
+                                        int z1_coarse_h, int z1_coarse_w, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_feature_fusion_frag", &feature_fusion_frag_impl, stream, z0, z1, out, z0_stride, z1_stride, out_stride, rows, C, w_stream, b1, bg, bf, z1_coarse_h, z1_coarse_w, dtype);
+}
 
-extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+
+static int feature_fusion_impl(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
                                    long long rows, int C, const void* w1, const float* b1, const void* w2, const float* bg,
                                    const float* bf, int z1_coarse_h, int z1_coarse_w, int dtype, void* stream) {
     using namespace s2m2;
@@ -504,3 +511,9 @@ extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, lo
     if (C == 128) return launch_fusion<float, 128, 32, 4>(a, st);
     return launch_fusion<float, 256, 32, 8>(a, st);
 }
+extern "C" int s2m2_feature_fusion(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
+                                   long long rows, int C, const void* w1, const float* b1, const void* w2, const float* bg,
+                                   const float* bf, int z1_coarse_h, int z1_coarse_w, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_feature_fusion", &feature_fusion_impl, stream, z0, z1, out, z0_stride, z1_stride, out_stride, rows, C, w1, b1, w2, bg, bf, z1_coarse_h, z1_coarse_w, dtype);
+}
+

@@ -19,6 +19,7 @@
 // Every feature token is read from HBM once and normalised once per strip; the cost volume is written once.
 // Algorithmic traffic per pair: 2*h*w*C*sizeof(T) read + h*w*w*sizeof(TO) written.
 #include "common.h"
+#include "plan.h"
 #include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -516,7 +517,7 @@ static int dispatch_c(const void* feat, const float* g, const float* bta, void* 
 
 }  // namespace s2m2
 
-extern "C" int s2m2_cost_volume(const s2m2_corr_desc* d, void* stream) {
+static int cost_volume_impl(const s2m2_corr_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "cost_volume: null descriptor");
     S2M2_REQUIRE(d->tokens && d->cv, "cost_volume: null pointer");
@@ -544,6 +545,10 @@ extern "C" int s2m2_cost_volume(const s2m2_corr_desc* d, void* stream) {
     }
     return set_error("cost_volume: unsupported dtype pair tokens=%d cv=%d", td, cd);
 }
+extern "C" int s2m2_cost_volume(const s2m2_corr_desc* d, void* stream) {
+    return s2m2::plan_dispatch_desc<s2m2_corr_desc>("s2m2_cost_volume", &cost_volume_impl, d, stream);
+}
+
 
 // ---- the entry points of ABI versions up to 400: shims over s2m2_cost_volume, kept for one ABI version -------------------------------
 static int k1_shim(const void* tokens, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,

@@ -8,6 +8,7 @@
 //    atomicAdd pair per block and group), then the normalise+affine sweep.
 // Both compute in fp32 regardless of the I/O dtype.
 #include "common.h"
+#include "plan.h"
 
 namespace s2m2 {
 
@@ -172,7 +173,7 @@ static int run_groupnorm(const void* x, void* y, const float* gamma, const float
 
 }  // namespace s2m2
 
-extern "C" int s2m2_layernorm(const void* x, void* y, long long rows, int C, long long x_stride, long long y_stride, int dtype,
+static int layernorm_impl(const void* x, void* y, long long rows, int C, long long x_stride, long long y_stride, int dtype,
                               void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(x && y, "layernorm: null pointer");
@@ -183,10 +184,15 @@ extern "C" int s2m2_layernorm(const void* x, void* y, long long rows, int C, lon
     if (dtype == S2M2_F32) return dispatch_ln<float>(x, y, rows, C, x_stride, y_stride, st);
     return set_error("layernorm: unsupported dtype %d", dtype);
 }
+extern "C" int s2m2_layernorm(const void* x, void* y, long long rows, int C, long long x_stride, long long y_stride, int dtype,
+                              void* stream) {
+    return s2m2::plan_dispatch("s2m2_layernorm", &layernorm_impl, stream, x, y, rows, C, x_stride, y_stride, dtype);
+}
+
 
 extern "C" size_t s2m2_groupnorm_workspace_bytes(int N, int G) { return sizeof(double) * 2 * (size_t)N * G; }
 
-extern "C" int s2m2_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* workspace, int N,
+static int groupnorm_nhwc_impl(const void* x, void* y, const float* gamma, const float* beta, void* workspace, int N,
                                    long long HW, int C, int G, float eps, int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(x && y && gamma && beta && workspace, "groupnorm: null pointer");
@@ -199,3 +205,8 @@ extern "C" int s2m2_groupnorm_nhwc(const void* x, void* y, const float* gamma, c
     if (dtype == S2M2_F32) return run_groupnorm<float>(x, y, gamma, beta, static_cast<double*>(workspace), N, HW, C, G, eps, st);
     return set_error("groupnorm: unsupported dtype %d", dtype);
 }
+extern "C" int s2m2_groupnorm_nhwc(const void* x, void* y, const float* gamma, const float* beta, void* workspace, int N,
+                                   long long HW, int C, int G, float eps, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_groupnorm_nhwc", &groupnorm_nhwc_impl, stream, x, y, gamma, beta, workspace, N, HW, C, G, eps, dtype);
+}
+

@@ -7,6 +7,7 @@
 //   unary          tanh of the context features (hidden state init)                 (s2m2.py:166)
 // All maps are (B,h,w) fp32; "small" side inputs are (B,h,w,8) NHWC in the activation dtype with unused channels zero.
 #include "common.h"
+#include "plan.h"
 #include "epilogue.h"
 
 namespace s2m2 {
@@ -119,7 +120,7 @@ static inline dim3 grid1(long long n) { return dim3((unsigned)((n + 255) / 256))
 
 }  // namespace s2m2
 
-extern "C" int s2m2_image_prep(const void* img0, const void* img1, void* x8, int B, int H, int W, int img_dtype, int dtype, void* stream) {
+static int image_prep_impl(const void* img0, const void* img1, void* x8, int B, int H, int W, int img_dtype, int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(img0 && img1 && x8 && B > 0 && H > 0 && W > 0 && 2LL * B * H * W < (1LL << 31), "image_prep: bad arguments (at most 2^31 pixels per launch)");
     const long long HW = (long long)H * W, n = 2LL * B * HW;
@@ -136,8 +137,12 @@ extern "C" int s2m2_image_prep(const void* img0, const void* img1, void* x8, int
     #undef S2M2_IP
     return check_launch("image_prep");
 }
+extern "C" int s2m2_image_prep(const void* img0, const void* img1, void* x8, int B, int H, int W, int img_dtype, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_image_prep", &image_prep_impl, stream, img0, img1, x8, B, H, W, img_dtype, dtype);
+}
 
-extern "C" int s2m2_refine_prep(const float* disp, const float* conf, const float* occ, void* small8, long long npix, int mode, int dtype,
+
+static int refine_prep_impl(const float* disp, const float* conf, const float* occ, void* small8, long long npix, int mode, int dtype,
                                 void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(disp && conf && small8 && npix > 0 && (mode == 0 || (mode == 1 && occ)), "refine_prep: bad arguments");
@@ -147,8 +152,13 @@ extern "C" int s2m2_refine_prep(const float* disp, const float* conf, const floa
     else return set_error("refine_prep: unsupported dtype %d", dtype);
     return check_launch("refine_prep");
 }
+extern "C" int s2m2_refine_prep(const float* disp, const float* conf, const float* occ, void* small8, long long npix, int mode, int dtype,
+                                void* stream) {
+    return s2m2::plan_dispatch("s2m2_refine_prep", &refine_prep_impl, stream, disp, conf, occ, small8, npix, mode, dtype);
+}
 
-extern "C" int s2m2_global_update(const void* upd, int upd_stride, const float* disp, const float* conf, float* out, long long npix,
+
+static int global_update_impl(const void* upd, int upd_stride, const float* disp, const float* conf, float* out, long long npix,
                                   int clamp0, int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(upd && disp && conf && out && npix > 0 && upd_stride > 0, "global_update: bad arguments");
@@ -158,8 +168,13 @@ extern "C" int s2m2_global_update(const void* upd, int upd_stride, const float* 
     else return set_error("global_update: unsupported dtype %d", dtype);
     return check_launch("global_update");
 }
+extern "C" int s2m2_global_update(const void* upd, int upd_stride, const float* disp, const float* conf, float* out, long long npix,
+                                  int clamp0, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_global_update", &global_update_impl, stream, upd, upd_stride, disp, conf, out, npix, clamp0, dtype);
+}
 
-extern "C" int s2m2_refine_update_to(const void* dco, int dco_stride, const float* disp, const float* conf, const float* occ,
+
+static int refine_update_to_impl(const void* dco, int dco_stride, const float* disp, const float* conf, const float* occ,
                                      float* disp_out, float* conf_out, float* occ_out, void* small8_next, long long npix, int w,
                                      int use_positivity, int dtype, void* stream) {
     using namespace s2m2;
@@ -176,6 +191,12 @@ extern "C" int s2m2_refine_update_to(const void* dco, int dco_stride, const floa
     else return set_error("refine_update: unsupported dtype %d", dtype);
     return check_launch("refine_update");
 }
+extern "C" int s2m2_refine_update_to(const void* dco, int dco_stride, const float* disp, const float* conf, const float* occ,
+                                     float* disp_out, float* conf_out, float* occ_out, void* small8_next, long long npix, int w,
+                                     int use_positivity, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_refine_update_to", &refine_update_to_impl, stream, dco, dco_stride, disp, conf, occ, disp_out, conf_out, occ_out, small8_next, npix, w, use_positivity, dtype);
+}
+
 
 extern "C" int s2m2_refine_update(const void* dco, int dco_stride, float* disp, float* conf, float* occ, long long npix, int w,
                                   int use_positivity, int dtype, void* stream) {
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(256) void stem_mlp_kernel(const T* __restrict__ x8,
 
 }  // namespace s2m2
 
-extern "C" int s2m2_stem_mlp(const void* x8, const float* w0, const float* b0, const float* w1, const float* b1, void* out, long long npix,
+static int stem_mlp_impl(const void* x8, const float* w0, const float* b0, const float* w1, const float* b1, void* out, long long npix,
                              int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(x8 && w0 && b0 && w1 && b1 && out && npix > 0, "stem_mlp: bad arguments");
@@ -244,8 +265,13 @@ extern "C" int s2m2_stem_mlp(const void* x8, const float* w0, const float* b0, c
     else return set_error("stem_mlp: unsupported dtype %d", dtype);
     return check_launch("stem_mlp");
 }
+extern "C" int s2m2_stem_mlp(const void* x8, const float* w0, const float* b0, const float* w1, const float* b1, void* out, long long npix,
+                             int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_stem_mlp", &stem_mlp_impl, stream, x8, w0, b0, w1, b1, out, npix, dtype);
+}
 
-extern "C" int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream) {
+
+static int tanh_impl(const void* x, void* y, long long n, int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(x && y && n > 0 && n % 8 == 0, "tanh: bad arguments (n must be a multiple of 8)");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -254,6 +280,10 @@ extern "C" int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* s
     else return set_error("tanh: unsupported dtype %d", dtype);
     return check_launch("tanh");
 }
+extern "C" int s2m2_tanh(const void* x, void* y, long long n, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_tanh", &tanh_impl, stream, x, y, n, dtype);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // image_pad (reference src/s2m2/core/utils/image_utils.py:27-71): pad (B,C,H,W) to multiples of `factor` -- the border is NOT
@@ -309,7 +339,7 @@ __global__ __launch_bounds__(256) void pad_fill_kernel(const TI* __restrict__ im
 
 }  // namespace s2m2
 
-extern "C" int s2m2_image_pad(const void* img, float* pooled, float* out, int B, int C, int H, int W, int factor, int img_dtype,
+static int image_pad_impl(const void* img, float* pooled, float* out, int B, int C, int H, int W, int factor, int img_dtype,
                               void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(img && pooled && out && B > 0 && C > 0 && factor > 0 && H >= factor && W >= factor, "image_pad: bad arguments");
@@ -329,3 +359,8 @@ extern "C" int s2m2_image_pad(const void* img, float* pooled, float* out, int B,
     #undef S2M2_PAD
     return check_launch("image_pad");
 }
+extern "C" int s2m2_image_pad(const void* img, float* pooled, float* out, int B, int C, int H, int W, int factor, int img_dtype,
+                              void* stream) {
+    return s2m2::plan_dispatch("s2m2_image_pad", &image_pad_impl, stream, img, pooled, out, B, C, H, W, factor, img_dtype);
+}
+

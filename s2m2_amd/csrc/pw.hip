@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "plan.h"
 #include "epilogue.h"
 
 namespace s2m2 {
@@ -192,7 +193,7 @@ extern "C" int s2m2_pw_direct_supported(int K, int Cout, int dtype) {
            (nwn == 1 || nwn == 2 || nwn == 3 || nwn == 4 || nwn == 6 || nwn == 8);
 }
 
-extern "C" int s2m2_pw_direct(const s2m2_pw_desc* d, void* stream) {
+static int pw_direct_impl(const s2m2_pw_desc* d, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(d, "pw_direct: null descriptor");
     S2M2_REQUIRE(d->nsrc >= 1 && d->nsrc <= 4 && d->rows > 0 && d->rows < (1LL << 40), "pw_direct: nsrc=%d rows=%lld", d->nsrc, d->rows);
@@ -234,3 +235,7 @@ extern "C" int s2m2_pw_direct(const s2m2_pw_desc* d, void* stream) {
         default: return dispatch_pw_n<24>(a, st);
     }
 }
+extern "C" int s2m2_pw_direct(const s2m2_pw_desc* d, void* stream) {
+    return s2m2::plan_dispatch_desc<s2m2_pw_desc>("s2m2_pw_direct", &pw_direct_impl, d, stream);
+}
+

@@ -1,7 +1,10 @@
 // Host-side runtime glue of libs2m2_hip.so: version, thread-local error text, launch checks.
 #include "common.h"
+#include "plan.h"
 
 #include <mutex>
+#include <string.h>
+#include <vector>
 
 namespace s2m2 {
 
@@ -91,6 +94,126 @@ extern "C" int s2m2_debug_poison_lds(void* stream) {
     if (reserve_lds(reinterpret_cast<const void*>(poison_lds_kernel), kBytes, granted, "debug_poison_lds")) return 1;
     hipLaunchKernelGGL(poison_lds_kernel, dim3(1024), dim3(256), kBytes, static_cast<hipStream_t>(stream), (unsigned*)nullptr, kBytes / 4);
     return check_launch("debug_poison_lds");
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Recorded launch plans (include/s2m2_hip.h: s2m2_plan_*).  A plan is the list of library calls one thread made between s2m2_plan_begin and
+// s2m2_plan_end -- each as a flat argument blob plus a trampoline (plan.h) -- with the pointers into the caller's EXTERNAL buffers (declared at
+// s2m2_plan_end) stored relative to their buffer, so that s2m2_plan_run can re-issue the whole sequence from C++ with the externals somewhere
+// else.  Every other pointer (weights, the scratch and intermediate tensors of the recorded run) is replayed as recorded: whoever records keeps
+// those allocations alive for the life of the plan.  The blobs are scanned for external pointers as 8-byte words -- a device address is a
+// 64-bit value in a range no size, stride or flag field of the descriptors reaches.
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct s2m2_plan {
+    struct Call { int (*tramp)(const void*, void*); size_t off, words; const char* name; };
+    struct Patch { int call; int word; int slot; long long delta; };
+    std::vector<unsigned long long> arena;      // the blobs, 8-byte aligned
+    std::vector<Call> calls;
+    std::vector<Patch> patches;
+    int nslots = 0;
+    bool sealed = false, failed = false;
+    size_t max_words = 0;
+};
+
+namespace s2m2 {
+static thread_local s2m2_plan* g_plan = nullptr;
+
+bool plan_recording() { return g_plan != nullptr; }
+
+int plan_append(int (*tramp)(const void*, void*), const void* blob, size_t bytes, const char* name) {
+    s2m2_plan* p = g_plan;
+    if (!p) return 0;
+    const size_t words = (bytes + 7) / 8;
+    const size_t off = p->arena.size();
+    p->arena.resize(off + words, 0ULL);
+    memcpy(p->arena.data() + off, blob, bytes);
+    p->calls.push_back({tramp, off, words, name});
+    if (words > p->max_words) p->max_words = words;
+    return 0;
+}
+}  // namespace s2m2
+
+extern "C" int s2m2_plan_begin(s2m2_plan** plan) {
+    using namespace s2m2;
+    S2M2_REQUIRE(plan, "plan_begin: null pointer");
+    S2M2_REQUIRE(!g_plan, "plan_begin: this thread is recording a plan already");
+    *plan = new s2m2_plan();
+    g_plan = *plan;
+    return 0;
+}
+
+extern "C" int s2m2_plan_end(s2m2_plan* plan, const void* const* ext_base, const size_t* ext_bytes, int next) {
+    using namespace s2m2;
+    S2M2_REQUIRE(plan && g_plan == plan, "plan_end: not the plan this thread is recording");
+    g_plan = nullptr;
+    S2M2_REQUIRE(next >= 0 && next <= 16 && (next == 0 || (ext_base && ext_bytes)), "plan_end: next=%d external buffers (0..16)", next);
+    plan->nslots = next;
+    for (int c = 0; c < (int)plan->calls.size(); ++c) {
+        const auto& call = plan->calls[c];
+        for (size_t wd = 1; wd < call.words; ++wd) {               // word 0 is the function pointer of the call
+            const unsigned long long v = plan->arena[call.off + wd];
+            for (int s = 0; s < next; ++s) {
+                const unsigned long long b = (unsigned long long)(uintptr_t)ext_base[s];
+                if (b && ext_bytes[s] && v >= b && v < b + ext_bytes[s]) {
+                    plan->patches.push_back({c, (int)wd, s, (long long)(v - b)});
+                    break;
+                }
+            }
+        }
+    }
+    plan->sealed = true;
+    return 0;
+}
+
+extern "C" int s2m2_plan_abort(s2m2_plan* plan) {                    // stop recording without a usable plan (an exception between begin and end)
+    if (s2m2::g_plan == plan) s2m2::g_plan = nullptr;
+    if (plan) plan->failed = true;
+    return 0;
+}
+
+extern "C" int s2m2_plan_launches(const s2m2_plan* plan) { return plan ? (int)plan->calls.size() : -1; }
+
+// recorded pointers that follow external buffer `slot` (diagnostics; slot < 0: all)
+extern "C" int s2m2_plan_patches(const s2m2_plan* plan, int slot) {
+    if (!plan) return -1;
+    int n = 0;
+    for (const auto& pt : plan->patches) n += slot < 0 || pt.slot == slot;
+    return n;
+}
+
+extern "C" int s2m2_plan_run(const s2m2_plan* plan, const void* const* ext_ptrs, int next, void* stream) {
+    using namespace s2m2;
+    S2M2_REQUIRE(plan && plan->sealed && !plan->failed, "plan_run: the plan was not recorded to its end");
+    S2M2_REQUIRE(next == plan->nslots && (next == 0 || ext_ptrs), "plan_run: %d external buffers given, the plan was recorded with %d", next, plan->nslots);
+    S2M2_REQUIRE(!g_plan, "plan_run: this thread is recording a plan");
+    std::vector<unsigned long long> blob(plan->max_words);           // a private copy per call: concurrent runs of one plan do not share state
+    size_t pi = 0;
+    for (int c = 0; c < (int)plan->calls.size(); ++c) {
+        const auto& call = plan->calls[c];
+        memcpy(blob.data(), plan->arena.data() + call.off, call.words * 8);
+        for (; pi < plan->patches.size() && plan->patches[pi].call == c; ++pi) {
+            const auto& pt = plan->patches[pi];
+            S2M2_REQUIRE(ext_ptrs[pt.slot], "plan_run: external buffer %d is null but call %d (%s) uses it", pt.slot, c, call.name);
+            blob[pt.word] = (unsigned long long)(uintptr_t)ext_ptrs[pt.slot] + (unsigned long long)pt.delta;
+        }
+        if (call.tramp(blob.data(), stream) != 0) return 1;           // (the entry point's own message is in s2m2_last_error)
+    }
+    return 0;
+}
+
+extern "C" int s2m2_plan_destroy(s2m2_plan* plan) {
+    if (s2m2::g_plan == plan) s2m2::g_plan = nullptr;
+    delete plan;
+    return 0;
+}
+
+// One refinement iteration as ONE native call (LocalRefiner.forward + the loop epilogue, refinenet.py:126-154, s2m2.py:175-180: K3, the
+// corr / disparity / confidence feature layers, the U-Net with its attention blocks, the ConvGRU, the update heads and refine_update --
+// about 55 launches): a plan recorded around that iteration whose externals are, in this order, the iteration's inputs.
+extern "C" int s2m2_refine_step(const s2m2_plan* step, const void* hidden, const void* ctx, const void* disp, const void* conf, const void* occ,
+                                const void* cv, const void* side_input, void* stream) {
+    const void* ext[7] = {hidden, ctx, disp, conf, occ, cv, side_input};
+    return s2m2_plan_run(step, ext, 7, stream);
 }
 
 extern "C" int s2m2_version(void) { return S2M2_ABI_VERSION; }   // include/s2m2_hip.h

@@ -23,6 +23,7 @@
 // exceeds it by more than 40 (checked once per 8 elements with a wave vote), otherwise an element costs a subtract, an exp and an
 // add -- the exact sum of exp(x - m) for a fixed m, just not the tightest m.
 #include "common.h"
+#include "plan.h"
 #include <stdlib.h>
 
 namespace s2m2 {
@@ -429,7 +430,7 @@ extern "C" size_t s2m2_sinkhorn_workspace_bytes(int B, int h, int w, int cv_dtyp
     return 0;                                    // u, v and the partials live in LDS
 }
 
-extern "C" int s2m2_sinkhorn_regress(const void* cv, float* disp, float* conf, float* occ, int32_t* argmax, int B, int h, int w,
+static int sinkhorn_regress_impl(const void* cv, float* disp, float* conf, float* occ, int32_t* argmax, int B, int h, int w,
                                      int ot_iter, int use_positivity, int cv_dtype, int cv_pitch, void* workspace, void* stream) {
     using namespace s2m2;
     (void)workspace;
@@ -443,3 +444,8 @@ extern "C" int s2m2_sinkhorn_regress(const void* cv, float* disp, float* conf, f
     if (cv_dtype == S2M2_F32) return dispatch_ppl<float>(cv, disp, conf, occ, argmax, B * h, w, ot_iter, use_positivity, cv_pitch, st);
     return set_error("sinkhorn: unsupported cv dtype %d", cv_dtype);
 }
+extern "C" int s2m2_sinkhorn_regress(const void* cv, float* disp, float* conf, float* occ, int32_t* argmax, int B, int h, int w,
+                                     int ot_iter, int use_positivity, int cv_dtype, int cv_pitch, void* workspace, void* stream) {
+    return s2m2::plan_dispatch("s2m2_sinkhorn_regress", &sinkhorn_regress_impl, stream, cv, disp, conf, occ, argmax, B, h, w, ot_iter, use_positivity, cv_dtype, cv_pitch, workspace);
+}
+

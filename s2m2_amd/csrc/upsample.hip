@@ -7,6 +7,7 @@
 // gathers the 9 low-resolution neighbours from cache.  HBM-bound: ~(logit row + 3*4 B) per output pixel.
 //   out[m][b,Y,X] = scale_m * sum_n softmax_n(logit[b,Y,X,:9]) * x[m][b, clamp(Y/f + n/3 - 1), clamp(X/f + n%3 - 1)]
 #include "common.h"
+#include "plan.h"
 
 namespace s2m2 {
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(256) void resample2x_kernel(const T* __restrict__ x
 
 }  // namespace s2m2
 
-extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
+static int convex_upsample_impl(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
                                     int logit_stride, int B, int hs, int ws, int factor, int logit_up2, void* chan_out,
                                     long long chan_stride, int dtype, void* stream) {
     using namespace s2m2;
@@ -161,8 +162,14 @@ extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, co
     else return set_error("convex_upsample: unsupported dtype %d", dtype);
     return check_launch("convex_upsample");
 }
+extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
+                                    int logit_stride, int B, int hs, int ws, int factor, int logit_up2, void* chan_out,
+                                    long long chan_stride, int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_convex_upsample", &convex_upsample_impl, stream, x, out, scale, nmaps, logits, logit_stride, B, hs, ws, factor, logit_up2, chan_out, chan_stride, dtype);
+}
 
-extern "C" int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int C, long long x_stride, long long y_stride, int mode,
+
+static int resample2x_impl(const void* x, void* y, int N, int H, int W, int C, long long x_stride, long long y_stride, int mode,
                                int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(x && y, "resample2x: null pointer");
@@ -182,3 +189,8 @@ extern "C" int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int 
     else return set_error("resample2x: unsupported dtype %d", dtype);
     return check_launch("resample2x");
 }
+extern "C" int s2m2_resample2x(const void* x, void* y, int N, int H, int W, int C, long long x_stride, long long y_stride, int mode,
+                               int dtype, void* stream) {
+    return s2m2::plan_dispatch("s2m2_resample2x", &resample2x_impl, stream, x, y, N, H, W, C, x_stride, y_stride, mode, dtype);
+}
+

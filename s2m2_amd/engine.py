@@ -110,6 +110,8 @@ class Engine:
         self.use_k12 = os.environ.get("S2M2_K12", "1") != "0"
         # S2M2_K12_HEAD=0: UpsampleMask1x's conv_concat.0 and conv_concat.2 as two launches (K12 + K11) instead of the fused head
         self.use_k12_head = self.use_k12 and os.environ.get("S2M2_K12_HEAD", "1") != "0"
+        # S2M2_REFINE_NATIVE=0: every refinement iteration enqueued from Python (A/B; the default replays a recorded plan: s2m2_refine_step)
+        self.native_refine = os.environ.get("S2M2_REFINE_NATIVE", "1") != "0"
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -568,6 +570,38 @@ class Engine:
                          [u])
         return (hn,) + tuple(hip.refine_update(dco, disp, conf, occ, self.use_positivity, want_small=want_small))
 
+    def refine_step_native(self, it: int, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor,
+                           small: Optional[Tensor], want_small: bool):
+        """One refinement iteration through the library's recorded plan (s2m2_refine_step, include/s2m2_hip.h): the ~55 launches of
+        local_refiner are enqueued by ONE native call instead of ~55 Python -> ctypes round trips.  Life cycle per (iteration, shapes,
+        scratch namespace): call 1 runs local_refiner as always (weights get packed, kernel attributes set), call 2 runs it once more while the
+        library records (its intermediates and outputs are allocated from a private MemPool that lives with the plan), every later call
+        replays the plan with the seven externals -- hidden, ctx, disp, conf, occ, cv, side input -- wherever they are now; the iteration's
+        outputs are the tensors of the recorded run.  A captured hipGraph (GraphRunner: two warm-up forwards, then the capture) therefore
+        holds the plan's launches; bit-identical to the Python-enqueued iteration (tests/test_hip_e2e.py)."""
+        ns = self._ns if self._ns is not None else torch.cuda.current_stream(self.device).cuda_stream   # eager: one plan (and its intermediates) per stream
+        key = ("refine_plan", it, tuple(hidden.shape), tuple(cv.shape), cv.stride(2), hidden.dtype, small is None, want_small, ns)
+        ent = self._bufs.get(key)
+        if ent is None:                                            # first call: the plain Python path (one-time set-up happens here)
+            self._bufs[key] = "warm"
+            return self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, None, it, small=small, want_small=want_small)
+        ext = [hidden, ctx, disp, conf, occ, cv, small]
+        if ent == "warm":
+            plan, pool, scratch = hip.Plan(), torch.cuda.MemPool(), {}
+            outer = (self._bufs, self._ns)
+            self._bufs, self._ns = scratch, ("plan", it)          # the iteration's persistent scratch belongs to the plan as well
+            try:
+                with torch.cuda.use_mem_pool(pool, device=self.device):
+                    with _PlanRecord(plan, ext, cv):
+                        res = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, None, it, small=small, want_small=want_small)
+            finally:
+                self._bufs, self._ns = outer
+            self._bufs[key] = (plan, res, pool, scratch)
+            return res
+        plan, res, _, _ = ent
+        plan.refine_step(*ext)
+        return res
+
     # ---- upsampling masks ----------------------------------------------------------------------------
     def mask4x(self, p: str, hidden: Tensor, f2x: Tensor) -> Tensor:
         """UpsampleMask4x (submodules.py:96-115) -> logits (B,H,W,16), 9 used."""
@@ -684,7 +718,10 @@ class Engine:
         small = None
         for it in range(self.refine_iter):
             more = it + 1 < self.refine_iter                       # the epilogue also writes the next iteration's side input
-            res = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, cap, it, small=small, want_small=more)
+            if self.native_refine and cap is None and hip.METER is None and disp.is_contiguous():
+                res = self.refine_step_native(it, hidden, ctx, disp, conf, occ, cv, small, more)
+            else:
+                res = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, cap, it, small=small, want_small=more)
             hidden, disp, conf, occ = res[:4]
             small = res[4] if more else None
             if cap is not None:
@@ -727,6 +764,34 @@ class Engine:
     def _conv0(self) -> Spec:
         """cnn_backbone.conv0.0 (1x1, 3 -> 16) reading the RGB planes from channels 1..3 of the 8-channel input tensor."""
         return self.merged("cnn_backbone.conv0.0|rgb@1", [("cnn_backbone.conv0.0", 1, 1.0, False)], 8)
+
+
+class _PlanRecord:
+    """hip.Plan.record with the cost volume's extent taken from its strides (a row-padded ``[..., :w]`` view: numel() undercounts it)"""
+
+    def __init__(self, plan, ext, cv):
+        self.plan, self.ext, self.cv = plan, ext, cv
+
+    def __enter__(self):
+        class _Span:                                               # duck-typed "tensor" carrying base pointer and byte extent
+            def __init__(s, t, nbytes):
+                s.t, s.nbytes = t, nbytes
+
+            def data_ptr(s):
+                return s.t.data_ptr()
+
+            def numel(s):
+                return s.nbytes
+
+            def element_size(s):
+                return 1
+        cv = self.cv
+        span = _Span(cv, cv.shape[0] * cv.stride(0) * cv.element_size())
+        self.rec = self.plan.record([span if t is cv else t for t in self.ext])
+        return self.rec.__enter__()
+
+    def __exit__(self, *a):
+        return self.rec.__exit__(*a)
 
 
 class GraphRunner:

@@ -81,6 +81,14 @@ SIGNATURES = {
     "s2m2_last_error": (ctypes.c_char_p, []),
     "s2m2_ln_corr_kernel_name": (ctypes.c_char_p, [_i, _i, _i]),
     "s2m2_cost_volume": (_i, [ctypes.POINTER(CorrDesc), _vp]),
+    "s2m2_plan_begin": (_i, [ctypes.POINTER(_vp)]),
+    "s2m2_plan_end": (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_size_t), _i]),
+    "s2m2_plan_abort": (_i, [_vp]),
+    "s2m2_plan_launches": (_i, [_vp]),
+    "s2m2_plan_patches": (_i, [_vp, _i]),
+    "s2m2_plan_run": (_i, [_vp, ctypes.POINTER(_vp), _i, _vp]),
+    "s2m2_plan_destroy": (_i, [_vp]),
+    "s2m2_refine_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "s2m2_pack_frag_elems": (_ll, [ctypes.POINTER(PackDesc)]),
     "s2m2_pack_frag": (_i, [ctypes.POINTER(PackDesc), _vp]),
     "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -196,6 +204,64 @@ def pack_frag(kind: int, w: torch.Tensor, w2: Optional[torch.Tensor] = None, nta
     with torch.cuda.device(w.device):
         _check(lib.s2m2_pack_frag(ctypes.byref(d), _stream()), "s2m2_pack_frag")
     return out
+
+
+class Plan:
+    """A recorded launch plan (s2m2_plan_*): ``with Plan.record(externals) as p: ...`` records every library call this thread makes inside the
+    block (they run as always); afterwards ``p.run(externals)`` re-issues the sequence natively with the external tensors somewhere else.
+    externals: list of tensors (or None).  The tensors allocated inside the block must be kept alive by the caller (engine: a private MemPool)."""
+
+    def __init__(self):
+        self.h = _vp()
+        self.n = 0
+        self.sealed = False
+
+    class _Rec:
+        def __init__(self, plan, externals):
+            self.plan, self.ext = plan, externals
+
+        def __enter__(self):
+            _check(load().s2m2_plan_begin(ctypes.byref(self.plan.h)), "s2m2_plan_begin")
+            return self.plan
+
+        def __exit__(self, et, ev, tb):
+            lib = load()
+            if et is not None:
+                lib.s2m2_plan_abort(self.plan.h)
+                return False
+            n = len(self.ext)
+            base = (_vp * max(n, 1))(*[(t.data_ptr() if t is not None else None) for t in self.ext])
+            size = (ctypes.c_size_t * max(n, 1))(*[(t.numel() * t.element_size() if t is not None else 0) for t in self.ext])
+            _check(lib.s2m2_plan_end(self.plan.h, base, size, n), "s2m2_plan_end")
+            self.plan.n, self.plan.sealed = n, True
+            return False
+
+    def record(self, externals):
+        return Plan._Rec(self, externals)
+
+    @property
+    def launches(self) -> int:
+        return load().s2m2_plan_launches(self.h)
+
+    def patches(self, slot: int = -1) -> int:
+        return load().s2m2_plan_patches(self.h, slot)
+
+    def run(self, externals) -> None:
+        n = len(externals)
+        ptrs = (_vp * max(n, 1))(*[(t.data_ptr() if t is not None else None) for t in externals])
+        _check(load().s2m2_plan_run(self.h, ptrs, n, _stream()), "s2m2_plan_run")
+
+    def refine_step(self, hidden, ctx, disp, conf, occ, cv, side) -> None:
+        """s2m2_refine_step: this plan as one refinement iteration, externals in the ABI's fixed order"""
+        p = [t.data_ptr() if t is not None else None for t in (hidden, ctx, disp, conf, occ, cv, side)]
+        _check(load().s2m2_refine_step(self.h, *p, _stream()), "s2m2_refine_step")
+
+    def __del__(self):
+        try:
+            if self.h:
+                load().s2m2_plan_destroy(self.h)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 class KernelTimer:
@@ -380,8 +446,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
             ac = Cout - epi_cout0 if name == "aux0" else Cout
             if a.dtype != dt or tuple(a.shape) != (n, ho, wo, ac):
                 raise ValueError(f"conv2d: {name} must be {(n, ho, wo, ac)} {dt}, got {tuple(a.shape)} {a.dtype}")
-            # (the kernel indexes aux0 with the cout: a tensor that covers couts >= epi_cout0 starts epi_cout0 elements "before" its base)
-            setattr(d, name, a.data_ptr() - (epi_cout0 * a.element_size() if name == "aux0" else 0))
+            setattr(d, name, a.data_ptr())                       # (aux0 of an epi_cout0 launch: its own base; the library applies the cout offset)
             setattr(d, name + "_stride", _nhwc(a))
     d.epi_cout0 = epi_cout0
     d.out_scale = out_scale

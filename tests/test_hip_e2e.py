@@ -114,3 +114,45 @@ def test_smallest_legal_image():
     l, r = synthetic_pair(32, 32, 1, 2, 3)
     d, o, c = m(l.cuda(), r.cuda())
     assert tuple(d.shape) == (1, 1, 32, 32) and torch.isfinite(d).all()
+
+
+def test_native_refine_step_is_bit_identical_and_rebinds_its_inputs(monkeypatch):
+    """s2m2_refine_step (a recorded plan per refinement iteration, replayed from C++) against the Python-enqueued iteration: eager forwards on
+    CHANGING images -- call 1 warms, call 2 records, calls 3+ replay with the externals (hidden, ctx, disp, conf, occ, cv) at new addresses and
+    with new contents -- and the hipGraph path, which captures the plan's launches."""
+    import torch
+    from s2m2_amd import hip
+    from s2m2_amd.model import S2M2
+    from s2m2_amd.weights import seeded_state_dict, synthetic_pair
+    sd = seeded_state_dict(128, 1, 1, 0)
+
+    def build():
+        m = S2M2(128, 1, 1, use_positivity=True, refine_iter=3)
+        m.load_state_dict(sd, strict=True)
+        return m.cuda().eval()
+
+    pairs = [tuple(t.cuda() for t in synthetic_pair(96, 160, 1, 8 + 4 * k, k)) for k in range(4)]
+    monkeypatch.setenv("S2M2_GRAPH", "0")
+    monkeypatch.setenv("S2M2_REFINE_NATIVE", "0")
+    ref_m = build()
+    with torch.autocast("cuda", dtype=torch.float16):
+        ref = [tuple(o.clone() for o in ref_m(l, r)) for l, r in pairs]
+    monkeypatch.setenv("S2M2_REFINE_NATIVE", "1")
+    nat_m = build()
+    keep = []                                                      # hold earlier outputs: forces the allocator to hand out new addresses
+    with torch.autocast("cuda", dtype=torch.float16):
+        for k, (l, r) in enumerate(pairs):
+            out = nat_m(l, r)
+            keep.append(torch.empty(1 << 20, device="cuda"))
+            for a, b in zip(out, ref[k]):
+                assert torch.equal(a, b), f"forward {k}"
+    eng = next(iter(nat_m._engines.values()))
+    plans = [v for k_, v in eng._bufs.items() if isinstance(k_, tuple) and k_[0] == "refine_plan" and isinstance(v, tuple)]
+    assert len(plans) == 3 and all(p[0].launches > 40 for p in plans), [p[0].launches for p in plans]
+    monkeypatch.setenv("S2M2_GRAPH", "1")                          # graph path: two warm-ups, capture, replays
+    g_m = build()
+    with torch.autocast("cuda", dtype=torch.float16):
+        for k, (l, r) in enumerate(pairs):
+            out = g_m(l, r)
+            for a, b in zip(out, ref[k]):
+                assert torch.equal(a, b), f"graph forward {k}"
