@@ -48,9 +48,44 @@ template <> struct DT<half_t> { static constexpr int code = S2M2_F16; static con
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(half_t x) { return (float)x; }
+// fp16 headroom probe (experiment builds only: -DS2M2_RANGE_CHECK=1 -> libs2m2_hip_range.so, tools/range_report.py): every fp32 -> fp16
+// conversion of the library goes through from_f32<half_t>; in the probe build it also folds |x| into ONE device word (atomic max on the bit
+// pattern: non-negative floats order like unsigned integers, NaN patterns sort above infinity), which the host moves into a per-launch log
+// after every launch (plan.h: plan_dispatch).  A trained checkpoint whose activations leave the fp16 range shows up as a ratio >= 1 (or NaN)
+// against 65504 in the layer that produces them -- before the value is rounded to inf.  The shipped library carries none of this.
+#ifndef S2M2_RANGE_CHECK
+#define S2M2_RANGE_CHECK 0
+#endif
+#if S2M2_RANGE_CHECK
+static __device__ unsigned* g_range_word_tu = nullptr;    // this translation unit's copy of the pointer to the library's range word
+unsigned* range_word();                                   // runtime.hip: the word (device memory, per device), allocated on first use
+int range_collect(const char* name, void* stream);        // runtime.hip: log[n++] = {name, word}; word = 0   (one tiny launch)
+static void range_bind_tu() {                             // (internal linkage: one copy, and one `bound` flag, PER translation unit) called by plan_dispatch before every launch
+    static bool bound[kMaxDevices] = {};
+    const int dev = current_device();
+    if (!bound[dev]) {
+        unsigned* w = range_word();
+        if (w && hipMemcpyToSymbol(HIP_SYMBOL(g_range_word_tu), &w, sizeof(w)) == hipSuccess) bound[dev] = true;
+    }
+}
+__device__ __forceinline__ void range_note(float x) {
+    unsigned* w = g_range_word_tu;
+    const unsigned b = __builtin_bit_cast(unsigned, x) & 0x7fffffffu;
+    if (w && b > *reinterpret_cast<volatile unsigned*>(w)) atomicMax(w, b);
+    // the kernels with untracked load rings count their waits (wait_vmcnt<N>): an atomic in flight ticks the same counter and may retire out of
+    // order with the loads, which would let a counted wait pass early -- drain before going on (the probe build is not a fast build)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+#endif
+
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
-template <> __device__ __forceinline__ half_t from_f32<half_t>(float x) { return (half_t)x; }
+template <> __device__ __forceinline__ half_t from_f32<half_t>(float x) {
+#if S2M2_RANGE_CHECK
+    range_note(x);
+#endif
+    return (half_t)x;
+}
 
 // load through an explicit global (address space 1) pointer: keeps the access a global_load even where the compiler cannot
 // prove the address space of a selected pointer (a flat load would also tick lgkmcnt and serialise with the LDS traffic)

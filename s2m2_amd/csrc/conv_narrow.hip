@@ -375,7 +375,7 @@ __global__ __launch_bounds__(CFG::NT) void conv_px_kernel(NarrowArgs p, int tile
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float a = acc[h * CFG::SM + i][j][4 * g + e] + bv[e];
-                                yf.v[4 * q + e] = (half_t)(relu ? fmaxf(a, 0.f) : a);       // (NONE / RELU only: checked by the host entry)
+                                yf.v[4 * q + e] = from_f32<half_t>(relu ? fmaxf(a, 0.f) : a);       // (NONE / RELU only: checked by the host entry)
                             }
                         }
                         mma32(acc2[i][0], w2f[2 * j + pp], yf);

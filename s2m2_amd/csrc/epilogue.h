@@ -120,7 +120,7 @@ __device__ __forceinline__ void stage_tile(const float16_t (&acc)[CFG::MT][CFG::
                         v[e] = (S2M2_CONV_DBG & 16) ? acc[i][j][4 * g + e] : activate<ACT>(acc[i][j][4 * g + e] + bv[e]) * out_scale;
                 }
                 if constexpr (sizeof(T) == 2) {
-                    half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    half4_t h = {from_f32<half_t>(v[0]), from_f32<half_t>(v[1]), from_f32<half_t>(v[2]), from_f32<half_t>(v[3])};
                     *reinterpret_cast<half4_t*>(crow + cl) = h;
                 } else {
                     float4_t f = {v[0], v[1], v[2], v[3]};

@@ -180,7 +180,7 @@ __device__ __forceinline__ void load_token(Vec16<T> (&p)[CFG::PPL], const T* __r
 
 template <typename TO> __device__ __forceinline__ void store_quad(TO* dst, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store_quad<half_t>(half_t* dst, float a, float b, float c, float d) {
-    half4_t v = {(half_t)a, (half_t)b, (half_t)c, (half_t)d};
+    half4_t v = {from_f32<half_t>(a), from_f32<half_t>(b), from_f32<half_t>(c), from_f32<half_t>(d)};
     *reinterpret_cast<half4_t*>(dst) = v;
 }
 template <> __device__ __forceinline__ void store_quad<float>(float* dst, float a, float b, float c, float d) {

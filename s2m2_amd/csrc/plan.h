@@ -3,6 +3,7 @@
 // plan as a flat blob (positional arguments as a trivially copyable pack, descriptors by value) together with a trampoline that re-issues it.
 #pragma once
 #include <stddef.h>
+#include "common.h"
 
 namespace s2m2 {
 
@@ -29,7 +30,12 @@ template <typename... A> inline void fill_pack(ArgPack<A...>&) {}
 template <typename H, typename... T> inline void fill_pack(ArgPack<H, T...>& p, H h, T... t) { p.head = h; fill_pack(p.tail, t...); }
 
 template <typename... A> int plan_dispatch(const char* name, int (*impl)(A..., void*), void* stream, A... a) {
+#if S2M2_RANGE_CHECK
+    range_bind_tu();
+    const int rc = impl(a..., stream) || range_collect(name, stream);
+#else
     const int rc = impl(a..., stream);
+#endif
     if (rc == 0 && plan_recording()) {
         PlanBlob<A...> b;
         __builtin_memset(&b, 0, sizeof(b));                        // padding words are scanned too: keep them deterministic
@@ -46,7 +52,12 @@ template <typename D> int plan_desc_tramp(const void* blob, void* stream) {
     return b->impl(&b->desc, stream);
 }
 template <typename D> int plan_dispatch_desc(const char* name, int (*impl)(const D*, void*), const D* d, void* stream) {
+#if S2M2_RANGE_CHECK
+    range_bind_tu();
+    const int rc = impl(d, stream) || range_collect(name, stream);
+#else
     const int rc = impl(d, stream);
+#endif
     if (rc == 0 && d && plan_recording()) {
         PlanDescBlob<D> b;
         __builtin_memset(&b, 0, sizeof(b));

@@ -216,5 +216,62 @@ extern "C" int s2m2_refine_step(const s2m2_plan* step, const void* hidden, const
     return s2m2_plan_run(step, ext, 7, stream);
 }
 
+#if S2M2_RANGE_CHECK
+// ---- fp16 headroom probe (common.h): the range word, the per-launch log and its read-out (libs2m2_hip_range.so only) --------------------
+namespace s2m2 {
+constexpr int kRangeLog = 4096;
+static unsigned* g_range_dev[kMaxDevices] = {};           // [0]: the live word, [1 .. kRangeLog]: the log
+static std::vector<const char*> g_range_names;
+static std::mutex g_range_mutex;
+
+unsigned* range_word() {
+    std::lock_guard<std::mutex> lock(g_range_mutex);
+    unsigned*& p = g_range_dev[current_device()];
+    if (!p && (hipMalloc(&p, (kRangeLog + 1) * sizeof(unsigned)) != hipSuccess || hipMemset(p, 0, (kRangeLog + 1) * sizeof(unsigned)) != hipSuccess)) p = nullptr;
+    return p;
+}
+
+__global__ void range_collect_kernel(unsigned* buf, int slot) {
+    buf[1 + slot] = buf[0];
+    buf[0] = 0u;
+}
+
+int range_collect(const char* name, void* stream) {
+    unsigned* buf = range_word();
+    if (!buf) return set_error("range probe: cannot allocate the log");
+    int slot;
+    {
+        std::lock_guard<std::mutex> lock(g_range_mutex);
+        slot = (int)g_range_names.size();
+        if (slot >= kRangeLog) return 0;                           // log full: later launches are not recorded
+        g_range_names.push_back(name);
+    }
+    hipLaunchKernelGGL(range_collect_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), buf, slot);
+    return check_launch("range_collect");
+}
+}  // namespace s2m2
+
+// read-out: synchronises the device; returns the number of logged launches, fills max |value| converted to fp16 per launch (up to cap);
+// s2m2_debug_range_name(i): the entry point of launch i; s2m2_debug_range_reset(): empties the log
+extern "C" int s2m2_debug_range_log(float* maxima, int cap) {
+    using namespace s2m2;
+    unsigned* buf = range_word();
+    if (!buf || hipDeviceSynchronize() != hipSuccess) return -1;
+    const int n = (int)g_range_names.size();
+    std::vector<unsigned> host((size_t)n + 1);
+    if (n && hipMemcpy(host.data(), buf, ((size_t)n + 1) * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < cap; ++i) memcpy(&maxima[i], &host[1 + i], sizeof(float));
+    return n;
+}
+extern "C" const char* s2m2_debug_range_name(int i) {
+    return (i >= 0 && i < (int)s2m2::g_range_names.size()) ? s2m2::g_range_names[i] : "";
+}
+extern "C" int s2m2_debug_range_reset(void) {
+    std::lock_guard<std::mutex> lock(s2m2::g_range_mutex);
+    s2m2::g_range_names.clear();
+    return 0;
+}
+#endif
+
 extern "C" int s2m2_version(void) { return S2M2_ABI_VERSION; }   // include/s2m2_hip.h
 extern "C" const char* s2m2_last_error(void) { return s2m2::g_err; }
