@@ -180,13 +180,16 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     constexpr int K_TASKS = KVT * KP, V_TASKS = (KVT / 4) * KP;
     constexpr int MINT = 64 * CFG::MINW;                        // blocks have >= MINW waves (launch_attn)
     constexpr int K_IT_MAX = (K_TASKS + MINT - 1) / MINT, V_IT_MAX = (V_TASKS + MINT - 1) / MINT;
-    Vec16<T> rk[K_IT_MAX];
-    Vec16<T> rv[V_IT_MAX][4];
+    // key-split blocks (few, long rows; fp16, no PE) are chains of short stages -- two sub-tiles of arithmetic per wave between the barriers --
+    // whose K / V fetch (requested one stage ahead) is not covered by that arithmetic: they keep TWO stages in flight in registers
+    constexpr bool DEEP = CFG::KSPLIT && !CFG::PE && sizeof(T) == 2 && !(S2M2_ATTN_DBG & 16);
+    Vec16<T> rkA[K_IT_MAX], rkB[DEEP ? K_IT_MAX : 1];
+    Vec16<T> rvA[V_IT_MAX][4], rvB[DEEP ? V_IT_MAX : 1][4];
     auto zero16 = []() { Vec16<T> z;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { if constexpr (sizeof(T) == 2) z.v[e] = (half_t)0.f; else z.v[e] = 0.f; }
         return z; };
-    auto fetch = [&](int kv0) __attribute__((always_inline)) {
+    auto fetch_into = [&](auto& rk, auto& rv, int kv0) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < K_IT_MAX; ++it) {
             const int t = tid + it * nthr;
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
             }
         }
     };
-    auto stash = [&]() __attribute__((always_inline)) {
+    auto stash_from = [&](auto& rk, auto& rv) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < K_IT_MAX; ++it) {
             const int t = tid + it * nthr;
@@ -255,12 +258,7 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     const int yq = CFG::PE ? qi_pe / a.gw : 0, xq = CFG::PE ? qi_pe - yq * a.gw : 0;
 
     const int nstage = (a.Nk + KVT - 1) / KVT;
-    fetch(0);
-    for (int t = 0; t < nstage; ++t) {
-        if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();      // previous stage fully consumed (also covers the PE table fill)
-        if (!(S2M2_ATTN_DBG & 1) || t == 0) stash();
-        if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();
-        if (t + 1 < nstage && !(S2M2_ATTN_DBG & 1)) fetch((t + 1) * KVT);   // in flight under this stage's MFMAs
+    auto compute_stage = [&](int t) __attribute__((always_inline)) {
         if (wave_active) {
 #pragma unroll 1
             for (int sub = CFG::KSPLIT ? wv : 0; sub < CFG::KT; sub += CFG::KSPLIT ? 4 : 1) {
@@ -280,20 +278,31 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 }
                 // ---- online softmax (lane: one query, keys crow(r, hi) of this sub-tile)
                 // scores in the log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 = 2^x): m_run, m_new are log2-domain maxima
+                // (the maximum is taken on the raw scores and scaled once -- scale2 > 0 --, and scale and shift are ONE fma per element:
+                // 4 instead of 5 VALU operations per score)
                 float p[16];
-                float mloc = -INFINITY;
+                float smax = -INFINITY;
+                const bool full = kv0 + 32 <= a.Nk;                // (wave-uniform) a whole sub-tile of keys: no per-element bound check
+                if (full) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kv = kv0 + acc_row(r, lane);
-                    p[r] = kv < a.Nk ? sacc[r] * scale2 : -INFINITY;
-                    mloc = fmaxf(mloc, p[r]);
+                    for (int r = 0; r < 16; ++r) smax = fmaxf(smax, sacc[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + acc_row(r, lane);
+                        sacc[r] = kv < a.Nk ? sacc[r] : -INFINITY;
+                        smax = fmaxf(smax, sacc[r]);
+                    }
                 }
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                const float m_new = fmaxf(m_run, mloc);           // finite: every sub-tile has at least one valid key
+                smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
+                const float m_new = fmaxf(m_run, smax * scale2);   // finite: every sub-tile has at least one valid key
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 2^(-inf) = 0 on the first tile
                 float lsum = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = (S2M2_ATTN_DBG & 2) ? p[r] : __builtin_amdgcn_exp2f(p[r] - m_new); lsum += p[r]; }
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = (S2M2_ATTN_DBG & 2) ? sacc[r] : __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], scale2, -m_new));   // (-inf * scale2 - m = -inf: 0)
+                    lsum += p[r];
+                }
                 l_run = l_run * alpha + lsum;
                 m_run = m_new;
                 if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {                 // the running maximum rarely moves after the first tiles
@@ -351,6 +360,35 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                     }
                 }
             }
+        }
+    };
+    if constexpr (DEEP) {
+        // two stages in flight: stage t is stashed from one register set while stage t + 1 is still landing in the other; the set just stashed
+        // is re-requested with stage t + 2 right away
+        fetch_into(rkA, rvA, 0);
+        if (nstage > 1) fetch_into(rkB, rvB, KVT);
+        for (int t = 0; t < nstage; t += 2) {
+            __syncthreads();                                      // previous stage fully consumed
+            stash_from(rkA, rvA);
+            __syncthreads();
+            if (t + 2 < nstage) fetch_into(rkA, rvA, (t + 2) * KVT);
+            compute_stage(t);
+            if (t + 1 < nstage) {
+                __syncthreads();
+                stash_from(rkB, rvB);
+                __syncthreads();
+                if (t + 3 < nstage) fetch_into(rkB, rvB, (t + 3) * KVT);
+                compute_stage(t + 1);
+            }
+        }
+    } else {
+        fetch_into(rkA, rvA, 0);
+        for (int t = 0; t < nstage; ++t) {
+            if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();      // previous stage fully consumed (also covers the PE table fill)
+            if (!(S2M2_ATTN_DBG & 1) || t == 0) stash_from(rkA, rvA);
+            if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();
+            if (t + 1 < nstage && !(S2M2_ATTN_DBG & 1)) fetch_into(rkA, rvA, (t + 1) * KVT);   // in flight under this stage's MFMAs
+            compute_stage(t);
         }
     }
 
