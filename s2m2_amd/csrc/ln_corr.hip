@@ -463,10 +463,9 @@ static int launch_ln_corr(const void* feat, const float* g, const float* bta, vo
     if (reserve_lds(reinterpret_cast<const void*>(kern), CFG::lds_bytes(CFG::NWMAX), lds_granted, "ln_corr")) return 1;
     const int tiles = (w + 31) / 32;                     // 32-pixel row tiles = waves needed per image row
     int nstrip = (tiles + CFG::NWMAX - 1) / CFG::NWMAX;
-    // small problems: split rows into strips until the grid covers the chip (each strip re-reads / re-normalises the right row).
-    // S2M2_K1_MINBLOCKS (experiment switch): the block count below which a row is split further
-    static const int minblocks = getenv("S2M2_K1_MINBLOCKS") ? atoi(getenv("S2M2_K1_MINBLOCKS")) : 200;
-    while (B * h * nstrip < minblocks && nstrip < tiles && (tiles + nstrip) / (nstrip + 1) >= (minblocks > 200 ? 1 : 2)) ++nstrip;
+    // small problems: split rows into strips until the grid covers the chip (each strip re-reads / re-normalises the right row).  More, smaller
+    // blocks do not help the 120-row case (c2): 240 three-wave blocks 12.1 us, 480-600 one- / two-wave blocks 14.6-15.6 us (profiles/r05/k1_minblocks.txt)
+    while (B * h * nstrip < 200 && nstrip < tiles && (tiles + nstrip) / (nstrip + 1) >= 2) ++nstrip;
     int nw = (tiles + nstrip - 1) / nstrip;
     nw = (nw + CFG::NWGRAN - 1) / CFG::NWGRAN * CFG::NWGRAN;      // chunks of nw * TPW right tokens are whole 32-column tiles
     const int nblocks = B * h * nstrip;

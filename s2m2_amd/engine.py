@@ -711,7 +711,14 @@ class Engine:
         # (measured and dropped, profiles/r04/ab_k1_store_sc1lib_overlap.txt: this branch -- and the f2x layers of the two mask heads -- on a second stream as
         # parallel branches of the captured hipGraph: 8.95 vs 8.83 ms per pair and K1 19.4 vs 17.7 us, the side kernels evict K1's tokens)
         fus = self.fusion("feat_fusion_layer", tr0, py0[:B])
-        ctx = self.cconv(self.std("ctx_feat.2"), [self.cconv(self.std("ctx_feat.0"), [fus], act=hip.ACT_GELU)])
+        c0, c2 = self.std("ctx_feat.0"), self.std("ctx_feat.2")
+        cc = fus.shape[-1]
+        if (c0[2] == 1 and c2[2] == 1 and tuple(c0[0].shape) == (cc, cc) and tuple(c2[0].shape) == (cc, cc) and not getattr(c0, "korder", 0)
+                and self.chain_frag_ok(cc)):
+            # ctx_feat = 1x1 - GELU - 1x1 (s2m2.py:59,165): ONE two-stage K9 launch (the intermediate never leaves the CU) instead of two
+            ctx = hip.mlp_chain(fus, [(self.wfrag(c0), c0[1], hip.ACT_GELU, None), (self.wfrag(c2), c2[1], hip.ACT_NONE, None)], frag=True)
+        else:
+            ctx = self.cconv(c2, [self.cconv(c0, [fus], act=hip.ACT_GELU)])
         hidden = hip.tanh(ctx)
         if cap is not None:
             cap["ctx"] = ctx.permute(0, 3, 1, 2)
