@@ -38,6 +38,41 @@ __device__ __forceinline__ float fast_gelu(float x) {
     const float q = pl * t * __builtin_amdgcn_exp2f((ax * ax) * (-0.5f * 1.44269504088896340736f));
     return __builtin_fmaf(-ax, q, fmaxf(x, 0.f));
 }
+// GELU whose result is rounded to fp16 (every GELU of the fp16 forward: the hidden activations feed the next layer's MFMAs as fp16):
+//   x Phi(x) = relu(x) - a Phi(-a),  a = |x|,  Phi(-a) = 2^P(a),  P = the degree-7 minimax fit of log2 Phi(-a) on [0, 6.5] (Remez,
+//   |P - log2 Phi(-a)| <= 6.8e-6: RELATIVE error 4.7e-6 of the a Phi(-a) term, absolute <= 8.1e-7 over all x; past 6.5 the leading
+//   coefficient keeps P falling and the term is < 1e-13).
+// Per PAIR of elements: 2 and + 7 v_pk_fma_f32 + 2 v_exp_f32 + 2 max + 1 v_pk_fma_f32 and NO reciprocal; fast_gelu costs 19 plain issues + 2 rcp
+// + 2 exp2 per pair, and the transcendental unit runs at a quarter of the fma rate (~140 -> ~80 issue cycles per pair).
+// Rounded to fp16 the result differs from the correctly rounded x Phi(x) at 0.13 % of a dense sweep of [-8, 8] (by one ulp); fast_gelu,
+// whose error is absolute (0.75e-7 |x|), differs at 4.1 % -- all of them in the negative tail where the result is an fp16 subnormal.
+// fp32 destinations keep fast_gelu (absolute error 3.3e-7 against 8.1e-7).
+#ifndef S2M2_GELU16_POLY
+#define S2M2_GELU16_POLY 1          // 0: A/B build with fast_gelu everywhere (the form up to round 4)
+#endif
+typedef float float2_t __attribute__((ext_vector_type(2)));
+// two elements at a time, written on 2-vectors so that every fma is a v_pk_fma_f32 (left to the compiler, the |x| of a scalar form is folded
+// into the fma as a source modifier, which the packed instruction does not have: seven unpacked fmas per element).  The empty asm pins the
+// fp32 result in registers: without it the compiler fuses the last fma and the conversion to fp16 into v_fma_mixlo_f16 (one rounding
+// instead of two) in SOME instantiations, and the forms of one layer (row-major / direct) stop agreeing bit for bit.
+__device__ __forceinline__ float2_t fast_gelu16x2(float2_t x) {
+    const float2_t a = __builtin_elementwise_abs(x);
+    float2_t p = __builtin_elementwise_fma((float2_t)(-1.7577767721377313e-06f), a, (float2_t)(5.9936584875686094e-05f));
+    p = __builtin_elementwise_fma(p, a, (float2_t)(-0.0009163629147224128f));
+    p = __builtin_elementwise_fma(p, a, (float2_t)(0.008447385393083096f));
+    p = __builtin_elementwise_fma(p, a, (float2_t)(-0.05382449924945831f));
+    p = __builtin_elementwise_fma(p, a, (float2_t)(-0.4586157202720642f));
+    p = __builtin_elementwise_fma(p, a, (float2_t)(-1.1511801481246948f));
+    p = __builtin_elementwise_fma(p, a, (float2_t)(-1.0000038146972656f));
+    const float2_t e = {__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)};
+    float2_t r = __builtin_elementwise_fma(-a, e, __builtin_elementwise_max(x, (float2_t)(0.f)));
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ float fast_gelu16(float x) {
+    const float2_t r = fast_gelu16x2((float2_t){x, x});
+    return r.x;
+}
 template <int ACT> __device__ __forceinline__ float activate(float x) {
 #if defined(S2M2_GELU_ERF_FORM)                                  // A/B build: the round-1 form 0.5 x (1 + erf(x / sqrt 2))
     if (ACT == S2M2_ACT_GELU) return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
@@ -47,6 +82,11 @@ template <int ACT> __device__ __forceinline__ float activate(float x) {
     if (ACT == S2M2_ACT_SIGMOID) return fast_rcp(1.0f + fast_exp(-x));
     if (ACT == S2M2_ACT_TANH) return 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * x));
     return x;
+}
+// the activation of a value that is stored as T next
+template <int ACT, typename T> __device__ __forceinline__ float activate_to(float x) {
+    if constexpr (ACT == S2M2_ACT_GELU && sizeof(T) == 2 && S2M2_GELU16_POLY) return fast_gelu16(x);
+    else return activate<ACT>(x);
 }
 
 // Pre-LayerNorm folded into a 1x1 layer (reference attentions.py:117,148,182,213,243: LayerNorm without affine feeding a Linear):
@@ -112,12 +152,19 @@ __device__ __forceinline__ void stage_tile(const float16_t (&acc)[CFG::MT][CFG::
                 if constexpr (LN) {
                     const raw16_t ws = wsum->v[j][g];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = activate<ACT>(ln[i].rstd * __builtin_fmaf(-ln[i].mean, ws[e], acc[i][j][4 * g + e]) + bv[e]) * out_scale;
+                    for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(ln[i].rstd, __builtin_fmaf(-ln[i].mean, ws[e], acc[i][j][4 * g + e]), bv[e]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = (S2M2_CONV_DBG & 16) ? acc[i][j][4 * g + e] : activate<ACT>(acc[i][j][4 * g + e] + bv[e]) * out_scale;
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
+                }
+                if constexpr (ACT == S2M2_ACT_GELU && sizeof(T) == 2 && S2M2_GELU16_POLY) {
+                    if (!(S2M2_CONV_DBG & 16)) {
+                        const float2_t r0 = fast_gelu16x2((float2_t){v[0], v[1]}), r1 = fast_gelu16x2((float2_t){v[2], v[3]});
+                        v[0] = r0.x * out_scale; v[1] = r0.y * out_scale; v[2] = r1.x * out_scale; v[3] = r1.y * out_scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (!LN && (S2M2_CONV_DBG & 16)) ? acc[i][j][4 * g + e] : activate<ACT>(v[e]) * out_scale;
                 }
                 if constexpr (sizeof(T) == 2) {
                     half4_t h = {from_f32<half_t>(v[0]), from_f32<half_t>(v[1]), from_f32<half_t>(v[2]), from_f32<half_t>(v[3])};

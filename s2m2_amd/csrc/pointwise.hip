@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void stem_mlp_kernel(const T* __restrict__ x8,
         float a = b0[j];
 #pragma unroll
         for (int k = 0; k < 8; ++k) a = __builtin_fmaf(w0[j * 8 + k], x[k], a);
-        h[j] = to_f32(from_f32<T>(activate<S2M2_ACT_GELU>(a)));
+        h[j] = to_f32(from_f32<T>(activate_to<S2M2_ACT_GELU, T>(a)));
     }
     float y[16];
 #pragma unroll
