@@ -49,6 +49,8 @@ struct AttnArgs {
     int xcd;                            // 1: XCD-aware block order (see attention_kernel)
 };
 
+template <int V> struct IntC { static constexpr int value = V; };       // compile-time mode argument of the key-loop lambda
+
 template <typename T, int DP_, bool PE_, int MINW_ = 4, bool KSPLIT_ = false, int NXT_ = 2, int NYT_ = 1>
 struct AttnCfg {
     static constexpr int NXT = NXT_, NYT = NYT_;         // PE: 32-wide bin tiles along x / y of the token grid (grid up to 32*NXT x 32*NYT)
@@ -77,6 +79,30 @@ struct AttnCfg {
     static constexpr size_t V_BYTES = (size_t)VROWS * VRS * sizeof(T);
     static constexpr int KP = DP / VEC;                  // 16-byte pieces per K/V row
     static constexpr int MAXW = (DP * sizeof(T) >= 384) ? 4 : 8;   // waves per block: 512 registers per lane for the wide heads
+    // d = 384 in fp16 (the XL model's 1/4 level): 12 output tiles = 192 accumulator registers, and the 24 Q fragments (96 registers) no longer
+    // fit next to the staging registers -- the compiler kept them in SCRATCH, re-read per 32-key sub-tile through the vector-memory path and,
+    // because vmcnt retires in order, behind the K / V prefetch of the NEXT stage (its whole latency exposed in every stage: 100 TF/s).
+    // Here the wave's 32 query rows live in LDS (same row stride as the K tile) and are read as fragments like the K operand.
+#ifndef S2M2_ATTN_TWOPASS
+#define S2M2_ATTN_TWOPASS 1            // 0: A/B build, the online softmax for every head dim (the form up to round 5)
+#endif
+#ifndef S2M2_ATTN_QLDS
+#define S2M2_ATTN_QLDS 1
+#endif
+    // Wide heads (d >= 192: the 1/4 level of the M / L / XL models) keep their 6-12 output tiles in accumulation registers (AGPRs).  The
+    // online softmax's `O *= alpha` is a VALU operation on them, and although it almost never runs, the compiler makes VGPRs the home of
+    // the tiles across the key loop and copies ALL of them to AGPRs and back around every stage's MFMAs (2 x 96-192 v_accvgpr moves per 32
+    // keys; plus scratch at d = 384).  TWOPASS removes the multiply instead of fighting the allocator: a first sweep over K takes the exact
+    // row maximum (QK^T only: a third more MFMA work, K staged twice), the second sweep runs softmax and PV against that fixed maximum --
+    // the tiles are touched by MFMAs alone.  Mathematically the same softmax; no running-maximum rounding at all.
+    // Measured (profiles/r05/ab_attn_twopass.txt, fp16, same box, against the online form with the d = 384 queries already in LDS):
+    //   d = 192 (512,1,304):  207 -> 156 us (256 registers instead of 336: two blocks per CU)
+    //   d = 384 (1024,1,608): 3290 -> 2273 us (no scratch; 5760 us in round 4 with the Q fragments in scratch as well)
+    //   d = 256 (512,1,304):  223 -> 256 us (312 registers either way, one block per CU: the extra QK^T sweep is not paid back) -> stays online
+    static constexpr bool TWOPASS = S2M2_ATTN_TWOPASS && !PE_ && !KSPLIT_ && (DP_ == 192 || DP_ >= 384);
+    static constexpr bool QLDS = S2M2_ATTN_QLDS && !PE_ && !KSPLIT_ && sizeof(T) == 2 && DP_ >= 384;
+    static constexpr size_t Q_OFF = (K_BYTES + V_BYTES + 15) / 16 * 16;
+    static constexpr size_t Q_WAVE_BYTES = (size_t)32 * KRS * sizeof(T);
     // (measured and dropped, profiles/r04/ab_minwaves.txt: a second launch bound of three waves per SIMD takes the key-split kernel from 208 to 121
     // registers without a spill -- four blocks per CU instead of two -- and changes nothing: 20.4 us, 8.857 vs 8.858 ms per pair)
     // KSPLIT merge scratch (reuses the K/V staging area after the key loop): running max / sum + the four partial O tiles
@@ -156,8 +182,27 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     }
 
     // ---- Q fragments of this wave (B operand: lane = query, 8 consecutive d per k16 step), zero beyond D
-    Frag<T> qf[CFG::KSTEPS];
-    {
+    Frag<T> qf[CFG::QLDS ? 1 : CFG::KSTEPS];
+    const T* qs_lane = nullptr;
+    if constexpr (CFG::QLDS) {
+        T* Qs = reinterpret_cast<T*>(smem + CFG::Q_OFF + (size_t)wv * CFG::Q_WAVE_BYTES);      // wave-private: no block barrier involved
+        qs_lane = Qs + (size_t)l31 * KRS + hi * 8;
+        if (wave_active) {
+#pragma unroll 4
+            for (int t = lane; t < 32 * KP; t += 64) {
+                const int r = t / KP, pc = t - r * KP;
+                int qi = q0 + r;
+                qi = qi < a.Nq ? qi : a.Nq - 1;
+                Vec16<T> v;
+                if (pc * VEC < a.D) v = *reinterpret_cast<const Vec16<T>*>(qb + (long long)qi * a.sq + pc * VEC);
+                else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) v.v[e] = (half_t)0.f;
+                }
+                *reinterpret_cast<Vec16<T>*>(Qs + (size_t)r * KRS + pc * VEC) = v;
+            }
+        }
+    } else {
         int qi = q0 + l31;
         qi = qi < a.Nq ? qi : a.Nq - 1;
         const T* qp = qb + (long long)qi * a.sq;
@@ -237,11 +282,48 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
         }
     };
 
+    auto fetch_k = [&](auto& rk, int kv0) __attribute__((always_inline)) {       // the K half of fetch_into / stash_from (TWOPASS, first sweep)
+#pragma unroll
+        for (int it = 0; it < K_IT_MAX; ++it) {
+            const int t = tid + it * nthr;
+            if (t < K_TASKS) {
+                const int r = t / KP, pc = t - r * KP;
+                const int kv = kv0 + r;
+                rk[it] = (kv < a.Nk && pc * VEC < a.D) ? *reinterpret_cast<const Vec16<T>*>(kb + (long long)kv * a.sk + pc * VEC) : zero16();
+            }
+        }
+    };
+    auto stash_k = [&](auto& rk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < K_IT_MAX; ++it) {
+            const int t = tid + it * nthr;
+            if (t < K_TASKS) {
+                const int r = t / KP, pc = t - r * KP;
+                *reinterpret_cast<Vec16<T>*>(Ks + (size_t)r * KRS + pc * VEC) = rk[it];
+            }
+        }
+    };
+
     float16_t oacc[ND];
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    if constexpr (CFG::TWOPASS) {
+        // the tiles start life as MFMA results (0 . 0 + 0): with every value that reaches the key loop's phi defined in an accumulation
+        // register, the compiler makes the phi an AGPR (SIFoldOperands::tryFoldPhiAGPR); zeros built by moves make it a VGPR phi with a
+        // copy of every tile in each direction per stage
+        Frag<T> zf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { if constexpr (sizeof(T) == 2) zf.v[e] = (half_t)0.f; else zf.v[e] = 0.f; }
+        if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(zf.v));   // (opaque: a constant-folded product would be moves again)
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(zf.v[e]));
+        }
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) mma32(oacc[dt], zf, zf);
+    }
     float16_t bacc[CFG::PE ? CFG::NXT + CFG::NYT : 1];        // PE: marginal bins^T [bin][query], x tiles then y tiles
     if constexpr (CFG::PE) {
 #pragma unroll
@@ -258,7 +340,10 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
     const int yq = CFG::PE ? qi_pe / a.gw : 0, xq = CFG::PE ? qi_pe - yq * a.gw : 0;
 
     const int nstage = (a.Nk + KVT - 1) / KVT;
-    auto compute_stage = [&](int t) __attribute__((always_inline)) {
+    // MODE 0: online softmax (running maximum, O rescaled when it moves); 1: row maximum only (first sweep of TWOPASS); 2: softmax + PV
+    // against the final maximum left in m_run by the first sweep
+    auto compute_stage = [&](int t, auto mode_c) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_c)::value;
         if (wave_active) {
 #pragma unroll 1
             for (int sub = CFG::KSPLIT ? wv : 0; sub < CFG::KT; sub += CFG::KSPLIT ? 4 : 1) {
@@ -273,6 +358,11 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 for (int kk = 0; kk < CFG::KSTEPS; ++kk) {
                     Frag<T> kf;
                     load_frag(kf, kp + kk * 16);
+                    if constexpr (CFG::QLDS) {
+                        Frag<T> qk;
+                        load_frag(qk, qs_lane + kk * 16);
+                        mma32(sacc, kf, qk);
+                    } else
                     if (S2M2_ATTN_DBG & 4) { sacc[kk & 15] += (float)kf.v[0] * (float)qf[kk].v[0]; } else
                     mma32(sacc, kf, qf[kk]);
                 }
@@ -295,8 +385,9 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                     }
                 }
                 smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
-                const float m_new = fmaxf(m_run, smax * scale2);   // finite: every sub-tile has at least one valid key
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 2^(-inf) = 0 on the first tile
+                if constexpr (MODE == 1) { m_run = fmaxf(m_run, smax * scale2); continue; }
+                const float m_new = MODE == 2 ? m_run : fmaxf(m_run, smax * scale2);   // finite: every sub-tile has at least one valid key
+                const float alpha = MODE == 2 ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);        // 2^(-inf) = 0 on the first tile
                 float lsum = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -305,11 +396,13 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
                 }
                 l_run = l_run * alpha + lsum;
                 m_run = m_new;
-                if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {                 // the running maximum rarely moves after the first tiles
+                if constexpr (MODE == 0) {
+                    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f)) {             // the running maximum rarely moves after the first tiles
 #pragma unroll
-                    for (int dt = 0; dt < ND; ++dt)
+                        for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                            for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+                    }
                 }
                 // ---- O^T += Vt . P^T
                 Frag<T> pf[2];
@@ -372,23 +465,33 @@ __global__ __launch_bounds__(CFG::MAXW * 64) void attention_kernel(AttnArgs a) {
             stash_from(rkA, rvA);
             __syncthreads();
             if (t + 2 < nstage) fetch_into(rkA, rvA, (t + 2) * KVT);
-            compute_stage(t);
+            compute_stage(t, IntC<0>{});
             if (t + 1 < nstage) {
                 __syncthreads();
                 stash_from(rkB, rvB);
                 __syncthreads();
                 if (t + 3 < nstage) fetch_into(rkB, rvB, (t + 3) * KVT);
-                compute_stage(t + 1);
+                compute_stage(t + 1, IntC<0>{});
             }
         }
     } else {
+        if constexpr (CFG::TWOPASS) {                                 // first sweep: K only, exact row maxima into m_run
+            fetch_k(rkA, 0);
+            for (int t = 0; t < nstage; ++t) {
+                __syncthreads();
+                stash_k(rkA);
+                __syncthreads();
+                if (t + 1 < nstage) fetch_k(rkA, (t + 1) * KVT);
+                compute_stage(t, IntC<1>{});
+            }
+        }
         fetch_into(rkA, rvA, 0);
         for (int t = 0; t < nstage; ++t) {
             if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();      // previous stage fully consumed (also covers the PE table fill)
             if (!(S2M2_ATTN_DBG & 1) || t == 0) stash_from(rkA, rvA);
             if (!(S2M2_ATTN_DBG & 8) || t == 0) __syncthreads();
             if (t + 1 < nstage && !(S2M2_ATTN_DBG & 1)) fetch_into(rkA, rvA, (t + 1) * KVT);   // in flight under this stage's MFMAs
-            compute_stage(t);
+            compute_stage(t, IntC<CFG::TWOPASS ? 2 : 0>{});
         }
     }
 
@@ -522,6 +625,7 @@ static int launch_attn_t(const AttnArgs& a, int nw, hipStream_t st) {
     auto kern = attention_kernel<CFG, T>;
     size_t lds = CFG::K_BYTES + CFG::V_BYTES;
     if (KSPLIT) lds = lds > CFG::MERGE_BYTES ? lds : CFG::MERGE_BYTES;
+    if (CFG::QLDS) lds = CFG::Q_OFF + (size_t)nw * CFG::Q_WAVE_BYTES;
     if (PE) {                                                     // tables + (w + h | 1) marginal bins per query of every wave
         auto need = [&](int n) { return CFG::PE_OFF + ((size_t)(2 * a.gw - 1 + 2 * a.gh - 1) * 16 + (size_t)n * 32 * CFG::SM) * sizeof(float); };
         // large token grids: fewer waves per block until tables + bins fit next to the K/V stages (the block count follows nw below;

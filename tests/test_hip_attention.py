@@ -30,6 +30,8 @@ CASES = [  # nb, heads, N, D, swap
     (6, 1, 304, 128, False), (4, 1, 304, 128, True), (4, 2, 152, 64, True), (4, 4, 76, 64, False), (2, 8, 300, 32, False),
     (2, 8, 1216, 32, True), (1, 8, 300, 16, False), (3, 1, 8, 128, False), (2, 1, 33, 64, True), (2, 2, 95, 48, False),
     (2, 1, 70, 256, True), (2, 2, 65, 96, False), (1, 8, 100, 24, False),
+    # the wide heads of the M / L / XL models' 1/4 level (two-sweep softmax, accumulators in AGPRs; d = 384 fp16: queries in LDS)
+    (2, 1, 304, 192, False), (2, 1, 70, 192, True), (2, 1, 304, 256, False), (2, 1, 608, 384, False), (4, 1, 100, 384, True), (1, 1, 8, 384, False),
 ]
 
 
@@ -47,6 +49,26 @@ def test_attention_vs_torch(hip, case, dtype):
     ref, _ = _ref(q, k, v, heads, swap)
     err = float((out.float() - ref).abs().max())
     assert err < (3e-5 if dtype == torch.float32 else 4e-3 * float(v.float().abs().max())), err
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("case", [(2, 1, 304, 128), (2, 1, 304, 192), (2, 1, 304, 256), (2, 1, 608, 384), (2, 8, 1216, 32)])
+def test_attention_row_maximum_late_in_the_key_sequence(hip, case, dtype):
+    """the dominant keys of every query sit in the LAST stage (and a second group in the middle): the running maximum of the online form moves
+    late, the two-sweep form of the wide heads must land on the same softmax"""
+    nb, heads, N, D = case
+    g = torch.Generator(device="cuda").manual_seed(N + D)
+    C = heads * D
+    q = torch.randn(nb, N, C, device="cuda", generator=g)
+    k = torch.randn(nb, N, C, device="cuda", generator=g) * 0.5
+    v = torch.randn(nb, N, C, device="cuda", generator=g)
+    k[:, N // 2: N // 2 + 3] *= 3.0
+    k[:, -5:] *= 6.0
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = hip.attention(q, k, v, heads)
+    ref, _ = _ref(q, k, v, heads, False)
+    err = float((out.float() - ref).abs().max())
+    assert err < (5e-5 if dtype == torch.float32 else 4e-3 * float(v.float().abs().max())), err
 
 
 def _tables(h, w, device):

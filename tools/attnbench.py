@@ -10,8 +10,12 @@ from tools.kbench import timeit_graph
 timeit = lambda fn, n: timeit_graph(fn, 20, 3)
 SHAPES = [("L0 self 1-D", 512, 1, 304, 128, False, None), ("L0 cross 1-D", 512, 1, 304, 128, True, None), ("L1 1-D", 256, 2, 152, 64, False, None),
           ("L2 1-D", 128, 4, 76, 64, False, None), ("L3 2-D self", 2, 8, 1216, 32, False, None), ("L3 2-D cross", 2, 8, 1216, 32, True, None),
-          ("refiner 2-D", 1, 8, 1216, 32, False, None), ("global ref 2-D", 1, 8, 1216, 16, False, None), ("pyramid PE", 2, 8, 1216, 32, False, (32, 38))]
+          ("refiner 2-D", 1, 8, 1216, 32, False, None), ("global ref 2-D", 1, 8, 1216, 16, False, None), ("pyramid PE", 2, 8, 1216, 32, False, (32, 38)),
+          ("M L0 1-D", 512, 1, 304, 192, False, None), ("L L0 1-D", 512, 1, 304, 256, False, None), ("XL L0 1-D", 1024, 1, 608, 384, False, None)]
+ONLY = os.environ.get("ATTNBENCH_ONLY", "")          # substring filter on the shape names
 for name, nb, h, N, d, swap, grid in SHAPES:
+    if ONLY and ONLY not in name:
+        continue
     C = h * d
     qkv = torch.randn(nb, N, 3 * C, device="cuda").half()
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
