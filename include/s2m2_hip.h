@@ -108,13 +108,17 @@ int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b,
  *   S2M2_PACK_ROWS       s2m2_chain_desc.weight / fan_weight with weight_frag = 1 (K9; stack the layers of fan_weight along rows),
  *                        s2m2_pw_desc.weight_frag (K11): [row tile of 32][k16 step][lane][8], zero padded to whole tiles / steps
  *   S2M2_PACK_NARROW     s2m2_narrow_desc.weight_frag (K12), ntap = KH * KW: as ROWS; layers on >= 128 input channels in chunks of 64
- *   S2M2_PACK_CONV_FRAG  s2m2_conv_desc.weight with korder = 2 (K5 v5), ntap = KH * KW: [cout tile][128-channel chunk][tap][k16 step]
+ *   S2M2_PACK_CONV_FRAG  s2m2_conv_desc.weight with korder = 2 (K5 v5), ntap = KH * KW: [cout tile][channel chunk][tap][k16 step], chunks of
+ *                        s2m2_conv_frag_chunk(rows, cols / ntap) channels (128; 192 for the layers of 192-channel models)
  *   S2M2_PACK_FUSION     s2m2_feature_fusion_frag's stream (K10): w = the first layers [feature_gate.0 ; feature_fusion.0] (3C, 2C) given as
  *                        rows = C, cols = 2C, w2 = [feature_gate.2 | feature_fusion.2] (C, 3C) (ld2: its row stride, 0 = 3C)
  *   S2M2_PACK_HEAD       s2m2_narrow_desc.head_frag: the 1x1 layer (rows <= 32 couts, cols = the 3x3 layer's couts) fused behind a K12 layer
  * One-time synchronous set-up (allocates and frees a small index map, waits for the stream): not for use under stream capture.
  */
 enum { S2M2_PACK_ROWS = 0, S2M2_PACK_NARROW = 1, S2M2_PACK_CONV_FRAG = 2, S2M2_PACK_FUSION = 3, S2M2_PACK_HEAD = 4 };
+/* channels per chunk of the K-order-2 stream of a layer (one input patch in LDS per chunk): 128, or 192 where that divides both sides and 128 does
+ * not divide Cout (Cout = Cin = 192, 192 <- 384: blocks of 192 couts, no padded couts, no half-empty chunk).  Packers and s2m2_conv2d use this rule. */
+static inline int s2m2_conv_frag_chunk(int cout, int cin) { return (cout % 128 != 0 && cout % 192 == 0 && cin % 192 == 0) ? 192 : 128; }
 typedef struct s2m2_pack_desc {
     int kind;
     const void* w;
@@ -234,8 +238,9 @@ typedef struct s2m2_conv_desc {
     int dtype;
     int korder;             /* K order of the packed weight: 0 = (Cout, KH, KW, Cin); 1 = (Cout, KH, Cin/CH, KW, CH) with CH = 64 bytes of
                                channels (32 fp16 / 16 fp32; Cin % CH == 0): horizontal taps become consecutive K tiles -> L1 reuse;
-                               2 = fp16 MFMA fragment stream [Cout/32][ceil(Cin/128)][KH*KW][8][64 lanes][8] (lane l: cout 32t + l%32,
-                               channel 128c + 16s + 8(l/32) + e; zero beyond Cin) for stride-1 3x3 / 3x1 / 1x3 layers with Cout % 128 == 0:
+                               2 = fp16 MFMA fragment stream [Cout/32][ceil(Cin/CK)][KH*KW][CK/16][64 lanes][8] (lane l: cout 32t + l%32,
+                               channel CK c + 16s + 8(l/32) + e; zero beyond Cin; CK = s2m2_conv_frag_chunk(Cout, Cin)) for stride-1
+                               3x3 / 3x1 / 1x3 layers with Cout % 128 == 0, or Cout % 192 == 0 and Cin % 192 == 0:
                                the weights go from L2 straight into MFMA operands, only the input patch is staged in LDS */
     int stride;             /* 1 or 2: out[y,x] is centred on in[y*stride, x*stride]; output (N, ceil(H/stride), ceil(W/stride), Cout) */
     const float* ln_wsum;   /* non-NULL: the layer is LayerNorm(Cin, elementwise_affine=False, eps=ln_eps) followed by this 1x1 layer

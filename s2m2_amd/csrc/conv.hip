@@ -1566,6 +1566,22 @@ static int dispatch_conv(const ConvArgs& a, int tile, hipStream_t st) {
             wide = tile == 40 || force_pw == 40 || (tile == 0 && force_pw != 32 && cost5 < cost4);
         }
         if constexpr (sizeof(T) == 2) {
+            // Cout a multiple of 192 but not of 128 with Cin a multiple of 192 (the M model's C = 192 layers): blocks of 192 couts (six
+            // waves) on 192-channel chunks (12 k16 steps per tap) -- no padded couts, no half-empty chunk; the weight stream is chunked
+            // accordingly by the packers (same rule: s2m2_conv_frag_chunk).  One block per CU (100 KB halo tile): 256 block slots per round
+            if (s2m2_conv_frag_chunk(a.Cout, a.Cin) == 192) {
+                const long long b4 = (long long)a.N * ((a.W + 31) / 32) * ((a.H + 3) / 4) * (a.Cout / 192);
+                const long long b5 = (long long)a.N * ((a.W + 39) / 40) * ((a.H + 3) / 4) * (a.Cout / 192);
+                // same choices as below with 256 slots per round: 64-pixel blocks for layers with an epilogue operand and for small grids,
+                // 4 x 40 patches where they save a partial round
+                const int ph192 = tile == 2 || tile == 4 ? tile : (a.epi != S2M2_EPI_NONE || b4 <= 128) ? 2 : 4;
+                const bool one = a.epi == S2M2_EPI_ADD || a.epi == S2M2_EPI_MUL;
+                bool wide192 = false;
+                if (one && (tile == 40 || tile == 0)) wide192 = tile == 40 || (b4 > 128 && ((b5 + 255) / 256) * 5 < ((b4 + 255) / 256) * 4 + 4);
+                else if (ph192 == 4 && a.epi == S2M2_EPI_NONE) wide192 = tile == 40 || (tile == 0 && ((b5 + 255) / 256) * 5 < ((b4 + 255) / 256) * 4);
+                if (wide192) return launch_conv_frag<T, 192, 192, 4, 40>(a, st);
+                return ph192 == 2 ? launch_conv_frag<T, 192, 192, 2>(a, st) : launch_conv_frag<T, 192, 192, 4>(a, st);
+            }
             if (wide) return launch_conv_frag<T, 128, 128, 4, 40>(a, st);
             return ph == 2 ? launch_conv_frag<T, 128, 128, 2>(a, st) : launch_conv_frag<T, 128, 128, 4>(a, st);
         } else {

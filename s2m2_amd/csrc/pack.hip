@@ -76,7 +76,8 @@ extern "C" long long s2m2_pack_frag_elems(const s2m2_pack_desc* d) {
         case S2M2_PACK_CONV_FRAG: {
             if (d->ntap <= 0 || d->cols % d->ntap) { set_error("pack_frag: cols=%d is not ntap=%d taps of channels", d->cols, d->ntap); return -1; }
             const int cin = d->cols / d->ntap;
-            return tiles * 32 * (long long)d->ntap * ((cin + 127) / 128 * 128);
+            const int ck = s2m2_conv_frag_chunk(d->rows, cin);
+            return tiles * 32 * (long long)d->ntap * ((cin + ck - 1) / ck * ck);
         }
         case S2M2_PACK_FUSION: return 9LL * d->rows * d->rows;
         case S2M2_PACK_HEAD: return 64LL * 8 * 2 * ((d->cols + 31) / 32);
@@ -120,17 +121,17 @@ extern "C" int s2m2_pack_frag(const s2m2_pack_desc* d, void* stream) {
             p.tile_stride = (long long)p.nsteps * 64;
             return run_plan(p, out, st);
         }
-        case S2M2_PACK_CONV_FRAG: {                  // K5 v5 (K order 2): [tile][chunk of 128 channels][tap][k16 step], zero beyond Cin
+        case S2M2_PACK_CONV_FRAG: {                  // K5 v5 (K order 2): [tile][chunk of 128 / 192 channels][tap][k16 step], zero beyond Cin
             S2M2_REQUIRE(d->rows % 32 == 0, "pack_frag: K order 2 needs Cout=%d to be a multiple of 32", d->rows);
-            const int cin = d->cols / d->ntap, nchunk = (cin + 127) / 128;
-            p.nsteps = nchunk * d->ntap * 8;
+            const int cin = d->cols / d->ntap, ck = s2m2_conv_frag_chunk(d->rows, cin), nchunk = (cin + ck - 1) / ck, nks = ck / 16;
+            p.nsteps = nchunk * d->ntap * nks;
             p.colmap.assign((size_t)p.nsteps * 16, -1);
             for (int ch = 0; ch < nchunk; ++ch)
                 for (int tap = 0; tap < d->ntap; ++tap)
-                    for (int ks = 0; ks < 8; ++ks)
+                    for (int ks = 0; ks < nks; ++ks)
                         for (int q = 0; q < 16; ++q) {
-                            const int c = ch * 128 + ks * 16 + q;
-                            if (c < cin) p.colmap[((size_t)(ch * d->ntap + tap) * 8 + ks) * 16 + q] = tap * cin + c;
+                            const int c = ch * ck + ks * 16 + q;
+                            if (c < cin) p.colmap[((size_t)(ch * d->ntap + tap) * nks + ks) * 16 + q] = tap * cin + c;
                         }
             p.tile_stride = (long long)p.nsteps * 64;
             return run_plan(p, out, st);

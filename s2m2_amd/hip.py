@@ -421,7 +421,8 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor], KH: int, KW
         d.src_c[i] = t.shape[3]
         d.src_stride[i] = _nhwc(t)
         cin += t.shape[3]
-    kcols = KH * KW * (-(-cin // 128) * 128) if korder == 2 else KH * KW * cin         # K order 2: K padded to whole 128-channel chunks
+    ck = 192 if (Cout % 128 != 0 and Cout % 192 == 0 and cin % 192 == 0) else 128        # s2m2_conv_frag_chunk
+    kcols = KH * KW * (-(-cin // ck) * ck) if korder == 2 else KH * KW * cin           # K order 2: K padded to whole chunks
     if weight.dtype != dt or not weight.is_contiguous() or tuple(weight.shape) != (Cout, kcols):
         raise ValueError(f"conv2d: packed weight must be {(Cout, kcols)} {dt}, got {tuple(weight.shape)} {weight.dtype}")
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != Cout or not bias.is_contiguous()):

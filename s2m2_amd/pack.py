@@ -69,21 +69,30 @@ def pack_conv(w: torch.Tensor, dtype: torch.dtype, splits: Optional[Sequence[Tup
     return wp.to(dtype).contiguous()
 
 
-FRAG_CH = 128        # channels per chunk of K order 2 (conv_frag_kernel: one halo tile in LDS per chunk)
+FRAG_CH = 128        # channels per chunk of K order 2 (conv_frag_kernel: one halo tile in LDS per chunk) ...
+
+
+def frag_chunk(cout_p: int, cin_p: int) -> int:
+    """... except for the layers of 192-channel models: include/s2m2_hip.h s2m2_conv_frag_chunk (same rule, tests/test_cabi.py compares them)"""
+    return 192 if (cout_p % 128 != 0 and cout_p % 192 == 0 and cin_p % 192 == 0) else FRAG_CH
 
 
 def frag_eligible(cout_p: int, cin_p: int, kh: int, kw: int, dtype: torch.dtype) -> bool:
     """Layers the fragment-stream kernel (K order 2) takes: fp16, stride-1 3x3 / 3x1 / 1x3, Cout % 128 == 0, Cin % 64 == 0 and
     >= 128 (a half-empty last chunk of 128 channels costs 25 % at Cin = 192, 17 % at 320, nothing at 128 / 256 / 384; Cin = 64
-    would waste half of the MFMAs and stays on the v3 tiles)."""
-    return (dtype == torch.float16 and kh * kw > 1 and kh in (1, 3) and kw in (1, 3) and cout_p % 128 == 0 and cin_p % 64 == 0
-            and cin_p >= 128)
+    would waste half of the MFMAs and stays on the v3 tiles) -- or Cout % 192 == 0 with Cin % 192 == 0 (192-cout blocks on 192-channel chunks)."""
+    if not (dtype == torch.float16 and kh * kw > 1 and kh in (1, 3) and kw in (1, 3)):
+        return False
+    if frag_chunk(cout_p, cin_p) == 192:
+        import os
+        return os.environ.get("S2M2_FRAG192", "1") != "0"          # A/B switch: 0 = these layers on the v3 halo tiles (as up to round 5)
+    return cout_p % 128 == 0 and cin_p % 64 == 0 and cin_p >= 128
 
 
 def pack_conv_frag(w: torch.Tensor, dtype: torch.dtype, splits: Optional[Sequence[Tuple[int, int]]] = None) -> torch.Tensor:
     """nn.Conv2d weight (Cout, Cin, KH, KW) -> K order 2 of s2m2_conv2d: the stream of MFMA A-fragments conv_frag_kernel consumes,
-    [Cout/32][chunk][tap][k16 step][lane][8] with lane l holding cout 32t + l % 32, channels 128*chunk + 16*step + 8*(l // 32) + e
-    (zero beyond Cin).  Returned as (Cout, KH*KW*nchunk*128): same row count as K order 0, K padded to whole chunks."""
+    [Cout/32][chunk][tap][k16 step][lane][8] with lane l holding cout 32t + l % 32, channels CK*chunk + 16*step + 8*(l // 32) + e
+    (zero beyond Cin; CK = frag_chunk(Cout, Cin): 128 or 192).  Returned as (Cout, KH*KW*nchunk*CK): same row count as K order 0, K padded to whole chunks."""
     assert dtype == torch.float16
     kh, kw = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
     ntap = kh * kw
@@ -95,14 +104,15 @@ def pack_conv_frag(w: torch.Tensor, dtype: torch.dtype, splits: Optional[Sequenc
     wp = pack_conv(w, torch.float32, splits)                      # (Cout_p, KH*KW*Cin_p), K = (tap, channel)
     cop, cin = wp.shape[0], wp.shape[1] // ntap
     assert cop % 32 == 0, cop
-    nchunk = (cin + FRAG_CH - 1) // FRAG_CH
+    ck = frag_chunk(cop, cin)
+    nchunk = (cin + ck - 1) // ck
     t = wp.reshape(cop, ntap, cin)
-    if nchunk * FRAG_CH > cin:
-        t = torch.cat([t, t.new_zeros(cop, ntap, nchunk * FRAG_CH - cin)], -1)
-    ks = FRAG_CH // 16
+    if nchunk * ck > cin:
+        t = torch.cat([t, t.new_zeros(cop, ntap, nchunk * ck - cin)], -1)
+    ks = ck // 16
     t = t.reshape(cop // 32, 32, ntap, nchunk, ks, 2, 8)          # cout tile, cout, tap, chunk, step, half, e
     t = t.permute(0, 3, 2, 4, 5, 1, 6)                            # cout tile, chunk, tap, step, half, cout, e  (lane = half*32 + cout)
-    return t.reshape(cop, ntap * nchunk * FRAG_CH).to(dtype).contiguous()
+    return t.reshape(cop, ntap * nchunk * ck).to(dtype).contiguous()
 
 
 def chain_frag(wp: torch.Tensor) -> torch.Tensor:

@@ -20,6 +20,7 @@ def lib():
 def _declared():
     txt = open(os.path.join(ROOT, "include", "s2m2_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"^static inline[^\n]*$", "", txt, flags=re.M)       # one-line helpers defined in the header itself (s2m2_conv_frag_chunk): not exports
     return set(re.findall(r"\b(s2m2_[a-z0-9_]+)\s*\(", txt))
 
 
@@ -194,3 +195,23 @@ def test_descriptor_structs_have_the_layout_of_the_header(tmp_path):
         name, size, off = line.split()
         assert name == cname and int(size) == ctypes.sizeof(py), (cname, size, ctypes.sizeof(py))
         assert int(off) == getattr(py, py._fields_[-1][0]).offset, (cname, off)
+
+
+def test_conv_frag_chunk_rule_of_the_header_is_the_rule_of_the_packers(tmp_path):
+    """s2m2_conv_frag_chunk (static inline in include/s2m2_hip.h, compiled by gcc) against pack.frag_chunk on a grid of layer shapes: the
+    kernel dispatcher, the library's packer and the Python packer all chunk the K-order-2 stream by this one rule"""
+    import shutil
+    import subprocess
+    from s2m2_amd import pack
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = [(co, ci) for co in (64, 128, 192, 256, 320, 384, 576, 768) for ci in (64, 128, 192, 256, 320, 384, 576)]
+    body = "".join(f'  printf("%d\\n", s2m2_conv_frag_chunk({co}, {ci}));\n' for co, ci in shapes)
+    src = tmp_path / "chunk.c"
+    src.write_text('#include <stdio.h>\n#include "s2m2_hip.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "chunk"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out == [pack.frag_chunk(co, ci) for co, ci in shapes]
+    assert pack.frag_chunk(192, 192) == 192 and pack.frag_chunk(192, 384) == 192 and pack.frag_chunk(384, 384) == 128

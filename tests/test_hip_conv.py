@@ -113,6 +113,12 @@ FRAG_CASES = [
     (2, 37, 45, [128], 256, 3, 3, 0, 1),                   # residual add without activation (ConvBlock2D's last conv), ragged, 2 cout blocks
     (2, 19, 70, [128, 128], 128, 1, 3, 4, 3),              # GRU pass (1x3): tanh + GRU blend, two epilogue operands (64-pixel blocks only)
     (1, 8, 40, [128, 128, 64, 64], 128, 3, 3, 1, 0),       # four sources, three chunks
+    # the M model's widths: 192-cout blocks (six waves) on 192-channel chunks
+    (1, 17, 23, [192], 192, 3, 3, 1, 0),                   # ragged
+    (2, 37, 45, [192], 192, 3, 3, 0, 1),                   # residual add
+    (1, 33, 19, [192, 192], 192, 3, 1, 3, 2),              # GRU gate: two sources = two chunks, sigmoid * aux
+    (2, 19, 70, [192, 192], 192, 1, 3, 4, 3),              # GRU candidate: two-operand blend (64-pixel blocks only)
+    (1, 64, 76, [96, 96], 384 + 192, 3, 3, 1, 0),          # three cout blocks of 192, a source boundary inside the chunk
 ]
 
 

@@ -65,7 +65,8 @@ def test_fusion_frag_native_equals_torch(hip, monkeypatch, C):
 
 
 @pytest.mark.parametrize("co,ci,kh,kw,splits", [(128, 128, 3, 3, None), (256, 256, 3, 1, [(128, 128), (128, 128)]), (128, 192, 3, 3, None),
-                                                 (384, 256, 3, 3, [(128, 128), (128, 128)]), (128, 320, 1, 3, None), (256, 384, 3, 3, None)])
+                                                 (384, 256, 3, 3, [(128, 128), (128, 128)]), (128, 320, 1, 3, None), (256, 384, 3, 3, None),
+                                                 (192, 192, 3, 3, None), (192, 384, 1, 3, [(192, 192), (192, 192)]), (576, 192, 3, 3, [(96, 96), (96, 96)])])
 def test_conv_frag_native_equals_torch(hip, monkeypatch, co, ci, kh, kw, splits):
     w = (torch.randn(co, ci, kh, kw, device="cuda") / math.sqrt(ci * kh * kw))
     a, b = _both(lambda: pack.pack_conv_frag(w, torch.float16, splits), monkeypatch)

@@ -38,6 +38,24 @@ def test_pack_conv_frag_is_the_documented_fragment_stream():
     assert not pack.frag_eligible(128, 128, 1, 1, torch.float16) and not pack.frag_eligible(128, 128, 3, 3, torch.float32)
 
 
+def test_pack_conv_frag_192_channel_chunks():
+    """the layers of 192-channel models (Cout % 192 == 0, not % 128, Cin % 192 == 0): chunks of 192 channels, 12 k16 steps per tap"""
+    for cout, cin, kh, kw in ((192, 192, 3, 3), (192, 384, 1, 3)):
+        assert pack.frag_chunk(cout, cin) == 192 and pack.frag_eligible(cout, cin, kh, kw, torch.float16)
+        w = torch.randn(cout, cin, kh, kw).half()
+        f = pack.pack_conv_frag(w, torch.float16, [(192, 192)] * (cin // 192))
+        nchunk = cin // 192
+        assert tuple(f.shape) == (cout, kh * kw * cin)
+        s = f.reshape(cout // 32, nchunk, kh * kw, 12, 64, 8)
+        for t, c, tap, st, lane, e in [(0, 0, 0, 0, 0, 0), (5, nchunk - 1, kh * kw - 1, 11, 63, 7), (1, 0, 1, 7, 31, 5), (2, nchunk - 1, 0, 4, 40, 2)]:
+            co, ch = 32 * t + lane % 32, 192 * c + 16 * st + 8 * (lane // 32) + e
+            assert s[t, c, tap, st, lane, e] == w[co, ch, tap // kw, tap % kw], (t, c, tap, st, lane, e)
+        assert torch.equal(f.float().abs().sum(), w.float().abs().sum()) or abs(float(f.float().abs().sum()) - float(w.float().abs().sum())) < 1e-2 * float(w.float().abs().sum())
+    # everything else keeps 128-channel chunks (384 and 256 are multiples of 128; 192 <- 128 + 64 is not a multiple of 192 channels)
+    assert pack.frag_chunk(384, 384) == 128 and pack.frag_chunk(256, 192) == 128 and pack.frag_chunk(128, 192) == 128
+    assert pack.frag_chunk(192, 320) == 128 and not pack.frag_eligible(192, 320, 3, 3, torch.float16)
+
+
 def test_transposed_conv_packings():
     w = torch.randn(6, 10, 3, 3)                                                 # ConvTranspose2d weight (Cin, Cout, KH, KW), stride 1
     c = pack.convT_s1_as_conv(w)
