@@ -35,8 +35,10 @@ enum { S2M2_F32 = 0, S2M2_F16 = 1 };
  * s2m2_conv_desc / s2m2_chain_desc grew epi_cout0, ln_out*, fan_*, weight_frag, pool_h / pool_w) -- a caller built against 100 must be
  * rebuilt; 400 = round 4 (s2m2_pw_direct, s2m2_conv_narrow, s2m2_ln_corr_pitched added; the round-3 experiment entry
  * points s2m2_corr_tiled / s2m2_corr_hybrid / s2m2_debug_store_pattern and the ln_out_tile* fields of s2m2_chain_desc removed;
- * head_* appended to s2m2_narrow_desc without a bump -- the reason for the exact comparison since 500); 500 = round 5. */
-#define S2M2_ABI_VERSION 500
+ * head_* appended to s2m2_narrow_desc without a bump -- the reason for the exact comparison since 500); 500 = round 5; 600 = round 6
+ * (s2m2_row_attn added; the five ABI-400 entry points of K1 -- s2m2_ln_corr, _timed, _banded, _pitched, s2m2_corr -- removed: every form of
+ * K1 is s2m2_cost_volume). */
+#define S2M2_ABI_VERSION 600
 int s2m2_version(void);
 const char* s2m2_last_error(void);
 /* test aid (not part of the path): fills the LDS of every CU with quiet-NaN patterns, so that a kernel launched next that reads an LDS word it
@@ -51,7 +53,7 @@ const char* s2m2_ln_corr_kernel_name(int C, int feat_dtype, int cv_dtype);
 
 /*
  * [A4] K1: (LayerNorm +) all-pairs epipolar correlation = the cost volume  (DispInit.forward, submodules.py:216-217; LayerNorm :165)
- *   ONE descriptor for every form of the kernel (ABI 500; the five entry points of ABI 400 below are shims over it, kept for one version):
+ *   ONE descriptor for every form of the kernel (ABI 500; the five positional entry points of ABI 400 were removed with ABI 600):
  *   tokens  (2B, h, w, C) NHWC, left images = batch entries [0,B), right = [B,2B)            dtype token_dtype
  *   ln_weight, ln_bias  (C) fp32: LayerNorm affine (eps 1e-5, biased variance), applied INSIDE the kernel.  Both NULL: the tokens are
  *           normalised already (DispInit's layer_norm folded into the launch that produced them: the ln_out rows of s2m2_mlp_chain) and
@@ -83,22 +85,6 @@ typedef struct s2m2_corr_desc {
 } s2m2_corr_desc;
 int s2m2_cost_volume(const s2m2_corr_desc* desc, void* stream);
 
-/* ABI 400 entry points of K1 (shims over s2m2_cost_volume; to be removed with the next ABI version):
- *   s2m2_ln_corr          LayerNorm inside, dense rows, full volume            s2m2_ln_corr_timed   + events
- *   s2m2_ln_corr_banded   + band >= 0 + events                                  s2m2_ln_corr_pitched every option
- *   s2m2_corr             tokens normalised already, every option */
-int s2m2_ln_corr(const void* feat, const float* ln_w, const float* ln_b, void* cv,
-                 int B, int h, int w, int C, int feat_dtype, int cv_dtype, void* stream);
-int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, void* cv,
-                       int B, int h, int w, int C, int feat_dtype, int cv_dtype, void* stream,
-                       void* start_event, void* stop_event);
-int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, void* cv,
-                        int B, int h, int w, int C, int feat_dtype, int cv_dtype, int band, void* stream,
-                        void* start_event, void* stop_event);
-int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
-              void* stream, void* start_event, void* stop_event);
-int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
-                         int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event);
 /*
  * Weight packing into the MFMA-fragment orders of the direct-form kernels (ABI 500; up to ABI 400 these permutations lived in the Python
  * binding, s2m2_amd/pack.py, and a C caller had to re-derive them).  Input: the PLAIN packing of a layer -- (rows = Cout padded to 8, cols = K)
@@ -334,6 +320,53 @@ int s2m2_mlp_chain_frag_supported(int C, int dtype);
  * ONE pass over the rows): 1 where the library has that form (the direct form, weight_frag = 1: fp16, C = 128 / 256, nfan 1..4), else 0 */
 int s2m2_mlp_fan_supported(int C, int nfan, int dtype);
 int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
+
+/*
+ * K13 -- one whole 1-D (epipolar) attention step on token rows in ONE launch (ABI 600): pre-LayerNorm -> Q | K | V projections -> softmax
+ *   attention along the image row -> output projection + residual -> pre-LayerNorm -> FFN (Linear - GELU - Linear) + residual.  Replaces, per
+ *   step, the launch triple s2m2_mlp_chain(fan-out Q|K|V) / s2m2_attention / s2m2_mlp_chain of the reference's
+ *   CrossAttnBlock1D + FFN and SelfAttnBlock1D + FFN (attentions.py:131-161, :99-128, :229-250; BasicAttnBlock.forward :347-355):
+ *     z' = z + proj( softmax( (LN(z) Wq^T)(LN(s) Wk^T)^T / sqrt(d) ) (LN(s) Wv^T + bv) ),   out = z' + W2 GELU(W0 LN(z') + b0) + b2
+ *   with z = a token row (image n, line y) and s = the same line of image (n + nimg/2) % nimg (cross = 1: left <-> right, shared weights, both
+ *   directions in the launch) or z itself (cross = 0).  One block per token row; Q, K, V, the attention output and the FFN hidden tensor never
+ *   leave the CU (K / V of the source row in LDS, everything else in registers).  Rounding points = those of the separate launches.
+ *     x, out      (nimg, h, w, 128) fp16, channels contiguous; x_stride / out_stride = elements between tokens (multiples of 4); out != x
+ *     weights     the six layers q, k, v, proj, ffn.0, ffn.2 back to back, 128 x 128 fp16 each (row = output channel) in the "row_attn
+ *                 packing", 16-byte aligned, 32 KB per layer:
+ *                 (1) columns: per 16 input channels the four quads of 4 channels in the order (0, 2, 1, 3) -- column 16g + 8a + 4b + e of the
+ *                 plain packing (s2m2_conv2d's 1x1 weight) holds input channel 16g + 8b + 4a + e (a, b in {0, 1}, e < 4; an involution): the
+ *                 k-slots of a 16-byte MFMA fragment then follow the accumulator layout of the layer before it;
+ *                 (2) unit-major: the 16-byte unit u (columns 8u .. 8u+7 of (1)) of row r at element (u * 128 + r) * 8 of the layer -- the
+ *                 kernel copies a layer into LDS with a linear LDS-DMA and reads conflict-free fragments at immediate offsets
+ *     vectors     twelve fp32 vectors of 128 back to back, 16-byte aligned (absent biases as zeros): 0 bias q, 1 row sums of q, 2 bias k,
+ *                 3 row sums of k, 4 bias proj, 5 bias ffn.0, 6 row sums of ffn.0, 7 bias ffn.2, 8 ln_out gamma, 9 ln_out beta, 10 bias v,
+ *                 11 row sums of v.  Row sums (of the plain fp16 weight, in fp32) fold the LayerNorm without affine (eps ln_eps) in front
+ *                 of q, k, v, ffn.0 as in s2m2_conv2d (ln_wsum); 8 / 9 are read only with ln_out
+ *     ln_out      optional second output: LayerNorm(out) * gamma + beta (eps ln_out_eps) -- DispInit's layer_norm (submodules.py:165,216)
+ *                 when this step writes feature_tr_4x, as s2m2_chain_desc.ln_out
+ *     xcd_hint    1 (h % 8 == 0): line y of every image runs on XCD y / (h / 8) -- where s2m2_cost_volume reads the rows (see
+ *                 s2m2_chain_desc.xcd_group_rows) and where the partner row's block runs
+ *   fp16, C = 128, heads 1 or 2 (head dim 128 / 64), 8 <= w <= 320: ask s2m2_row_attn_supported.
+ */
+typedef struct s2m2_rowattn_desc {
+    const void* x;
+    long long x_stride;
+    void* out;
+    long long out_stride;
+    int nimg, h, w, C;
+    int heads;
+    int cross;
+    const void* weights;
+    const float* vectors;
+    float ln_eps;
+    void* ln_out;
+    long long ln_out_stride;
+    float ln_out_eps;
+    int xcd_hint;
+    int dtype;
+} s2m2_rowattn_desc;
+int s2m2_row_attn_supported(int C, int heads, int w, int dtype);
+int s2m2_row_attn(const s2m2_rowattn_desc* desc, void* stream);
 
 /*
  * K11 -- a 1x1 layer with any channel counts in the direct style (fp16; round 4): Conv2d(kernel 1) / Linear / ConvTranspose2d(2, stride 2) on

@@ -48,7 +48,8 @@ def effective_defines(extra=()) -> list:
     __graft_entry__.build(): once taken, every later incremental compile of a single file must use it too -- objects with and without
     -DS2M2_UNTRACKED_LOADS=0 must never be linked together)."""
     keep = []
-    if os.path.exists(_defines_file()):
+    explicit = any(d.startswith("-DS2M2_UNTRACKED_LOADS=") for d in list(DEFINES) + list(extra))
+    if os.path.exists(_defines_file()) and not explicit:           # an explicit value (environment / caller) overrides the persisted one
         keep = [d for d in open(_defines_file()).read().split() if d.startswith("-DS2M2_UNTRACKED_LOADS=")]
     out = list(DEFINES)
     for d in list(extra) + keep:
@@ -91,13 +92,18 @@ def build(force: bool = False, verbose: bool = True, extra_defines=()) -> str:
     before = open(_defines_file()).read().split() if os.path.exists(_defines_file()) else None
     if before is not None and before != defines:
         force = True                                               # objects of another configuration: never mix
-    if before is None and extra_defines:
-        force = True
-    open(_defines_file(), "w").write(" ".join(defines) + "\n")
-    srcs = sources()
+    if before is None and (extra_defines or any(f.endswith(".o") for f in os.listdir(OBJ))):
+        force = True                                               # objects of an unknown configuration (an interrupted forced rebuild)
+    if force and os.path.exists(_defines_file()):
+        os.remove(_defines_file())                                 # written again only after EVERY object compiled (below): a failed
+    srcs = sources()                                               # forced rebuild leaves no stamp, so the next build forces again
     hdr = _deps_mtime()
     with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, hdr, tuple(defines)), srcs))
+    tmp = _defines_file() + ".tmp"
+    with open(tmp, "w") as f:
+        f.write(" ".join(defines) + "\n")
+    os.replace(tmp, _defines_file())                               # atomically, after all objects exist
     newest = max(os.path.getmtime(o) for o in objs)
     if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]

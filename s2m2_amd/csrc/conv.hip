@@ -1731,9 +1731,10 @@ static int conv2d_impl(const s2m2_conv_desc* d, void* stream) {
     a.ksplit = d->ksplit; a.bias2 = d->bias2;
     a.epi_cout0 = d->epi_cout0;
     if (d->epi_cout0)
-        S2M2_REQUIRE(d->korder == 2 && d->epi_cout0 > 0 && d->epi_cout0 % 128 == 0 && d->epi_cout0 < d->Cout &&
+        S2M2_REQUIRE(d->korder == 2 && d->epi_cout0 > 0 && d->epi_cout0 % s2m2_conv_frag_chunk(d->Cout, a.Cin) == 0 && d->epi_cout0 < d->Cout &&
                      (d->epi == S2M2_EPI_ADD || d->epi == S2M2_EPI_MUL),
-                     "conv2d: epi_cout0=%d needs K order 2, a one-operand epilogue (ADD / MUL) and a multiple of 128 below Cout", d->epi_cout0);
+                     "conv2d: epi_cout0=%d needs K order 2, a one-operand epilogue (ADD / MUL) and a multiple of the layer's cout block "
+                     "(s2m2_conv_frag_chunk: 128 or 192) below Cout", d->epi_cout0);
     if (d->epi == S2M2_EPI_DUALMIX)
         S2M2_REQUIRE(d->KH == 1 && d->KW == 1 && d->stride == 1 && !d->shuffle2 && !d->korder && !d->ln_wsum && d->aux1 &&
                      d->ksplit > 0 && d->ksplit < a.Cin && d->ksplit % 64 == 0 && d->act == S2M2_ACT_SIGMOID && d->out_scale == 1.0f,

@@ -549,46 +549,6 @@ extern "C" int s2m2_cost_volume(const s2m2_corr_desc* d, void* stream) {
 }
 
 
-// ---- the entry points of ABI versions up to 400: shims over s2m2_cost_volume, kept for one ABI version -------------------------------
-static int k1_shim(const void* tokens, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
-                   int token_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
-    s2m2_corr_desc d = {};
-    d.tokens = tokens; d.ln_weight = ln_w; d.ln_bias = ln_b; d.cv = cv;
-    d.B = B; d.h = h; d.w = w; d.C = C; d.cv_pitch = cv_pitch; d.band = band < 0 ? -1 : band;
-    d.token_dtype = token_dtype; d.cv_dtype = cv_dtype; d.start_event = start_event; d.stop_event = stop_event;
-    return s2m2_cost_volume(&d, stream);
-}
-
-extern "C" int s2m2_ln_corr(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
-                            int feat_dtype, int cv_dtype, void* stream) {
-    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
-    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, 0, feat_dtype, cv_dtype, -1, stream, nullptr, nullptr);
-}
-
-extern "C" int s2m2_ln_corr_timed(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
-                                  int feat_dtype, int cv_dtype, void* stream, void* start_event, void* stop_event) {
-    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
-    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, 0, feat_dtype, cv_dtype, -1, stream, start_event, stop_event);
-}
-
-extern "C" int s2m2_ln_corr_banded(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C,
-                                   int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
-    S2M2_REQUIRE(band >= 0, "ln_corr_banded: band=%d must be >= 0 (use s2m2_ln_corr for the full volume)", band);
-    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
-    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, 0, feat_dtype, cv_dtype, band, stream, start_event, stop_event);
-}
-
-extern "C" int s2m2_ln_corr_pitched(const void* feat, const float* ln_w, const float* ln_b, void* cv, int B, int h, int w, int C, int cv_pitch,
-                                    int feat_dtype, int cv_dtype, int band, void* stream, void* start_event, void* stop_event) {
-    S2M2_REQUIRE(ln_w && ln_b, "ln_corr: null pointer");
-    return k1_shim(feat, ln_w, ln_b, cv, B, h, w, C, cv_pitch, feat_dtype, cv_dtype, band, stream, start_event, stop_event);
-}
-
-extern "C" int s2m2_corr(const void* tokens, void* cv, int B, int h, int w, int C, int cv_pitch, int token_dtype, int cv_dtype, int band,
-                         void* stream, void* start_event, void* stop_event) {
-    return k1_shim(tokens, nullptr, nullptr, cv, B, h, w, C, cv_pitch, token_dtype, cv_dtype, band, stream, start_event, stop_event);
-}
-
 extern "C" int s2m2_event_create(void** event) {
     S2M2_REQUIRE(event, "event_create: null pointer");
     hipEvent_t e;

@@ -162,10 +162,27 @@ static int convex_upsample_impl(const float* const* x, float* const* out, const 
     else return set_error("convex_upsample: unsupported dtype %d", dtype);
     return check_launch("convex_upsample");
 }
+// Plans record arguments BY VALUE: the three host arrays of this entry point (device pointers of the maps, scales) are copied into a
+// descriptor whose words the plan scans and patches; the trampoline rebuilds the arrays from it.
+struct UpsampleBlob {
+    const float* x[3]; float* out[3]; float scale[3];
+    int nmaps; const void* logits; int logit_stride, B, hs, ws, factor, logit_up2; void* chan_out; long long chan_stride; int dtype;
+};
+static int convex_upsample_blob(const UpsampleBlob* b, void* stream) {
+    return convex_upsample_impl(b->x, b->out, b->scale, b->nmaps, b->logits, b->logit_stride, b->B, b->hs, b->ws, b->factor, b->logit_up2,
+                                b->chan_out, b->chan_stride, b->dtype, stream);
+}
 extern "C" int s2m2_convex_upsample(const float* const* x, float* const* out, const float* scale, int nmaps, const void* logits,
                                     int logit_stride, int B, int hs, int ws, int factor, int logit_up2, void* chan_out,
                                     long long chan_stride, int dtype, void* stream) {
-    return s2m2::plan_dispatch("s2m2_convex_upsample", &convex_upsample_impl, stream, x, out, scale, nmaps, logits, logit_stride, B, hs, ws, factor, logit_up2, chan_out, chan_stride, dtype);
+    if (!x || !out || !scale || nmaps < 1 || nmaps > 3)            // (the impl reports these; nothing to copy by value)
+        return convex_upsample_impl(x, out, scale, nmaps, logits, logit_stride, B, hs, ws, factor, logit_up2, chan_out, chan_stride, dtype, stream);
+    UpsampleBlob b;
+    __builtin_memset(&b, 0, sizeof(b));
+    for (int m = 0; m < nmaps; ++m) { b.x[m] = x[m]; b.out[m] = out[m]; b.scale[m] = scale[m]; }
+    b.nmaps = nmaps; b.logits = logits; b.logit_stride = logit_stride; b.B = B; b.hs = hs; b.ws = ws; b.factor = factor;
+    b.logit_up2 = logit_up2; b.chan_out = chan_out; b.chan_stride = chan_stride; b.dtype = dtype;
+    return s2m2::plan_dispatch_desc("s2m2_convex_upsample", &convex_upsample_blob, &b, stream);
 }
 
 

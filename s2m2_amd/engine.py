@@ -92,7 +92,8 @@ class Engine:
         self._packed: Dict[object, Spec] = {}
         self._pe_cache: Dict[Tuple[int, int], Tuple[Tensor, Tensor]] = {}
         self._bufs: Dict[object, Tensor] = {}
-        self._ns = None                              # scratch namespace, see zeros()
+        self._plans: Dict[object, object] = {}       # recorded refinement plans of EAGER calls (never evicted by zeros(): a plan owns the
+        self._ns = None                              # tensors it returns); scratch namespace, see zeros()
         self._wsum: Dict[int, Tensor] = {}
         self._chain_ok: Dict[object, bool] = {}
         self._fusion_ok: Dict[object, bool] = {}
@@ -112,6 +113,9 @@ class Engine:
         self.use_k12_head = self.use_k12 and os.environ.get("S2M2_K12_HEAD", "1") != "0"
         # S2M2_REFINE_NATIVE=0: every refinement iteration enqueued from Python (A/B; the default replays a recorded plan: s2m2_refine_step)
         self.native_refine = os.environ.get("S2M2_REFINE_NATIVE", "1") != "0"
+        # S2M2_ROWFUSE=0: every 1-D attention step as the launch triple Q|K|V fan-out / K4 / K9 chain (as up to round 5) instead of ONE K13
+        # launch per step (hip.row_attn: fp16, C = 128 -- the S model's 1/4 and 1/8 levels; profiles/r06/ab_rowfuse.txt)
+        self.use_rowfuse = os.environ.get("S2M2_ROWFUSE", "1") != "0"
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -464,12 +468,43 @@ class Engine:
         """prefix of the attention module a block applies first (cross attention where the block has one)"""
         return p + (".cross_attn.attn" if (p + ".cross_attn.attn.q.weight") in self.p else ".self_attn.attn")
 
+    def row_ok(self, z: Tensor, nh: int) -> bool:
+        """K13 takes the 1-D attention steps on this tensor (asked once per shape)"""
+        key = ("row", z.shape[-1], nh, z.shape[2])
+        ok = self._chain_ok.get(key)
+        if ok is None:
+            ok = self._chain_ok[key] = self.use_rowfuse and z.dim() == 4 and hip.row_attn_supported(z.shape[-1], nh, z.shape[2], self.dtype)
+        return ok
+
+    def row_step(self, pa: str, pf: str, z: Tensor, nh: int, cross: bool, ln_out=None) -> Tensor:
+        """One 1-D attention step -- pre-LN, Q | K | V, attention along the row (against the other view's row when ``cross``), proj + residual,
+        pre-LN, FFN + residual (attentions.py:131-161 / :99-128 with :229-250) -- as ONE K13 launch.  The step's six layers in the row_attn
+        packing and its twelve per-channel vectors are packed once per step (pack.rowattn_pack / rowattn_vectors)."""
+        key = ("rowstep", pa, pf, ln_out is not None)
+        ent = self._packed.get(key)
+        if ent is None:
+            c = z.shape[-1]
+            qs, proj, f0, f2 = self.qkv_spec(pa + ".attn"), self.std(pa + ".attn.proj"), self.std(pf + ".ffn.0"), self.std(pf + ".ffn.2")
+            ws = self.wsum(qs)
+            cut = lambda t: (None, None, None) if t is None else (t[:c], t[c:2 * c], t[2 * c:])      # noqa: E731
+            wts = pack.rowattn_pack(torch.cat([qs[0], proj[0], f0[0], f2[0]], 0))
+            vec = pack.rowattn_vectors(cut(ws) + (self.wsum(f0),), cut(qs[1]) + (proj[1], f0[1], f2[1]), ln_out[:2] if ln_out is not None else None)
+            ent = self._packed[key] = (wts, vec)
+        if ln_out is not None:
+            out, self._tokens_normed = hip.row_attn(z, nh, cross, ent[0], ent[1], ln_out_eps=ln_out[2])
+            return out
+        return hip.row_attn(z, nh, cross, ent[0], ent[1])
+
     def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False, ln_out=None, qkv_in: Optional[Tensor] = None,
                    next_block: Optional[str] = None):
         """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321).  ln_out: see attn_ffn (last launch of the block).
         qkv_in: the Q | K | V projection of ``z`` for the block's first attention, if the launch that produced ``z`` computed it;
         next_block: prefix of the attention block applied to the result next (its first projection is computed here).
         -> (result, that projection or None)."""
+        if not two_d and not use_pe and qkv_in is None and next_block is None and self.row_ok(z, nh):
+            if (p + ".cross_attn.attn.q.weight") in self.p:
+                z = self.row_step(p + ".cross_attn", p + ".ffn_c", z, nh, True)
+            return self.row_step(p + ".self_attn", p + ".ffn", z, nh, False, ln_out=ln_out), None
         if (p + ".cross_attn.attn.q.weight") in self.p:
             o = self.attn_core(p + ".cross_attn", z, nh, two_d, True, False, qkv=qkv_in)
             z, qkv_in = self.attn_ffn(p + ".cross_attn", p + ".ffn_c", o, z, next_attn=p + ".self_attn.attn")
@@ -581,11 +616,23 @@ class Engine:
         holds the plan's launches; bit-identical to the Python-enqueued iteration (tests/test_hip_e2e.py)."""
         ns = self._ns if self._ns is not None else torch.cuda.current_stream(self.device).cuda_stream   # eager: one plan (and its intermediates) per stream
         key = ("refine_plan", it, tuple(hidden.shape), tuple(cv.shape), cv.stride(2), hidden.dtype, small is None, want_small, ns)
-        ent = self._bufs.get(key)
+        # a GraphRunner's plans live (and die) with its scratch dictionary; eager plans in their own dictionary, which zeros() never evicts
+        # (an evicted plan's result tensors could still be the live hidden / disp of the running forward).  NOTE (aliasing, as with a
+        # hipGraph): the iteration's outputs are the tensors of the recorded run -- the next forward on the same stream overwrites them
+        # in place; S2M2.forward hands out clones / freshly upsampled maps, callers of Engine.finish must not keep these across forwards
+        store = self._bufs if self._ns is not None else self._plans
+        ent = store.get(key)
         if ent is None:                                            # first call: the plain Python path (one-time set-up happens here)
-            self._bufs[key] = "warm"
+            if store is self._plans and len(store) >= 32:
+                store.pop(next(iter(store)))                       # callers cycling through streams: oldest plan out (its tensors stay
+            store[key] = "warm"                                    # alive as long as somebody holds them)
             return self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, None, it, small=small, want_small=want_small)
         ext = [hidden, ctx, disp, conf, occ, cv, small]
+        # the plan patches every recorded pointer that falls inside an external's extent [data_ptr, data_ptr + numel * itemsize): only true
+        # for contiguous tensors (cv: a row-padded view whose extent comes from its strides, _PlanRecord)
+        for t in ext:
+            if t is not None and t is not cv and not t.is_contiguous():
+                return self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, None, it, small=small, want_small=want_small)
         if ent == "warm":
             plan, pool, scratch = hip.Plan(), torch.cuda.MemPool(), {}
             outer = (self._bufs, self._ns)
@@ -596,7 +643,7 @@ class Engine:
                         res = self.local_refiner("refiner", hidden, ctx, disp, conf, occ, cv, None, it, small=small, want_small=want_small)
             finally:
                 self._bufs, self._ns = outer
-            self._bufs[key] = (plan, res, pool, scratch)
+            store[key] = (plan, res, pool, scratch)
             return res
         plan, res, _, _ = ent
         plan.refine_step(*ext)

@@ -45,6 +45,13 @@ class ChainDesc(ctypes.Structure):
                 ("nfan", _i), ("xcd_group_rows", _ll), ("weight_frag", _i), ("pool_h", _i), ("pool_w", _i)]
 
 
+class RowAttnDesc(ctypes.Structure):
+    """mirror of s2m2_rowattn_desc (include/s2m2_hip.h): K13, one 1-D attention step per launch"""
+    _fields_ = [("x", _vp), ("x_stride", _ll), ("out", _vp), ("out_stride", _ll), ("nimg", _i), ("h", _i), ("w", _i), ("C", _i), ("heads", _i),
+                ("cross", _i), ("weights", _vp), ("vectors", _vp), ("ln_eps", ctypes.c_float),
+                ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_out_eps", ctypes.c_float), ("xcd_hint", _i), ("dtype", _i)]
+
+
 class PwDesc(ctypes.Structure):
     """mirror of s2m2_pw_desc (include/s2m2_hip.h)"""
     _fields_ = [("src", _vp * 4), ("src_c", _i * 4), ("src_stride", _ll * 4), ("nsrc", _i), ("rows", _ll), ("weight_frag", _vp), ("bias", _vp),
@@ -74,7 +81,7 @@ PACK_ROWS, PACK_NARROW, PACK_CONV_FRAG, PACK_FUSION, PACK_HEAD = range(5)
 
 
 # name -> (restype, argtypes); must list every symbol declared in include/s2m2_hip.h
-ABI_VERSION = 500                     # include/s2m2_hip.h: S2M2_ABI_VERSION (checked in load())
+ABI_VERSION = 600                     # include/s2m2_hip.h: S2M2_ABI_VERSION (checked in load())
 
 SIGNATURES = {
     "s2m2_version": (_i, []),
@@ -91,19 +98,14 @@ SIGNATURES = {
     "s2m2_refine_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "s2m2_pack_frag_elems": (_ll, [ctypes.POINTER(PackDesc)]),
     "s2m2_pack_frag": (_i, [ctypes.POINTER(PackDesc), _vp]),
-    "s2m2_ln_corr": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "s2m2_ln_corr_timed": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "s2m2_ln_corr_banded": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_event_create": (_i, [ctypes.POINTER(_vp)]),
     "s2m2_event_destroy": (_i, [_vp]),
     "s2m2_event_elapsed_us": (_i, [_vp, _vp, ctypes.POINTER(ctypes.c_float)]),
     "s2m2_sinkhorn_workspace_bytes": (ctypes.c_size_t, [_i, _i, _i, _i]),
-    "s2m2_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_pw_direct_supported": (_i, [_i, _i, _i]),
     "s2m2_pw_direct": (_i, [ctypes.POINTER(PwDesc), _vp]),
     "s2m2_conv_narrow_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "s2m2_conv_narrow": (_i, [ctypes.POINTER(NarrowDesc), _vp]),
-    "s2m2_ln_corr_pitched": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "s2m2_sinkhorn_regress": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "s2m2_cv_lookup": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _ll, _ll, _ll, _i, _vp]),
     "s2m2_conv2d": (_i, [ctypes.POINTER(ConvDesc), _vp]),
@@ -111,6 +113,8 @@ SIGNATURES = {
     "s2m2_mlp_chain_frag_supported": (_i, [_i, _i]),
     "s2m2_mlp_fan_supported": (_i, [_i, _i, _i]),
     "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
+    "s2m2_row_attn_supported": (_i, [_i, _i, _i, _i]),
+    "s2m2_row_attn": (_i, [ctypes.POINTER(RowAttnDesc), _vp]),
     "s2m2_feature_fusion_supported": (_i, [_i, _i]),
     "s2m2_feature_fusion": (_i, [_vp, _vp, _vp, _ll, _ll, _ll, _ll, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "s2m2_feature_fusion_frag_supported": (_i, [_i, _i]),
@@ -265,7 +269,7 @@ class Plan:
 
 
 class KernelTimer:
-    """A start / stop HIP event pair attached to ONE kernel dispatch (s2m2_ln_corr_timed): elapsed_us() is the kernel's own execution
+    """A start / stop HIP event pair attached to ONE kernel dispatch (s2m2_corr_desc.start_event / stop_event): elapsed_us() is the kernel's own execution
     time, what a rocprofv3 kernel trace reports, without the dispatch gaps that events recorded around a launch include."""
 
     def __init__(self):
@@ -608,6 +612,44 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
     _meter("mlp_chain", 2.0 * rows * C * C * (len(stages) + nfan))
     res_t = (out,) + ((normed,) if normed is not None else ()) + ((fan_out,) if fan_out is not None else ())
     return res_t[0] if len(res_t) == 1 else res_t
+
+
+def row_attn_supported(C: int, heads: int, w: int, dtype: torch.dtype) -> bool:
+    """K13 (row_attn) exists for rows of w tokens x C channels with this many heads (fp16, C = 128, 1 or 2 heads, w <= 320)"""
+    return bool(load().s2m2_row_attn_supported(C, heads, w, _DT[dtype]))
+
+
+def row_attn(x: torch.Tensor, heads: int, cross: bool, weights: torch.Tensor, vectors: torch.Tensor, ln_eps: float = 1e-5,
+             ln_out_eps: Optional[float] = None, xcd_hint: bool = True):
+    """K13: one 1-D attention step of BasicAttnBlock (attentions.py:347-355) on the token rows of x (nimg, h, w, 128) in one launch:
+    z' = z + proj(attention(LN(z), LN(s)));  out = z' + ffn(LN(z'))  with s = the same line of image (n + nimg/2) % nimg (cross) or z itself.
+    weights: (6 * 128, 128) fp16 -- q, k, v, proj, ffn.0, ffn.2 in the row_attn packing (pack.rowattn_pack); vectors: (12, 128) fp32 --
+    bias q, row sums q, bias k, row sums k, bias proj, bias ffn.0, row sums ffn.0, bias ffn.2, ln_out gamma, ln_out beta, bias v, row sums v
+    (pack.rowattn_vectors).  ln_out_eps: also return LayerNorm(out) * gamma + beta with that eps -> (out, normalised)."""
+    if x.dim() != 4 or x.dtype != torch.float16 or not x.is_cuda or x.stride(3) != 1:
+        raise ValueError("row_attn: x must be an (nimg, h, w, C) fp16 device tensor with contiguous channels")
+    nimg, h, w, C = x.shape
+    xs = x.stride(2)
+    if x.stride(1) != w * xs or (nimg > 1 and x.stride(0) != h * w * xs):
+        raise ValueError("row_attn: the tokens of x must be evenly strided")
+    if weights.dtype != x.dtype or tuple(weights.shape) != (6 * C, C) or not weights.is_contiguous() or not weights.is_cuda:
+        raise ValueError(f"row_attn: weights must be a contiguous ({6 * C}, {C}) {x.dtype} device tensor (pack.rowattn_pack)")
+    if vectors.dtype != torch.float32 or tuple(vectors.shape) != (12, C) or not vectors.is_contiguous() or not vectors.is_cuda:
+        raise ValueError(f"row_attn: vectors must be a contiguous (12, {C}) fp32 device tensor (pack.rowattn_vectors)")
+    d = RowAttnDesc()
+    out = torch.empty((nimg, h, w, C), device=x.device, dtype=x.dtype)
+    d.x, d.x_stride, d.out, d.out_stride = x.data_ptr(), xs, out.data_ptr(), C
+    d.nimg, d.h, d.w, d.C, d.heads, d.cross, d.ln_eps, d.dtype = nimg, h, w, C, heads, int(bool(cross)), ln_eps, _DT[x.dtype]
+    d.xcd_hint = int(bool(xcd_hint))
+    d.weights, d.vectors = weights.data_ptr(), vectors.data_ptr()
+    normed = None
+    if ln_out_eps is not None:
+        normed = torch.empty((nimg, h, w, C), device=x.device, dtype=x.dtype)
+        d.ln_out, d.ln_out_stride, d.ln_out_eps = normed.data_ptr(), C, float(ln_out_eps)
+    _check(load().s2m2_row_attn(ctypes.byref(d), _stream()), "s2m2_row_attn")
+    rows = nimg * h * w
+    _meter("row_attn", 2.0 * rows * C * C * 6 + 4.0 * nimg * h * w * w * C)
+    return out if normed is None else (out, normed)
 
 
 def pw_direct_supported(K: int, Cout: int, dtype: torch.dtype) -> bool:

@@ -230,3 +230,38 @@ def pack_bias_shuffle(b: Optional[torch.Tensor], cout: int) -> Optional[torch.Te
     out = b.new_zeros(4, cp, dtype=torch.float32)
     out[:, :cout] = b.float()[None]
     return out.reshape(-1).contiguous()
+
+
+def rowattn_cols(w: torch.Tensor) -> torch.Tensor:
+    """The column order of K13's operands: per 16 input channels the four quads of 4 channels in the order (0, 2, 1, 3) -- k-slot 8a + 4b + e
+    of a 16-channel group holds channel 8b + 4a + e, which makes the fp16 accumulator tile of one layer the B operand of the next
+    (csrc/rowattn.hip).  An involution: applying it twice returns the input."""
+    r, k = w.shape
+    assert k % 16 == 0, "row_attn packing: K must be a multiple of 16"
+    return w.reshape(r, k // 16, 2, 2, 4).transpose(2, 3).reshape(r, k).contiguous()
+
+
+def rowattn_pack(w: torch.Tensor) -> torch.Tensor:
+    """Plain packed (n * 128, 128) 1x1 weight(s) -> the "row_attn packing" of s2m2_row_attn (include/s2m2_hip.h), per block of 128 rows:
+    columns in K13's order (rowattn_cols), then UNIT-MAJOR -- the 16-byte unit u (columns 8u .. 8u+7) of row r at element (u * 128 + r) * 8 --
+    so that the kernel's LDS-DMA is a linear copy and its fragment reads are conflict-free.  Same shape, contiguous."""
+    r, k = w.shape
+    assert k == 128 and r % 128 == 0, "row_attn packing: (n * 128, 128) layers"
+    return rowattn_cols(w).reshape(r // 128, 128, 16, 8).transpose(1, 2).contiguous().reshape(r, k)
+
+
+def rowattn_unpack(wp: torch.Tensor) -> torch.Tensor:
+    """inverse of rowattn_pack (tests, the CPU stand-in)"""
+    r, k = wp.shape
+    return rowattn_cols(wp.reshape(r // 128, 16, 128, 8).transpose(1, 2).contiguous().reshape(r, k))
+
+
+def rowattn_vectors(wsums, biases, ln_affine=None) -> torch.Tensor:
+    """The (12, 128) fp32 vector block of s2m2_row_attn: wsums = row sums of (q, k, v, ffn.0), biases = (q, k, v, proj, ffn.0, ffn.2) or None
+    each, ln_affine = (gamma, beta) of the optional LayerNorm output or None."""
+    dev = wsums[0].device
+    z = torch.zeros(128, device=dev)
+    f = lambda t: z if t is None else t.float().reshape(128).to(dev)      # noqa: E731
+    bq, bk, bv, bp, b0, b2 = (f(b) for b in biases)
+    g, b = (f(ln_affine[0]), f(ln_affine[1])) if ln_affine is not None else (z + 1.0, z)
+    return torch.stack([bq, f(wsums[0]), bk, f(wsums[1]), bp, b0, f(wsums[3]), b2, g, b, bv, f(wsums[2])]).contiguous()

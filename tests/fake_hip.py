@@ -11,6 +11,34 @@ from oracle import s2m2_oracle as O
 ACTS = [lambda t: t, F.gelu, F.relu, torch.sigmoid, torch.tanh]
 
 
+def row_attn_reference(x, heads, cross, weights, vectors, ln_eps=1e-5, ln_out_eps=None, rounding=None):
+    """s2m2_row_attn (include/s2m2_hip.h) in plain PyTorch: z' = z + proj(attention(LN(z), LN(s)));  out = z' + ffn(LN(z')), s = the same line of
+    image (n + nimg/2) % nimg (cross) or z.  weights (768, 128) in the row_attn packing, vectors (12, 128) as the entry point takes them.
+    rounding: dtype every intermediate the kernel rounds is rounded to (None: fp32 throughout)."""
+    from s2m2_amd.pack import rowattn_unpack
+    rd = (lambda t: t.to(rounding).float()) if rounding is not None else (lambda t: t)
+    wq, wk, wv, wp, w0, w2 = rowattn_unpack(weights).float().chunk(6, 0)
+    v = vectors.float()
+    bq, wsq, bk, wsk, bp, b0, ws0, b2, g, b, bv, wsv = (v[i] for i in range(12))
+    for ws, w in ((wsq, wq), (wsk, wk), (wsv, wv), (ws0, w0)):
+        assert torch.allclose(ws, w.sum(1), atol=2e-3)
+    z = x.float()
+    nimg, h, w, C = z.shape
+    d = C // heads
+    ln = lambda t: F.layer_norm(t, (C,), eps=ln_eps)                      # noqa: E731
+    src = z.roll(nimg // 2, 0) if cross else z
+    q, k, vv = rd(F.linear(ln(z), wq, bq)), rd(F.linear(ln(src), wk, bk)), rd(F.linear(ln(src), wv, bv))
+    sp = lambda t: t.reshape(nimg * h, w, heads, d).transpose(1, 2)       # noqa: E731
+    a = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) * d ** -0.5, -1)
+    o = rd((a @ sp(vv)).transpose(1, 2).reshape(nimg, h, w, C))
+    z1 = rd(rd(F.linear(o, wp, bp)) + z)
+    hdn = rd(F.gelu(F.linear(ln(z1), w0, b0)))
+    out = rd(rd(F.linear(hdn, w2, b2)) + z1).to(x.dtype)
+    if ln_out_eps is None:
+        return out
+    return out, F.layer_norm(out.float(), (C,), g, b, ln_out_eps).to(x.dtype)
+
+
 def make():
     ns = types.SimpleNamespace(ACT_NONE=0, ACT_GELU=1, ACT_RELU=2, ACT_SIGMOID=3, ACT_TANH=4,
                                EPI_NONE=0, EPI_ADD=1, EPI_MUL=2, EPI_GRU=3, EPI_GATEMIX=4, EPI_DUALMIX=5, load=lambda: None)
@@ -128,6 +156,12 @@ def make():
     def feature_fusion_supported(C, dtype):
         return C in (128, 256)
 
+    def row_attn_supported(C, heads, w, dtype):
+        return C == 128 and heads in (1, 2) and 8 <= w <= 320       # (the kernel is fp16 only; the stand-in wires any dtype)
+
+    def row_attn(x, heads, cross, weights, vectors, ln_eps=1e-5, ln_out_eps=None, xcd_hint=True):
+        return row_attn_reference(x, heads, cross, weights, vectors, ln_eps, ln_out_eps)
+
     def feature_fusion(z0, z1, w1, b1, w2, bg, bf, z1_coarse=False):
         C = z0.shape[-1]
         if z1_coarse:
@@ -225,6 +259,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, pw_direct_supported, conv_narrow_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, pw_direct_supported, conv_narrow_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported, row_attn, row_attn_supported):
         setattr(ns, f.__name__, f)
     return ns

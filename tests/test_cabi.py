@@ -1,5 +1,6 @@
 """CPU-side checks of the drop-in boundary: libs2m2_hip.so loads and exports every symbol of include/s2m2_hip.h.
 No compute calls (there is no GPU in the build container); argument validation paths only."""
+import ctypes
 import os
 import re
 
@@ -34,7 +35,9 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 def test_version_and_error_reporting(lib):
     assert lib.s2m2_version() >= 100
-    assert lib.s2m2_ln_corr(None, None, None, None, 1, 1, 8, 128, 1, 1, None) != 0
+    kd = hip.CorrDesc()
+    kd.B, kd.h, kd.w, kd.C, kd.band, kd.token_dtype, kd.cv_dtype = 1, 1, 8, 128, -1, hip.F16, hip.F16
+    assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0
     assert b"null pointer" in lib.s2m2_last_error()
     assert lib.s2m2_sinkhorn_regress(None, None, None, None, None, 1, 1, 8, 3, 1, 1, 0, None, None) != 0
     assert lib.s2m2_cv_lookup(None, None, None, None, 1, 1, 8, 4, 1, 0, 0, 0, 0, 0, None) != 0
@@ -126,7 +129,7 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"act=" in lib.s2m2_last_error()
     nd.act, nd.head_cout, nd.head_frag = hip.ACT_RELU, 16, 4096                                                  # the fused head: 48-channel form only
     assert lib.s2m2_conv_narrow(ctypes.byref(nd), None) != 0 and b"fused 1x1 head" in lib.s2m2_last_error()
-    # round 5: K1 through one descriptor; the ABI 400 entry points are shims over it
+    # K1 through one descriptor (the positional ABI 400 entry points were removed with ABI 600)
     assert lib.s2m2_cost_volume(None, None) != 0 and b"null descriptor" in lib.s2m2_last_error()
     kd = hip.CorrDesc()
     kd.tokens, kd.cv, kd.B, kd.h, kd.w, kd.C, kd.band, kd.token_dtype, kd.cv_dtype = 4096, 4096, 1, 2, 12, 128, -1, hip.F16, hip.F16
@@ -139,7 +142,6 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0 and b"band" in lib.s2m2_last_error()
     kd.band, kd.token_dtype = -1, hip.F32
     assert lib.s2m2_cost_volume(ctypes.byref(kd), None) != 0 and b"dtype pair" in lib.s2m2_last_error()
-    assert lib.s2m2_corr(None, None, 1, 2, 16, 128, 0, hip.F16, hip.F16, -1, None, None, None) != 0 and b"null pointer" in lib.s2m2_last_error()
     assert lib.s2m2_feature_fusion_supported(128, hip.F16) == 1 and lib.s2m2_feature_fusion_supported(384, hip.F16) == 0
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 64, 192, 4096, 4096, 4096, 4096, 4096, 0, 0, hip.F16, None) != 0
     assert b"not supported" in lib.s2m2_last_error()

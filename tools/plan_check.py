@@ -22,7 +22,7 @@ with torch.autocast("cuda", dtype=torch.float16):
         out = nm(*pairs[k])
         print("pair", k, [bool(torch.equal(a, b)) for a, b in zip(out, ref[k])], [float((a - b).abs().max()) for a, b in zip(out, ref[k])])
 eng = next(iter(nm._engines.values()))
-for k_, v in eng._bufs.items():
+for k_, v in {**eng._bufs, **eng._plans}.items():
     if isinstance(k_, tuple) and k_[0] == "refine_plan":
         print(k_[1], type(v), v[0].launches if isinstance(v, tuple) else v, [v[0].patches(i) for i in range(7)] if isinstance(v, tuple) else '')
 os.environ["S2M2_GRAPH"] = "1"
