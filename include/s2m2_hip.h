@@ -339,9 +339,9 @@ int s2m2_mlp_chain(const s2m2_chain_desc* desc, void* stream);
  *                 (2) unit-major: the 16-byte unit u (columns 8u .. 8u+7 of (1)) of row r at element (u * 128 + r) * 8 of the layer -- the
  *                 kernel copies a layer into LDS with a linear LDS-DMA and reads conflict-free fragments at immediate offsets
  *     vectors     twelve fp32 vectors of 128 back to back, 16-byte aligned (absent biases as zeros): 0 bias q, 1 row sums of q, 2 bias k,
- *                 3 row sums of k, 4 bias proj, 5 bias ffn.0, 6 row sums of ffn.0, 7 bias ffn.2, 8 ln_out gamma, 9 ln_out beta, 10 bias v,
- *                 11 row sums of v.  Row sums (of the plain fp16 weight, in fp32) fold the LayerNorm without affine (eps ln_eps) in front
- *                 of q, k, v, ffn.0 as in s2m2_conv2d (ln_wsum); 8 / 9 are read only with ln_out
+ *                 3 row sums of k, 4 bias v, 5 row sums of v, 6 bias proj, 7 bias ffn.0, 8 row sums of ffn.0, 9 bias ffn.2, 10 ln_out gamma,
+ *                 11 ln_out beta.  Row sums (of the plain fp16 weight, in fp32) fold the LayerNorm without affine (eps ln_eps) in front
+ *                 of q, k, v, ffn.0 as in s2m2_conv2d (ln_wsum); 10 / 11 are used only with ln_out
  *     ln_out      optional second output: LayerNorm(out) * gamma + beta (eps ln_out_eps) -- DispInit's layer_norm (submodules.py:165,216)
  *                 when this step writes feature_tr_4x, as s2m2_chain_desc.ln_out
  *     xcd_hint    1 (h % 8 == 0): line y of every image runs on XCD y / (h / 8) -- where s2m2_cost_volume reads the rows (see

@@ -119,6 +119,45 @@ __device__ __forceinline__ void ra_load_tile(Tile& a, const half_t* tok, int hi)
         a[s].v = __builtin_bit_cast(half8_t, v);
     }
 }
+// the same tile requested with loads the compiler does not track (no s_waitcnt of its own: with LDS-DMA in flight hipcc would wait for
+// vmcnt(0), i.e. for every DMA issued after them as well); consumed through ra_settle_tile after a counted wait
+struct RawTile { raw8_t r[16]; };
+__device__ __forceinline__ void ra_load_tile_async(RawTile& t, const half_t* tok, int hi) {
+    const half_t* p = tok + 4 * hi;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(t.r[k]) : "v"(p), "n"(k * 16));
+}
+__device__ __forceinline__ void ra_settle_tile(Tile& a, RawTile& t) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) asm volatile("" : "+v"(t.r[k]));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const raw16_t v = {t.r[2 * s].x, t.r[2 * s].y, t.r[2 * s + 1].x, t.r[2 * s + 1].y};
+        a[s].v = __builtin_bit_cast(half8_t, v);
+    }
+}
+__device__ __forceinline__ void ra_wait_vmcnt(int n) {           // n outstanding vector-memory operations may remain (block-uniform n <= 16)
+    switch (n) {
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 __device__ __forceinline__ void ra_store_tile(half_t* tok, const Tile& a, int hi) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -235,7 +274,7 @@ __global__ __launch_bounds__(MAXT) void row_attn_kernel(RowAttnArgs a) {
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = nthr >> 6;
     float2_t* stat = reinterpret_cast<float2_t*>(smem + OFF_ST) + wv * 32;
-    float* cv = reinterpret_cast<float*>(smem + OFF_CV);         // front: bias q, wsum q, bias k, wsum k;  tail: bias proj, bias ffn.0, wsum ffn.0, bias ffn.2, gamma, beta
+    float* cv = reinterpret_cast<float*>(smem + OFF_CV);         // front: vectors 0..5 (q, k, v: bias, row sums);  tail: vectors 6..11
 
     // row of this block; with the placement hint, XCD x (blocks are dealt round robin) owns the x-th eighth of every image's lines, and the
     // rows of one line in all images (a cross-attention pair included) are neighbours in dispatch order on that XCD
@@ -255,28 +294,24 @@ __global__ __launch_bounds__(MAXT) void row_attn_kernel(RowAttnArgs a) {
     const int tokc = tok < w ? tok : w - 1;
     RA_T(0);
 
-    // ---- Wq (K buffer) + the front vectors + own tokens first; Wk (W1), Wv (W0) land under the Q projection; Q = LN-fold(Wq . x)
-    ra_dma(a.wgt, Ks, wv, nwv, lane);
-    ra_dma_vecs<4>(cv, a.vec, wv, lane);
+    // ---- the front vectors, own tokens, Wq (K buffer), then Wk (W1), Wv (W0): the Q projection starts when the first three have landed
+    // (vector-memory operations return in order: a counted wait leaves exactly the Wk / Wv copies of THIS wave in flight); Q = LN-fold(Wq . x)
+    ra_dma_vecs<6>(cv, a.vec, wv, lane);
     const int ntile = (w + 31) >> 5;
     const int nchunk = (ntile + 4) / 5;
     Tile q;
-    Tile sa0;                                                    // source tile of this wave's first projection item (chunk 0), requested now
     {
-        const int nt0 = ntile < 5 ? ntile : 5;
-        const int tl0 = wv >= nt0 ? wv - nt0 : wv;
-        int st_tok = tl0 * 32 + l31;
-        st_tok = st_tok < w ? st_tok : w - 1;
-        Tile xa;
-        ra_load_tile(xa, xrow + (long long)tokc * a.xs, hi);
-        if constexpr (MAXT <= 320) {                             // (five-wave blocks have 256 registers; at ten waves the 32 extra live registers spill)
-            if (wv < 2 * nt0) ra_load_tile(sa0, srcrow + (long long)st_tok * a.xs, hi);
-        }
-        float mean, rstd;
-        ra_ln_stats(xa, a.ln_eps, mean, rstd);                   // (waits for the tokens; the DMA issued before them has landed by then: in-order return)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RawTile xr;
+        ra_load_tile_async(xr, xrow + (long long)tokc * a.xs, hi);
+        ra_dma(a.wgt, Ks, wv, nwv, lane);
         ra_dma(a.wgt + 1 * C * C, W1, wv, nwv, lane);
         ra_dma(a.wgt + 2 * C * C, W0, wv, nwv, lane);
+        const int nkv = 2 * ((32 - wv + nwv - 1) / nwv);         // DMA instructions this wave issued for Wk and Wv
+        ra_wait_vmcnt(nkv < 16 ? nkv : 0);
+        Tile xa;
+        ra_settle_tile(xa, xr);
+        float mean, rstd;
+        ra_ln_stats(xa, a.ln_eps, mean, rstd);
         ra_barrier_lds();                                        // Wq and the vectors of every wave's share are in LDS
         RA_T(1);
         float16_t acc[4];
@@ -297,8 +332,8 @@ __global__ __launch_bounds__(MAXT) void row_attn_kernel(RowAttnArgs a) {
 #pragma unroll 1
     for (int c = 0; c < nchunk; ++c) {
         const int nt = ntile - 5 * c < 5 ? ntile - 5 * c : 5;    // key tiles of this chunk
-        if (c == 0) __syncthreads();                             // Q done with the K buffer, Wk / Wv have landed (drains the DMA)
-        else ra_barrier_lds();                                   // previous chunk's K, V consumed
+        if (c == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RA_T(6); }   // this wave's share of Wk / Wv has landed
+        ra_barrier_lds();                                        // Q done with the K buffer / previous chunk's K, V consumed
         if (c < 2) RA_T(3 + 3 * c);
         // ---- projection: items [0, nt) = K tiles, [nt, 2 nt) = V tiles, dealt to the waves
 #pragma unroll 1
@@ -308,10 +343,7 @@ __global__ __launch_bounds__(MAXT) void row_attn_kernel(RowAttnArgs a) {
             int st_tok = (5 * c + tl) * 32 + l31;
             st_tok = st_tok < w ? st_tok : w - 1;
             Tile sa;
-            if (MAXT <= 320 && c == 0 && item == wv) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sa[k] = sa0[k];
-            } else ra_load_tile(sa, srcrow + (long long)st_tok * a.xs, hi);
+            ra_load_tile(sa, srcrow + (long long)st_tok * a.xs, hi);
             float mean, rstd;
             ra_ln_stats(sa, a.ln_eps, mean, rstd);
             if (!isv) {
@@ -345,7 +377,7 @@ __global__ __launch_bounds__(MAXT) void row_attn_kernel(RowAttnArgs a) {
                     float16_t acc;
                     ra_linear_tile<true>(acc, W0, sa, T, l31, hi);
                     const int d = 32 * T + l31;
-                    const float bv = a.vec[10 * C + d], ws = a.vec[11 * C + d];
+                    const float bv = cv[4 * C + d], ws = cv[5 * C + d];
                     half_t* vr = Vt + d * VRS + tl * 32 + 8 * hi;
 #pragma unroll
                     for (int sp = 0; sp < 2; ++sp) {
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(MAXT) void row_attn_kernel(RowAttnArgs a) {
         if (c == nchunk - 1) {                                   // Wk / Wv and the front vectors are dead: proj -> W0, ffn.0 -> W1 and the tail's
             ra_dma(a.wgt + 3 * C * C, W0, wv, nwv, lane);        // vectors land under the attention below
             ra_dma(a.wgt + 4 * C * C, W1, wv, nwv, lane);
-            ra_dma_vecs<6>(cv, a.vec + 4 * C, wv, lane);
+            ra_dma_vecs<6>(cv, a.vec + 6 * C, wv, lane);
         }
         // ---- attention of this wave's 32 queries over the chunk's keys (K4's per-32-key online softmax)
 #pragma unroll 1

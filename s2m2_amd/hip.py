@@ -624,7 +624,7 @@ def row_attn(x: torch.Tensor, heads: int, cross: bool, weights: torch.Tensor, ve
     """K13: one 1-D attention step of BasicAttnBlock (attentions.py:347-355) on the token rows of x (nimg, h, w, 128) in one launch:
     z' = z + proj(attention(LN(z), LN(s)));  out = z' + ffn(LN(z'))  with s = the same line of image (n + nimg/2) % nimg (cross) or z itself.
     weights: (6 * 128, 128) fp16 -- q, k, v, proj, ffn.0, ffn.2 in the row_attn packing (pack.rowattn_pack); vectors: (12, 128) fp32 --
-    bias q, row sums q, bias k, row sums k, bias proj, bias ffn.0, row sums ffn.0, bias ffn.2, ln_out gamma, ln_out beta, bias v, row sums v
+    bias q, row sums q, bias k, row sums k, bias v, row sums v, bias proj, bias ffn.0, row sums ffn.0, bias ffn.2, ln_out gamma, ln_out beta
     (pack.rowattn_vectors).  ln_out_eps: also return LayerNorm(out) * gamma + beta with that eps -> (out, normalised)."""
     if x.dim() != 4 or x.dtype != torch.float16 or not x.is_cuda or x.stride(3) != 1:
         raise ValueError("row_attn: x must be an (nimg, h, w, C) fp16 device tensor with contiguous channels")

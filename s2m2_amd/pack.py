@@ -264,4 +264,4 @@ def rowattn_vectors(wsums, biases, ln_affine=None) -> torch.Tensor:
     f = lambda t: z if t is None else t.float().reshape(128).to(dev)      # noqa: E731
     bq, bk, bv, bp, b0, b2 = (f(b) for b in biases)
     g, b = (f(ln_affine[0]), f(ln_affine[1])) if ln_affine is not None else (z + 1.0, z)
-    return torch.stack([bq, f(wsums[0]), bk, f(wsums[1]), bp, b0, f(wsums[3]), b2, g, b, bv, f(wsums[2])]).contiguous()
+    return torch.stack([bq, f(wsums[0]), bk, f(wsums[1]), bv, f(wsums[2]), bp, b0, f(wsums[3]), b2, g, b]).contiguous()

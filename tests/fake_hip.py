@@ -19,7 +19,7 @@ def row_attn_reference(x, heads, cross, weights, vectors, ln_eps=1e-5, ln_out_ep
     rd = (lambda t: t.to(rounding).float()) if rounding is not None else (lambda t: t)
     wq, wk, wv, wp, w0, w2 = rowattn_unpack(weights).float().chunk(6, 0)
     v = vectors.float()
-    bq, wsq, bk, wsk, bp, b0, ws0, b2, g, b, bv, wsv = (v[i] for i in range(12))
+    bq, wsq, bk, wsk, bv, wsv, bp, b0, ws0, b2, g, b = (v[i] for i in range(12))
     for ws, w in ((wsq, wq), (wsk, wk), (wsv, wv), (ws0, w0)):
         assert torch.allclose(ws, w.sum(1), atol=2e-3)
     z = x.float()
