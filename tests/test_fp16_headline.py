@@ -255,10 +255,77 @@ def test_c3_fp16_headline_against_the_autocast_emulation():
                                       ref16_vs_ref32=yard, k1_k2=dict(cv_max=float(d.max()), cv_frac_differing=float((d > 0).float().mean()), **am2)))
     for nm in ("disp", "occ", "conf"):
         assert s3[nm]["median"] <= yard[nm]["median"] + 1e-4 and s3[nm]["p99"] <= yard[nm]["p99"] + 1e-3, (nm, s3[nm], yard[nm])
-    # the last iteration's 1/4-resolution disparity (before the upsampling head): the yardstick / 4 is 0.1946; the statistic is one realisation of
-    # amplified rounding noise and moves with every change of summation order upstream (0.1947 at r04, 0.1957 at r05 after the attention score
-    # form, the GroupNorm reduction tree and the two-stage ctx chain changed last bits) -- same 1.15 margin as the free-running finals of (a)
-    assert s3[f"disp_it{ri - 1}"]["median"] <= 1.15 * 0.25 * yard["disp"]["median"] + 1e-3, (s3[f"disp_it{ri - 1}"], yard["disp"])
+    # (the last iteration's 1/4-resolution disparity -- ONE realisation of amplified rounding noise per pair, 0.1947 / 0.1957 / 0.1908 / 0.1920 in
+    # rounds 4 - 6 against a yardstick / 4 of 0.1946 -- is judged on an ensemble of three pairs: test_c3_fp16_teacher_forced_ensemble)
+
+
+@pytest.mark.gpu
+def test_c3_fp16_teacher_forced_ensemble():
+    """The teacher-forced statistics of the headline workload as a MEAN over three seeded pairs, so that a change of summation order upstream
+    cannot flip the test either way.  Per pair: the oracle's autocast emulation (fp16) and the oracle in fp32, both free running on the natural
+    pair -> the yardstick (how far the fp16 deployment sits from fp32 on this pair, after three refinement iterations with randomly initialised
+    refiners); the HIP fp16 forward continued from the emulation's cv / disp0 / conf0 / occ0 against the emulation.  Bound: no margin on the
+    means, at full resolution (disp) and at 1/4 resolution before the upsampling head (disp_it{last})."""
+    import parity_util as PU
+    g, c = _load("c3")
+    ri = c["ri"]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    sd = seeded_state_dict(c["C"], 1, c["ntr"], c["seed"], gain=c["gain"])
+    names = ["disp", f"disp_it{ri - 1}"]
+    mine = {n: [] for n in names}
+    yard = {n: [] for n in names}
+    per_pair = []
+    for k in range(3):
+        left, right = synthetic_pair(c["H"], c["W"], 1, c["disparity"], c["seed"] + k)
+        n16, n32 = {}, {}
+        on16 = O.forward(sd, left, right, True, ri, False, n16, precision="fp16")
+        on32 = O.forward(sd, left, right, True, ri, False, n32, precision="fp32")
+        h3, hc3 = _hip(c, left, right, True, inject={key: n16[key] for key in ("cv", "disp0", "conf0", "occ0")})
+        r3, _ = PU.compare(hc3, h3, n16, on16, ri)
+        ry, _ = PU.compare(n16, on16, n32, on32, ri)
+        s3, sy = PU.select(r3, names), PU.select(ry, names)
+        for n in names:
+            mine[n].append(s3[n]["median"])
+            yard[n].append(sy[n]["median"])
+        per_pair.append(dict(seed=c["seed"] + k, hip16_vs_emulation={n: s3[n]["median"] for n in names}, emulation_vs_fp32={n: sy[n]["median"] for n in names}))
+    mean = lambda v: sum(v) / len(v)                                  # noqa: E731
+    _report("c3_teacher_forced_ensemble", dict(pairs=per_pair, mean_hip16_vs_emulation={n: mean(mine[n]) for n in names},
+                                               mean_emulation_vs_fp32={n: mean(yard[n]) for n in names},
+                                               golden_ref16_vs_ref32_pair0=_dist(g["n_disp_16"], g["n_disp_32"])["median"]))
+    for n in names:
+        assert mean(mine[n]) <= mean(yard[n]) + 1e-4, (n, mine[n], yard[n])
+
+
+@pytest.mark.gpu
+def test_web0025_full_size_fp16_against_the_references_cpu_autocast_run():
+    """The reference's own sample pair data/samples/Web/0025_{L,R}.png at its natural size (1100 x 800, padded to 1120 x 800 by image_pad), S model,
+    refine_iter 3, fp16: image_pad -> forward under autocast -> image_crop (the body of run_stereo_matching, model_utils.py:69-94) against the
+    golden of the reference's CPU-autocast run of the same body, with the reference's fp32 run as the yardstick (tests/golden/make_golden_web_fp16.py)."""
+    from s2m2_amd import utils
+    from s2m2_amd.model import S2M2
+    g = np.load(os.path.join(HERE, "golden", "e2e_S_web0025_full_fp16_r3.npz"))
+    C, ntr, H, W, _, pos, ri, _, seed = [int(v) for v in g["cfg"]]
+    left = torch.from_numpy(g["left"]).permute(2, 0, 1)[None].cuda()
+    right = torch.from_numpy(g["right"]).permute(2, 0, 1)[None].cuda()
+    m = S2M2(C, 1, ntr, use_positivity=bool(pos), refine_iter=ri)
+    m.load_state_dict(seeded_state_dict(C, 1, ntr, seed), strict=True)
+    m = m.cuda().eval()
+    lp, rp = utils.image_pad(left, 32), utils.image_pad(right, 32)
+    assert tuple(lp.shape[-2:]) == tuple(int(v) for v in g["padded"])
+    with torch.inference_mode(), torch.autocast("cuda", dtype=torch.float16):
+        out = m(lp, rp)
+    d, o, c = (utils.image_crop(t, (H, W)).squeeze().float().cpu() for t in out)
+    assert tuple(d.shape) == (H, W) and all(torch.isfinite(t).all() for t in (d, o, c))
+    rep = {}
+    for nm, t in (("disp", d), ("occ", o), ("conf", c)):
+        rep[nm] = dict(hip16_vs_ref16=_dist(t[::2, ::2], g[f"{nm}_fp16"]), ref16_vs_ref32=_dist(g[f"{nm}_fp16"], g[f"{nm}_fp32"]),
+                       hip16_vs_ref32=_dist(t[::2, ::2], g[f"{nm}_fp32"]))
+    score = float(c[100:-100, 100:-100].mean())
+    rep["avg_conf"] = dict(hip16=score, ref16=float(g["avg_conf_fp16"]), ref32=float(g["avg_conf_fp32"]))
+    _report("web0025_full_fp16", rep)
+    for nm, t in (("disp", d), ("occ", o), ("conf", c)):
+        _inside_spread(t[::2, ::2], g[f"{nm}_fp16"], g[f"{nm}_fp32"], f"web0025 HIP fp16 {nm}", eps=2e-3)
+    assert abs(score - float(g["avg_conf_fp16"])) <= max(3 * abs(float(g["avg_conf_fp16"]) - float(g["avg_conf_fp32"])), 2e-3), rep["avg_conf"]
 
 
 @pytest.mark.gpu
