@@ -311,7 +311,8 @@ typedef struct s2m2_chain_desc {
     /* > 0 (with weight_frag): x is an image tensor (N, pool_h, pool_w, C) with pixel stride x_stride, and row m = (n, yo, xo) of the
        (pool_h/2, pool_w/2) grid is the mean of its four pixels (2yo, 2xo) .. (2yo+1, 2xo+1): nn.AvgPool2d(2) in front of the 1x1 layer(s)
        (the down_conv of Unet / MRT, reference unet.py:24-29, stacked_MRT.py:21-26) folded into the tile load, rounded to fp16 like the
-       stand-alone pooling launch; rows = N * (pool_h/2) * (pool_w/2).  A residual (res) is not combined with it. */
+       stand-alone pooling launch; rows = N * (pool_h/2) * (pool_w/2).  With chain stages (nstage >= 1, ABI 600) or fan-out only; residual,
+       carry, ln_out and xcd_group_rows are not combined with it. */
     int pool_h, pool_w;
 } s2m2_chain_desc;
 int s2m2_mlp_chain_supported(int C, int dtype);

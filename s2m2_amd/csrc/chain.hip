@@ -629,8 +629,8 @@ static int mlp_chain_impl(const s2m2_chain_desc* d, void* stream) {
     S2M2_REQUIRE((d->pool_h == 0 && d->pool_w == 0) ||
                  (d->weight_frag && d->pool_h >= 2 && d->pool_w >= 2 && d->rows % ((long long)(d->pool_h / 2) * (d->pool_w / 2)) == 0),
                  "mlp_chain: pool_h / pool_w need weight_frag, an input of at least 2x2 pixels and rows = N * (pool_h/2) * (pool_w/2)");
-    S2M2_REQUIRE((d->pool_h == 0 && d->pool_w == 0) || (d->nstage == 0 && d->res_stage < 0 && !d->ln_out && d->xcd_group_rows == 0),
-                 "mlp_chain: pool_h / pool_w are a fan-out-only form (nstage = 0): no chain stages, residual, ln_out or xcd_group_rows with a pooled tile load");
+    S2M2_REQUIRE((d->pool_h == 0 && d->pool_w == 0) || (d->res_stage < 0 && !d->carry && !d->ln_out && d->xcd_group_rows == 0),
+                 "mlp_chain: no residual, carry, ln_out or xcd_group_rows with a pooled tile load (pool_h / pool_w)");
     if (d->nstage == 0 && d->weight_frag) {
         // fan-out only, direct form: the nfan layers read the x rows, their fragments straight from global memory (any row count)
         S2M2_REQUIRE(d->nfan >= 1 && d->nfan <= 4, "mlp_chain: nfan=%d (1..4)", d->nfan);

@@ -116,6 +116,11 @@ class Engine:
         # S2M2_ROWFUSE=0: every 1-D attention step as the launch triple Q|K|V fan-out / K4 / K9 chain (as up to round 5) instead of ONE K13
         # launch per step (hip.row_attn: fp16, C = 128 -- the S model's 1/4 and 1/8 levels; profiles/r06/ab_rowfuse.txt)
         self.use_rowfuse = os.environ.get("S2M2_ROWFUSE", "1") != "0"
+        # S2M2_COARSE_FUSE=0 (A/B): the 1/32 level's down_conv and the first block's Q | K | V, and the last block's chain and the decoder's
+        # up_conv, as separate launches (as up to round 5) instead of stages of one K9 launch each (profiles/r06/ab_coarse_fuse.txt)
+        self.coarse_fuse = os.environ.get("S2M2_COARSE_FUSE", "1") != "0"
+        # S2M2_GRU_FRAG=1 (A/B): ConvGRU's candidate layer (two-operand blend epilogue) on K5 v5's 64-pixel blocks instead of the v3 halo tiles
+        self.gru_frag = os.environ.get("S2M2_GRU_FRAG", "0") == "1"
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
         self.ln_w = self.p["disp_init.layer_norm.weight"].contiguous()
         self.ln_b = self.p["disp_init.layer_norm.bias"].contiguous()
@@ -297,15 +302,31 @@ class Engine:
             return hip.feature_fusion(z0, z1, ws, first[1], None, dual[1], dual[2], z1_coarse=z1_coarse, frag=True)
         return hip.feature_fusion(z0, z1, first[0], first[1], dual[0], dual[1], dual[2], z1_coarse=z1_coarse)
 
-    def fusion_up(self, p: str, z0: Tensor, pu: str, xc: Tensor) -> Tensor:
+    def fusion_up_ok(self, p: str, c: int, pu: str) -> bool:
+        """the decoder's fusion takes the coarse-grid form (1x1 up_conv on the coarse grid, K10 reads it through the bilinear resampling)"""
+        spec = self.std(pu + ".1")
+        first = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
+        return (spec[2] == 1 and spec[3] == 1 and spec[4] == c and first[2] == 1 and first[3] == 1
+                and self.p[p + ".feature_gate.0.weight"].shape[0] == c and self.fusion_ok(c))
+
+    def up_tail(self, p: str, c_fine: int, pu: str, c_coarse: int) -> Optional[Spec]:
+        """the decoder's up_conv as a fan-out stage of the K9 launch that produces its input (attn_ffn ``tail``): a plain C -> C 1x1 layer in
+        front of a coarse-grid fusion, direct K9 form available"""
+        spec = self.std(pu + ".1")
+        if (self.coarse_fuse and self.fusion_up_ok(p, c_fine, pu) and tuple(spec[0].shape) == (c_coarse, c_coarse) and c_fine == c_coarse
+                and not getattr(spec, "korder", 0) and self.chain_frag_ok(c_coarse)):
+            return spec
+        return None
+
+    def fusion_up(self, p: str, z0: Tensor, pu: str, xc: Tensor, up_pre: Optional[Tensor] = None) -> Tensor:
         """fusion(z0, up_conv(xc)) of the decoders (unet.py:98-110, stacked_MRT.py:113-121): the 1x1 up_conv runs on the coarse grid
-        (see up()) and K10 reads its output through the bilinear resampling -- no stand-alone K7 launch, no upsampled tensor."""
+        (see up()) and K10 reads its output through the bilinear resampling -- no stand-alone K7 launch, no upsampled tensor.
+        up_pre: up_conv(xc) on the coarse grid, where the launch that produced xc computed it (up_tail)."""
         spec = self.std(pu + ".1")
         c = z0.shape[-1]
         first = self.merged(p + "|gate+fusion", [(p + ".feature_gate.0", 0, 1.0, False), (p + ".feature_fusion.0", 0, 1.0, False)], 2 * c)
-        if (spec[2] == 1 and spec[3] == 1 and spec[4] == c and first[2] == 1 and first[3] == 1
-                and self.p[p + ".feature_gate.0.weight"].shape[0] == c and self.fusion_ok(c)):
-            return self.k10(p, z0, self.cconv(spec, [xc]), first, z1_coarse=True)
+        if self.fusion_up_ok(p, c, pu):
+            return self.k10(p, z0, up_pre if up_pre is not None else self.cconv(spec, [xc]), first, z1_coarse=True)
         return self.fusion(p, z0, self.up(pu, xc))
 
     def fusion(self, p: str, z0: Tensor, z1: Tensor) -> Tensor:
@@ -378,7 +399,7 @@ class Engine:
             wf = self._wfrag[wp.data_ptr()] = pack.chain_frag(wp)
         return wf
 
-    def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor, ln_out=None, next_attn: Optional[str] = None):
+    def attn_ffn(self, pa: str, pf: str, o: Tensor, z: Tensor, ln_out=None, next_attn: Optional[str] = None, tail: Optional[Spec] = None):
         """z' = z + proj(o);  z' + ffn.2(GELU(ffn.0(LayerNorm(z')))) (attentions.py:311-321,347-355): one K9 launch when the width
         is supported, else three K5 launches (pre-LN folded into the first FFN layer).  ln_out = (gamma, beta, eps): the K9 launch also
         writes LayerNorm(result) * gamma + beta (kept in ``self._tokens_normed`` for K1, see features()).  next_attn: prefix of the
@@ -403,6 +424,10 @@ class Engine:
                 qs = self.qkv_spec(next_attn)
                 if qs[2] == 1 and qs[3] == 1 and qs[4] == 3 * c:
                     return hip.mlp_chain(o, st, res=z, res_stage=0, carry=True, fan=(self.wfrag(qs), qs[1], self.wsum(qs)), frag=True)
+            if tail is not None:
+                # the layer applied to the result next (the decoder's 1x1 up_conv on the coarse grid) as a fan-out stage of this launch: no
+                # LayerNorm fold, its own bias -> (result, up_conv(result))
+                return hip.mlp_chain(o, st, res=z, res_stage=0, carry=True, fan=(self.wfrag(tail), tail[1], None), frag=True)
             return hip.mlp_chain(o, st, res=z, res_stage=0, carry=True, frag=True), None
         if self.chain_ok(c):                                       # LDS-staged form (fp32; fp16 at C = 384 / 512)
             st = [(sp[0], sp[1], act, self.wsum(sp) if sp is f0 else None) for sp, act in zip((proj, f0, f2), acts)]
@@ -496,7 +521,7 @@ class Engine:
         return hip.row_attn(z, nh, cross, ent[0], ent[1])
 
     def attn_block(self, p: str, z: Tensor, nh: int, two_d: bool, use_pe: bool = False, ln_out=None, qkv_in: Optional[Tensor] = None,
-                   next_block: Optional[str] = None):
+                   next_block: Optional[str] = None, tail: Optional[Spec] = None):
         """BasicAttnBlock (1-D, attentions.py:347-355) / GlobalAttnBlock (2-D, :311-321).  ln_out: see attn_ffn (last launch of the block).
         qkv_in: the Q | K | V projection of ``z`` for the block's first attention, if the launch that produced ``z`` computed it;
         next_block: prefix of the attention block applied to the result next (its first projection is computed here).
@@ -509,7 +534,8 @@ class Engine:
             o = self.attn_core(p + ".cross_attn", z, nh, two_d, True, False, qkv=qkv_in)
             z, qkv_in = self.attn_ffn(p + ".cross_attn", p + ".ffn_c", o, z, next_attn=p + ".self_attn.attn")
         o = self.attn_core(p + ".self_attn", z, nh, two_d, False, use_pe, qkv=qkv_in)
-        return self.attn_ffn(p + ".self_attn", p + ".ffn", o, z, ln_out=ln_out, next_attn=self.first_attn(next_block) if next_block else None)
+        return self.attn_ffn(p + ".self_attn", p + ".ffn", o, z, ln_out=ln_out, next_attn=self.first_attn(next_block) if next_block else None,
+                             tail=tail if next_block is None else None)
 
     def _count(self, prefix: str) -> int:
         n = 0
@@ -523,13 +549,29 @@ class Engine:
         z0 = self.conv_block(p + ".enc0", z)
         z1 = self.conv_block(p + ".enc1", self.down(p + ".down_conv0", z0))
         z2 = self.conv_block(p + ".enc2", self.down(p + ".down_conv1", z1))
-        z3 = self.down(p + ".down_conv2", z2)
         blocks = [(f"{p}.enc3s.{i}", use_pe) for i in range(self._count(p + ".enc3s"))] + \
                  [(f"{p}.dec3s.{i}", False) for i in range(self._count(p + ".dec3s"))]
         q = None
+        dspec = self.std(p + ".down_conv2.1")
+        c2 = z2.shape[-1]
+        qs = self.qkv_spec(self.first_attn(blocks[0][0])) if blocks else None
+        if (self.coarse_fuse and qs is not None and dspec[2] == 1 and dspec[3] == 1 and tuple(dspec[0].shape) == (c2, c2) and dspec[4] == c2
+                and not getattr(dspec, "korder", 0) and z2.shape[1] >= 2 and z2.shape[2] >= 2 and self.chain_frag_ok(c2)
+                and qs[2] == 1 and qs[3] == 1 and qs[4] == 3 * c2):
+            # AvgPool2d(2) + down_conv2 (unet.py:24-29) and the first attention block's pre-LN + Q | K | V in ONE K9 launch: a one-stage chain
+            # on the pooled tile with the projection as its fan-out stages
+            z3, q = hip.mlp_chain(z2, [(self.wfrag(dspec), dspec[1], hip.ACT_NONE, None)], fan=(self.wfrag(qs), qs[1], self.wsum(qs)),
+                                  frag=True, pool2=True)
+        else:
+            z3 = self.down(p + ".down_conv2", z2)
+        tail = self.up_tail(p + ".concat_conv2", c2, p + ".up_conv2", z3.shape[-1]) if blocks else None
+        up3 = None
         for k, (bp, pe) in enumerate(blocks):                     # consecutive blocks on the same tensor: each computes the next one's Q | K | V
-            z3, q = self.attn_block(bp, z3, 8, True, pe, qkv_in=q, next_block=blocks[k + 1][0] if k + 1 < len(blocks) else None)
-        n2 = self.conv_block(p + ".dec2", self.fusion_up(p + ".concat_conv2", z2, p + ".up_conv2", z3))
+            last = k + 1 == len(blocks)
+            z3, q = self.attn_block(bp, z3, 8, True, pe, qkv_in=q, next_block=None if last else blocks[k + 1][0], tail=tail if last else None)
+            if last and tail is not None:
+                up3, q = q, None
+        n2 = self.conv_block(p + ".dec2", self.fusion_up(p + ".concat_conv2", z2, p + ".up_conv2", z3, up_pre=up3))
         n1 = self.conv_block(p + ".dec1", self.fusion_up(p + ".concat_conv1", z1, p + ".up_conv1", n2))
         n0 = self.conv_block(p + ".dec0", self.fusion_up(p + ".concat_conv0", z0, p + ".up_conv0", n1))
         return n0, n1, n2, z3
@@ -541,9 +583,14 @@ class Engine:
         z3 = self.fusion(p + ".down_concat3", z3, self.down(p + ".down_conv2", z2))
         blocks = [f"{p}.enc_attn3s.{i}" for i in range(2)] + [f"{p}.dec_attn3s.{i}" for i in range(2)]
         q = None
+        tail = self.up_tail(p + ".up_concat2", z2.shape[-1], p + ".up_conv2", z3.shape[-1])
+        up3 = None
         for k, bp in enumerate(blocks):
-            z3, q = self.attn_block(bp, z3, 8, True, qkv_in=q, next_block=blocks[k + 1] if k + 1 < len(blocks) else None)
-        z2 = self.attn_block(p + ".dec_attn2", self.fusion_up(p + ".up_concat2", z2, p + ".up_conv2", z3), 4, False)[0]
+            last = k + 1 == len(blocks)
+            z3, q = self.attn_block(bp, z3, 8, True, qkv_in=q, next_block=None if last else blocks[k + 1], tail=tail if last else None)
+            if last and tail is not None:
+                up3, q = q, None
+        z2 = self.attn_block(p + ".dec_attn2", self.fusion_up(p + ".up_concat2", z2, p + ".up_conv2", z3, up_pre=up3), 4, False)[0]
         z1 = self.attn_block(p + ".dec_attn1", self.fusion_up(p + ".up_concat1", z1, p + ".up_conv1", z2), 2, False)[0]
         z0 = self.attn_block(p + ".dec_attn0", self.fusion_up(p + ".up_concat0", z0, p + ".up_conv0", z1), 1, False, ln_out=ln_out)[0]
         return z0, z1, z2, z3
@@ -570,7 +617,7 @@ class Engine:
             else:
                 z = self.cconv(self.std(f"{p}.convz{sfx}"), [h, x], act=hip.ACT_SIGMOID)
                 rh = self.cconv(self.std(f"{p}.convr{sfx}"), [h, x], act=hip.ACT_SIGMOID, epi=hip.EPI_MUL, aux0=h)
-            h = self.cconv(self.std(f"{p}.convq{sfx}", frag=False), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
+            h = self.cconv(self.std(f"{p}.convq{sfx}", frag=self.gru_frag), [rh, x], act=hip.ACT_TANH, epi=hip.EPI_GRU, aux0=z, aux1=h)
         return h
 
     def local_refiner(self, p: str, hidden: Tensor, ctx: Tensor, disp: Tensor, conf: Tensor, occ: Tensor, cv: Tensor, cap, it,

@@ -546,7 +546,7 @@ def mlp_chain_ln_out_supported(C: int, dtype: torch.dtype) -> bool:
 
 def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_stage: int = -1, carry: bool = False,
               ln_eps: float = 1e-5, ln_out: Optional[Tuple[torch.Tensor, torch.Tensor, float]] = None, xcd_group_rows: int = 0,
-              fan=None, frag: bool = False):
+              fan=None, frag: bool = False, pool2: bool = False):
     """Up to three C -> C 1x1 layers on the rows of x (..., C) in one launch (s2m2_mlp_chain).  stages: list of
     (packed weight (C, C), fp32 bias (C) or None, activation, ln_wsum fp32 (C) or None = pre-LayerNorm of that stage's input);
     res (same shape as x) is added to the output of stage res_stage; carry adds the output of stage 0 to the last of 3 stages.
@@ -555,11 +555,19 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
     fan = (packed weight (n*C, C), fp32 bias (n*C) or None, ln_wsum fp32 (n*C) or None): n further C -> C layers on the OUTPUT rows
     (pre-LayerNorm folded in when ln_wsum is given), returned as one (..., n*C) tensor: the fused QKV projection of the next attention.
     frag: every weight (stages and fan) is in MFMA-fragment order (pack.chain_frag) -> the direct form of the kernel, meant for short row
-    counts (mlp_chain_frag_supported).
+    counts (mlp_chain_frag_supported).  pool2 (frag, x (N,H,W,C), no res / carry / ln_out): nn.AvgPool2d(2) in front of the first stage,
+    folded into the tile load -> outputs on the (N, H//2, W//2) grid.
     Return value: out, or a tuple (out[, normalised][, fan_out]) in that order."""
     C = x.shape[-1]
     rows, xs = _token_rows(x, "mlp_chain")
+    oshape = tuple(x.shape[:-1])
     d = ChainDesc()
+    if pool2:
+        if not frag or x.dim() != 4 or x.shape[1] < 2 or x.shape[2] < 2 or res_stage >= 0 or carry or ln_out is not None:
+            raise ValueError("mlp_chain: pool2 needs frag, an (N,H,W,C) tensor of at least 2x2 pixels and no res / carry / ln_out")
+        oshape = (x.shape[0], x.shape[1] // 2, x.shape[2] // 2)
+        rows = oshape[0] * oshape[1] * oshape[2]
+        d.pool_h, d.pool_w = x.shape[1], x.shape[2]
     d.x, d.x_stride, d.rows, d.C, d.nstage, d.dtype = x.data_ptr(), xs, rows, C, len(stages), _DT[x.dtype]
     if not 1 <= len(stages) <= 3:
         raise ValueError("mlp_chain: 1..3 stages")
@@ -583,7 +591,7 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
         if res is None or res.dtype != x.dtype or tuple(res.shape) != tuple(x.shape):
             raise ValueError("mlp_chain: res must match x")
         d.res, d.res_stride = res.data_ptr(), _token_rows(res, "mlp_chain")[1]
-    out = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    out = torch.empty(oshape + (C,), device=x.device, dtype=x.dtype)
     d.out, d.out_stride = out.data_ptr(), C
     normed = None
     if ln_out is not None:
@@ -604,7 +612,7 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
         for name, t in (("fan bias", fb), ("fan ln_wsum", fws)):
             if t is not None and (t.dtype != torch.float32 or t.numel() != nfan * C or not t.is_contiguous() or not t.is_cuda):
                 raise ValueError(f"mlp_chain: {name} must be fp32 ({nfan * C}) on the device")
-        fan_out = torch.empty(tuple(x.shape[:-1]) + (nfan * C,), device=x.device, dtype=x.dtype)
+        fan_out = torch.empty(oshape + (nfan * C,), device=x.device, dtype=x.dtype)
         d.fan_weight, d.fan_out, d.fan_out_stride, d.nfan = fw.data_ptr(), fan_out.data_ptr(), nfan * C, nfan
         d.fan_bias = fb.data_ptr() if fb is not None else None
         d.fan_ln_wsum = fws.data_ptr() if fws is not None else None

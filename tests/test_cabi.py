@@ -89,12 +89,12 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"pool_h" in lib.s2m2_last_error()
     c.weight_frag, c.rows = 1, 7                                    # 7 rows are not N * 2 * 2 pooled pixels
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"pool_h" in lib.s2m2_last_error()
-    c.rows, c.nstage = 8, 1                                         # round 4: the pooled tile load is a fan-out-only form (nstage = 0):
-    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"fan-out-only" in lib.s2m2_last_error()     # ... no chain stages,
-    c.nstage, c.nfan, c.xcd_group_rows = 0, 1, 4
-    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"fan-out-only" in lib.s2m2_last_error()     # ... no XCD placement hint,
+    c.rows, c.nstage, c.res_stage, c.res = 8, 1, 0, 4096            # the pooled tile load (ABI 600: chain stages allowed) takes no residual,
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"pooled tile load" in lib.s2m2_last_error()
+    c.res_stage, c.nstage, c.nfan, c.xcd_group_rows = -1, 0, 1, 4
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"pooled tile load" in lib.s2m2_last_error()     # ... no XCD placement hint,
     c.xcd_group_rows, c.ln_out = 0, 4096
-    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"fan-out-only" in lib.s2m2_last_error()     # ... no LayerNorm output
+    assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"pooled tile load" in lib.s2m2_last_error()     # ... no LayerNorm output
     assert lib.s2m2_version() == hip.ABI_VERSION
     c = hip.ChainDesc()                                            # fan-out only, direct form: nfan 1..4
     c.x, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.res_stage, c.weight_frag, c.nfan = 4096, 256, 0, hip.F16, 8, 256, -1, 1, 5

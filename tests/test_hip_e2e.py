@@ -156,3 +156,20 @@ def test_native_refine_step_is_bit_identical_and_rebinds_its_inputs(monkeypatch)
             out = g_m(l, r)
             for a, b in zip(out, ref[k]):
                 assert torch.equal(a, b), f"graph forward {k}"
+
+
+@pytest.mark.gpu
+def test_coarse_level_stage_fusion_is_bit_identical(monkeypatch):
+    """S2M2_COARSE_FUSE (engine.py): at 1/32, AvgPool + down_conv2 + the first attention block's Q | K | V as one K9 launch, and the last
+    block's chain + the decoder's up_conv as one K9 launch -- the same arithmetic in the same order as the separate launches."""
+    from s2m2_amd.weights import seeded_state_dict, synthetic_pair
+    import parity_util as PU
+    l, r = synthetic_pair(128, 192, 1, 16, 5)
+    sd = seeded_state_dict(128, 1, 1, 0)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("S2M2_COARSE_FUSE", flag)
+        res[flag] = PU.hip_forward(sd, 128, 1, 2, l, r, True)
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert torch.equal(a, b)
+    assert torch.equal(res["1"][1]["feature_tr_4x"], res["0"][1]["feature_tr_4x"])
