@@ -160,30 +160,46 @@ def attention_and_work(eng, left, right, use_fp16, B, ms_per_pair):
     from s2m2_amd import hip
     saved = eng.k1_events
     eng.k1_events = None
-    hip.METER, hip.ATTN_EVENTS = {}, []
+    hip.METER, hip.ATTN_EVENTS, hip.ROW_EVENTS = {}, [], []
     with torch.autocast("cuda", enabled=False):
         eng.run(left, right, None)
     torch.cuda.synchronize()
-    meter, attn_ev = hip.METER, hip.ATTN_EVENTS
-    hip.METER = hip.ATTN_EVENTS = None
+    meter, attn_ev, row_ev = hip.METER, hip.ATTN_EVENTS, hip.ROW_EVENTS
+    hip.METER = hip.ATTN_EVENTS = hip.ROW_EVENTS = None
     eng.k1_events = saved
     peak_tf = MFMA_F16_PEAK_TFLOPS if use_fp16 else MFMA_F32_PEAK_TFLOPS
-    a_us = sum(1e3 * s.elapsed_time(e_) for s, e_, _, _ in attn_ev)
-    a_fl = sum(f for _, _, f, _ in attn_ev)
+    a_us = sum(1e3 * s.elapsed_time(e_) for s, e_, *_ in attn_ev)
+    a_fl = sum(f for _, _, f, *_ in attn_ev)
     by_shape = {}
-    for s, e_, f, tag in attn_ev:
-        d = by_shape.setdefault(tag, [0, 0.0, 0.0])
+    for s, e_, f, tag, nbytes in attn_ev:
+        d = by_shape.setdefault(tag, [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += 1e3 * s.elapsed_time(e_)
         d[2] += f
+        d[3] += nbytes
+
+    def roof(us, flops, nbytes):
+        """a launch (or a sum of launches) against min(HBM, MFMA): the time the binding roofline allows over the time measured"""
+        t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9) * 1e6, flops / (peak_tf * 1e12) * 1e6
+        return {"us": round(us, 1), "tflops": round(flops / (us * 1e-6) / 1e12, 1) if us > 0 else 0.0, "roofline_us": round(max(t_hbm, t_mfma), 2),
+                "bound": "hbm" if t_hbm > t_mfma else "mfma", "frac_of_roofline": round(max(t_hbm, t_mfma) / us, 4) if us > 0 else 0.0}
+
+    rows_by = {}
+    for s, e_, f, nbytes, tag in row_ev:
+        d = rows_by.setdefault(tag, [0, 0.0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += 1e3 * s.elapsed_time(e_)
+        d[2] += f
+        d[3] += nbytes
     fwd_flops = sum(v[0] for v in meter.values()) / B
     attn = {"kernel": "attention_kernel (K4: every QK^T / PV contraction of a forward)", "bound": "mfma",
             "achieved": a_fl / (a_us * 1e-6) / 1e12 if a_us > 0 else 0.0, "peak": peak_tf, "unit": "TFLOP/s",
             "frac": (a_fl / (a_us * 1e-6) / 1e12 / peak_tf) if a_us > 0 else 0.0,
             "flops_per_forward": a_fl, "us_per_forward": a_us, "launches": len(attn_ev),
             "how": "HIP events around each K4 launch in one eager forward after the timed region (adds ~2 us of dispatch per launch)",
-            "by_shape(batch,heads,N,d)": {k: {"launches": v[0], "us": round(v[1], 1), "tflops": round(v[2] / (v[1] * 1e-6) / 1e12, 1)}
-                                          for k, v in by_shape.items()}}
+            "by_shape(batch,heads,N,d)": {k: dict(launches=v[0], **roof(v[1], v[2], v[3])) for k, v in by_shape.items()},
+            "row_attn(K13: Q|K|V, attention, proj, FFN of a 1-D attention step in one launch; flops = all six layers + QK^T + PV)":
+                {k: dict(launches=v[0], **roof(v[1], v[2], v[3])) for k, v in rows_by.items()}}
     fwd = {"flops_per_pair_executed": fwd_flops, "achieved_tflops": fwd_flops / (ms_per_pair * 1e-3) / 1e12,
            "frac_of_mfma_peak": fwd_flops / (ms_per_pair * 1e-3) / 1e12 / peak_tf,
            "flops_by_family": {k: v[0] / B for k, v in meter.items()}, "launches_by_family": {k: v[1] for k, v in meter.items()},
@@ -238,7 +254,7 @@ def secondary_config(tag, model_type, H, W, positivity, dev, use_fp16, refine_it
                         "mfma_frac": (k1_flops / (us * 1e-6) / 1e12 / peak_tf) if us > 0 else 0.0}}
     if detail:
         attn, fwd = attention_and_work(eng, left, right, use_fp16, 1, ms_pair)
-        res["roofline_attention"] = {k: attn[k] for k in ("achieved", "peak", "unit", "frac", "flops_per_forward", "us_per_forward", "launches", "by_shape(batch,heads,N,d)")}
+        res["roofline_attention"] = {k: attn[k] for k in attn if k not in ("kernel", "bound", "how")}
         res["forward"] = {k: fwd[k] for k in ("flops_per_pair_executed", "achieved_tflops", "frac_of_mfma_peak")}
     res["peak_mem_gib"] = round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)
     eng.k1_events = None

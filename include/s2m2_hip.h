@@ -36,7 +36,7 @@ enum { S2M2_F32 = 0, S2M2_F16 = 1 };
  * rebuilt; 400 = round 4 (s2m2_pw_direct, s2m2_conv_narrow, s2m2_ln_corr_pitched added; the round-3 experiment entry
  * points s2m2_corr_tiled / s2m2_corr_hybrid / s2m2_debug_store_pattern and the ln_out_tile* fields of s2m2_chain_desc removed;
  * head_* appended to s2m2_narrow_desc without a bump -- the reason for the exact comparison since 500); 500 = round 5; 600 = round 6
- * (s2m2_row_attn added; the five ABI-400 entry points of K1 -- s2m2_ln_corr, _timed, _banded, _pitched, s2m2_corr -- removed: every form of
+ * (s2m2_row_attn and s2m2_conv_block added; the five ABI-400 entry points of K1 -- s2m2_ln_corr, _timed, _banded, _pitched, s2m2_corr -- removed: every form of
  * K1 is s2m2_cost_volume). */
 #define S2M2_ABI_VERSION 600
 int s2m2_version(void);
@@ -368,6 +368,39 @@ typedef struct s2m2_rowattn_desc {
 } s2m2_rowattn_desc;
 int s2m2_row_attn_supported(int C, int heads, int w, int dtype);
 int s2m2_row_attn(const s2m2_rowattn_desc* desc, void* stream);
+
+/*
+ * K14 -- a whole ConvBlock2D (attentions.py:255-281) in ONE launch, for the coarse pyramid levels (ABI 600):
+ *     out = convs.2( GELU( convs.0(x) ) ) + convs_1x.2( ReLU( convs_1x.0(x) ) )          convs.* 3x3 (padding 1), convs_1x.* 1x1, all C -> C
+ *   Replaces the launch triple s2m2_mlp_chain (1x1 branch) / s2m2_conv2d (korder 2) / s2m2_conv2d (korder 2, EPI_ADD) with the same arithmetic
+ *   in the same order (bit-identical): a block owns a patch of output pixels and all C channels, recomputes the one-pixel ring of the first
+ *   3x3 layer and keeps the GELU tensor in LDS.  Meant for grids whose launches are latency chains (1/8 ... 1/32 resolution).
+ *     x, out     (N, H, W, C) fp16, channels contiguous, pixel strides in elements (x: multiple of 8, out: multiple of 4); out != x
+ *     w_conv0/2  the 3x3 layers as s2m2_conv_desc.weight with korder = 2 (s2m2_pack_frag S2M2_PACK_CONV_FRAG, 128-channel chunks)
+ *     w_1x0/2    the 1x1 layers as s2m2_chain_desc.weight with weight_frag = 1 (S2M2_PACK_ROWS)
+ *     b_*        fp32 (C) or NULL
+ *     patch_rows 0 = the library's choice; 2 / 4 force the patch height (C = 128; C = 256 runs 2-row patches)
+ *   fp16, C = 128 / 256: ask s2m2_conv_block_supported.
+ */
+typedef struct s2m2_convblock_desc {
+    const void* x;
+    long long x_stride;
+    void* out;
+    long long out_stride;
+    int N, H, W, C;
+    const void* w_conv0;
+    const void* w_conv2;
+    const void* w_1x0;
+    const void* w_1x2;
+    const float* b_conv0;
+    const float* b_conv2;
+    const float* b_1x0;
+    const float* b_1x2;
+    int patch_rows;
+    int dtype;
+} s2m2_convblock_desc;
+int s2m2_conv_block_supported(int C, int H, int W, int dtype);
+int s2m2_conv_block(const s2m2_convblock_desc* desc, void* stream);
 
 /*
  * K11 -- a 1x1 layer with any channel counts in the direct style (fp16; round 4): Conv2d(kernel 1) / Linear / ConvTranspose2d(2, stride 2) on

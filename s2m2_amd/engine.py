@@ -119,6 +119,13 @@ class Engine:
         # S2M2_COARSE_FUSE=0 (A/B): the 1/32 level's down_conv and the first block's Q | K | V, and the last block's chain and the decoder's
         # up_conv, as separate launches (as up to round 5) instead of stages of one K9 launch each (profiles/r06/ab_coarse_fuse.txt)
         self.coarse_fuse = os.environ.get("S2M2_COARSE_FUSE", "1") != "0"
+        # S2M2_CONVBLOCK=0 (A/B): every ConvBlock2D as three launches (K9 chain, K5 v5, K5 v5 + residual) instead of ONE K14 launch on the coarse
+        # grids (at most S2M2_CONVBLOCK_MAXPIX pixels per launch; fp16, C = 128 / 256; profiles/r06/ab_convblock.txt)
+        self.use_convblock = os.environ.get("S2M2_CONVBLOCK", "1") != "0"
+        self.convblock_maxpix = int(os.environ.get("S2M2_CONVBLOCK_MAXPIX", "40000"))
+        # (C = 256 -- the 1/16 level -- stays on the three launches: a block must produce all 256 intermediate channels, 96 blocks of 8 waves carry
+        # the whole layer pair and the launch is MFMA-bound on a third of the chip: 50 vs 37 us, profiles/r06/convblock_bench.txt; S2M2_CONVBLOCK_C256=1)
+        self.convblock_c256 = os.environ.get("S2M2_CONVBLOCK_C256", "0") == "1"
         # S2M2_GRU_FRAG=1 (A/B): ConvGRU's candidate layer (two-operand blend epilogue) on K5 v5's 64-pixel blocks instead of the v3 halo tiles
         self.gru_frag = os.environ.get("S2M2_GRU_FRAG", "0") == "1"
         self._tokens_normed: Optional[Tensor] = None             # DispInit's LayerNorm of feature_tr_4x, written by the last K9 launch
@@ -265,6 +272,14 @@ class Engine:
         c0, c2 = self.std(p + ".convs_1x.0"), self.std(p + ".convs_1x.2")
         c = z.shape[-1]
         same = c0[4] == c and c2[4] == c
+        if (self.use_convblock and same and z.dim() == 4 and z.shape[0] * z.shape[1] * z.shape[2] <= self.convblock_maxpix
+                and (c == 128 or self.convblock_c256) and self.chain_frag_ok(c) and self.convblock_ok(c, z.shape[1], z.shape[2])):
+            k0, k2 = self.std(p + ".convs.0"), self.std(p + ".convs.2")
+            if (getattr(k0, "korder", 0) == 2 and getattr(k2, "korder", 0) == 2 and k0[2] == 3 and k0[3] == 3 and k2[2] == 3 and k2[3] == 3
+                    and k0[4] == c and k2[4] == c and k0[0].numel() == 9 * c * c and k2[0].numel() == 9 * c * c
+                    and tuple(c0[0].shape) == (c, c) and tuple(c2[0].shape) == (c, c)):
+                # the whole block -- 1x1 branch, 3x3 - GELU - 3x3, the final add -- as ONE K14 launch (the coarse grids: latency chains)
+                return hip.conv_block(z, k0[0], k0[1], k2[0], k2[1], self.wfrag(c0), c0[1], self.wfrag(c2), c2[1])
         if same and self.chain_frag_ok(c):                         # the 1x1 branch as one K9 launch (direct form)
             b = hip.mlp_chain(z, [(self.wfrag(c0), c0[1], hip.ACT_RELU, None), (self.wfrag(c2), c2[1], hip.ACT_NONE, None)], frag=True)
         elif same and self.chain_ok(c):
@@ -492,6 +507,14 @@ class Engine:
     def first_attn(self, p: str) -> str:
         """prefix of the attention module a block applies first (cross attention where the block has one)"""
         return p + (".cross_attn.attn" if (p + ".cross_attn.attn.q.weight") in self.p else ".self_attn.attn")
+
+    def convblock_ok(self, c: int, h: int, w: int) -> bool:
+        """K14 takes a ConvBlock2D of this width on this grid (asked once per shape)"""
+        key = ("convblock", c, h, w)
+        ok = self._chain_ok.get(key)
+        if ok is None:
+            ok = self._chain_ok[key] = hip.conv_block_supported(c, h, w, self.dtype)
+        return ok
 
     def row_ok(self, z: Tensor, nh: int) -> bool:
         """K13 takes the 1-D attention steps on this tensor (asked once per shape)"""

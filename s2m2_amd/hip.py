@@ -52,6 +52,13 @@ class RowAttnDesc(ctypes.Structure):
                 ("ln_out", _vp), ("ln_out_stride", _ll), ("ln_out_eps", ctypes.c_float), ("xcd_hint", _i), ("dtype", _i)]
 
 
+class ConvBlockDesc(ctypes.Structure):
+    """mirror of s2m2_convblock_desc (include/s2m2_hip.h): K14, a whole ConvBlock2D per launch"""
+    _fields_ = [("x", _vp), ("x_stride", _ll), ("out", _vp), ("out_stride", _ll), ("N", _i), ("H", _i), ("W", _i), ("C", _i),
+                ("w_conv0", _vp), ("w_conv2", _vp), ("w_1x0", _vp), ("w_1x2", _vp), ("b_conv0", _vp), ("b_conv2", _vp), ("b_1x0", _vp),
+                ("b_1x2", _vp), ("patch_rows", _i), ("dtype", _i)]
+
+
 class PwDesc(ctypes.Structure):
     """mirror of s2m2_pw_desc (include/s2m2_hip.h)"""
     _fields_ = [("src", _vp * 4), ("src_c", _i * 4), ("src_stride", _ll * 4), ("nsrc", _i), ("rows", _ll), ("weight_frag", _vp), ("bias", _vp),
@@ -113,6 +120,8 @@ SIGNATURES = {
     "s2m2_mlp_chain_frag_supported": (_i, [_i, _i]),
     "s2m2_mlp_fan_supported": (_i, [_i, _i, _i]),
     "s2m2_mlp_chain": (_i, [ctypes.POINTER(ChainDesc), _vp]),
+    "s2m2_conv_block_supported": (_i, [_i, _i, _i, _i]),
+    "s2m2_conv_block": (_i, [ctypes.POINTER(ConvBlockDesc), _vp]),
     "s2m2_row_attn_supported": (_i, [_i, _i, _i, _i]),
     "s2m2_row_attn": (_i, [ctypes.POINTER(RowAttnDesc), _vp]),
     "s2m2_feature_fusion_supported": (_i, [_i, _i]),
@@ -164,6 +173,7 @@ def load() -> ctypes.CDLL:
 # counts, 2 flops per MAC); ATTN_EVENTS: list collecting (start event, end event, flops, shape tag) around every K4 launch.
 METER: Optional[dict] = None
 ATTN_EVENTS: Optional[list] = None
+ROW_EVENTS: Optional[list] = None     # like ATTN_EVENTS around every K13 launch: (start, end, flops, unique HBM bytes, shape tag)
 
 
 def _meter(family: str, flops: float) -> None:
@@ -622,6 +632,39 @@ def mlp_chain(x: torch.Tensor, stages, res: Optional[torch.Tensor] = None, res_s
     return res_t[0] if len(res_t) == 1 else res_t
 
 
+def conv_block_supported(C: int, H: int, W: int, dtype: torch.dtype) -> bool:
+    """K14 (conv_block) takes a ConvBlock2D of this width on an H x W grid (fp16, C = 128 / 256, coarse grids)"""
+    return bool(load().s2m2_conv_block_supported(C, H, W, _DT[dtype]))
+
+
+def conv_block(x: torch.Tensor, w_conv0: torch.Tensor, b_conv0, w_conv2: torch.Tensor, b_conv2, w_1x0: torch.Tensor, b_1x0, w_1x2: torch.Tensor, b_1x2,
+               patch_rows: int = 0) -> torch.Tensor:
+    """K14: ConvBlock2D (attentions.py:255-281) on x (N,H,W,C) in one launch: convs.2(GELU(convs.0(x))) + convs_1x.2(ReLU(convs_1x.0(x))).
+    w_conv0 / w_conv2: the 3x3 layers as K5 v5 fragment streams (pack.pack_conv_frag), w_1x0 / w_1x2: the 1x1 layers in K9's fragment order
+    (pack.chain_frag); biases fp32 (C) or None."""
+    if x.dim() != 4 or x.dtype != torch.float16 or not x.is_cuda or x.stride(3) != 1:
+        raise ValueError("conv_block: x must be an (N,H,W,C) fp16 device tensor with contiguous channels")
+    N, H, W, C = x.shape
+    xs = x.stride(2)
+    if x.stride(1) != W * xs or (N > 1 and x.stride(0) != H * W * xs):
+        raise ValueError("conv_block: the pixels of x must be evenly strided")
+    d = ConvBlockDesc()
+    out = torch.empty((N, H, W, C), device=x.device, dtype=x.dtype)
+    d.x, d.x_stride, d.out, d.out_stride, d.N, d.H, d.W, d.C = x.data_ptr(), xs, out.data_ptr(), C, N, H, W, C
+    for name, w, n in (("w_conv0", w_conv0, 9 * C * C), ("w_conv2", w_conv2, 9 * C * C), ("w_1x0", w_1x0, C * C), ("w_1x2", w_1x2, C * C)):
+        if w.dtype != x.dtype or w.numel() != n or not w.is_contiguous() or not w.is_cuda:
+            raise ValueError(f"conv_block: {name} must be a contiguous fp16 device tensor of {n} elements")
+        setattr(d, name, w.data_ptr())
+    for name, b in (("b_conv0", b_conv0), ("b_conv2", b_conv2), ("b_1x0", b_1x0), ("b_1x2", b_1x2)):
+        if b is not None and (b.dtype != torch.float32 or b.numel() != C or not b.is_contiguous() or not b.is_cuda):
+            raise ValueError(f"conv_block: {name} must be fp32 ({C}) on the device or None")
+        setattr(d, name, b.data_ptr() if b is not None else None)
+    d.patch_rows, d.dtype = patch_rows, _DT[x.dtype]
+    _check(load().s2m2_conv_block(ctypes.byref(d), _stream()), "s2m2_conv_block")
+    _meter("conv_block", 2.0 * N * H * W * C * C * 20)
+    return out
+
+
 def row_attn_supported(C: int, heads: int, w: int, dtype: torch.dtype) -> bool:
     """K13 (row_attn) exists for rows of w tokens x C channels with this many heads (fp16, C = 128, 1 or 2 heads, w <= 320)"""
     return bool(load().s2m2_row_attn_supported(C, heads, w, _DT[dtype]))
@@ -654,9 +697,18 @@ def row_attn(x: torch.Tensor, heads: int, cross: bool, weights: torch.Tensor, ve
     if ln_out_eps is not None:
         normed = torch.empty((nimg, h, w, C), device=x.device, dtype=x.dtype)
         d.ln_out, d.ln_out_stride, d.ln_out_eps = normed.data_ptr(), C, float(ln_out_eps)
+    ev = None
+    if ROW_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _check(load().s2m2_row_attn(ctypes.byref(d), _stream()), "s2m2_row_attn")
     rows = nimg * h * w
-    _meter("row_attn", 2.0 * rows * C * C * 6 + 4.0 * nimg * h * w * w * C)
+    flops = 2.0 * rows * C * C * 6 + 4.0 * nimg * h * w * w * C
+    if ev is not None:
+        ev[1].record()
+        ROW_EVENTS.append((ev[0], ev[1], flops, 2.0 * rows * C * (3 if normed is not None else 2),      # unique bytes: rows read once, written once (+ ln_out)
+                           f"({nimg},{h},{w},{C}) heads {heads} {'cross' if cross else 'self'}"))
+    _meter("row_attn", flops)
     return out if normed is None else (out, normed)
 
 
@@ -883,7 +935,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, swa
            "s2m2_attention")
     if ev is not None:
         ev[1].record()
-        ATTN_EVENTS.append((ev[0], ev[1], flops, f"({nb},{heads},{Nq},{D}){'+pe' if pe is not None else ''}"))
+        ATTN_EVENTS.append((ev[0], ev[1], flops, f"({nb},{heads},{Nq},{D}){'+pe' if pe is not None else ''}",
+                            2.0 * nb * heads * D * (2 * Nq + 2 * Nk)))       # unique bytes: q, k, v read + o written (fp16)
     _meter("attention", flops)
     return (out, pe_out) if pe is not None else out
 

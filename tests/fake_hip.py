@@ -156,6 +156,9 @@ def make():
     def feature_fusion_supported(C, dtype):
         return C in (128, 256)
 
+    def conv_block_supported(C, H, W, dtype):
+        return False                                     # (fp16 only; the engine needs the K5 v5 / K9 fragment packings for it)
+
     def row_attn_supported(C, heads, w, dtype):
         return C == 128 and heads in (1, 2) and 8 <= w <= 320       # (the kernel is fp16 only; the stand-in wires any dtype)
 
@@ -259,6 +262,6 @@ def make():
     def tanh(x):
         return torch.tanh(x)
 
-    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, pw_direct_supported, conv_narrow_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported, row_attn, row_attn_supported):
+    for f in (image_prep, refine_prep, global_update, refine_update, tanh, ln_corr, sinkhorn_regress, cv_lookup_into, conv2d, layernorm, groupnorm_nhwc, resample2x, attention, convex_upsample, mlp_chain, mlp_chain_supported, mlp_chain_ln_out_supported, mlp_chain_frag_supported, feature_fusion_frag_supported, pw_direct_supported, conv_narrow_supported, mlp_fan_supported, corr, cv_alloc, stem_mlp, feature_fusion, feature_fusion_supported, row_attn, row_attn_supported, conv_block_supported):
         setattr(ns, f.__name__, f)
     return ns
