@@ -148,6 +148,41 @@ def cpu_baseline(model_type, H, W, refine_iter):
                       f"1 warm-up, 1 run per thread count, median of 3 at the best count"}
 
 
+def gpu_state(local_rank=0):
+    """Best-effort snapshot of the board's power cap / average power / clocks (an extra of the line: a power-capped or down-clocked box of
+    the pool then shows in the record next to its ms/pair).  amdgpu hwmon files (no privileges needed); rocm-smi --json as a second source."""
+    import glob
+    import json as _json
+    import subprocess
+    out = {}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        if cards:
+            hw = cards[min(local_rank, len(cards) - 1)]
+
+            def rd(name):
+                try:
+                    return int(open(os.path.join(hw, name)).read().strip())
+                except (OSError, ValueError):
+                    return None
+            for key, name, scale in (("power_cap_w", "power1_cap", 1e-6), ("power_avg_w", "power1_average", 1e-6), ("power_input_w", "power1_input", 1e-6),
+                                     ("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6), ("temp_c", "temp1_input", 1e-3)):
+                v = rd(name)
+                if v is not None:
+                    out[key] = round(v * scale, 1)
+    except Exception as e:  # noqa: BLE001
+        out["hwmon_error"] = str(e)[:100]
+    try:
+        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--showperflevel", "--json"], capture_output=True, text=True, timeout=20)
+        if r.returncode == 0 and r.stdout.strip().startswith("{"):
+            js = _json.loads(r.stdout)
+            card = js.get(f"card{local_rank}") or next(iter(js.values()))
+            out["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("power", "sclk", "mclk", "performance"))}
+    except Exception as e:  # noqa: BLE001
+        out["rocm_smi_error"] = str(e)[:100]
+    return out
+
+
 def k1_algorithmic(h, w, C, e, B=1):
     """read both feature maps once + write the volume once (bytes), 2*h*w*w*C flops"""
     return B * (2 * h * w * C * e + h * w * w * e), 2.0 * B * h * w * w * C
@@ -533,6 +568,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     eng.k1_events.clear()                             # keep only the launches of the timed region
+    state_before = gpu_state(local_rank) if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
@@ -542,6 +578,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    state_after = gpu_state(local_rank) if rank == 0 else None
     k1_ms = [t.elapsed_us() * 1e-3 for t in eng.k1_events]
     own_elapsed = elapsed
     per_rank_ms = [1e3 * elapsed / a.steps]
@@ -623,6 +660,9 @@ def main():
             "forward": fwd_block,
         }
         line["per_rank_ms_per_step"] = [round(x, 4) for x in per_rank_ms]
+        line["gpu_state"] = {"before_timed_region": state_before, "after_timed_region": state_after,
+                             "note": "board power cap / average power / clocks read by rank 0 outside the timed region (hwmon, rocm-smi); boxes of "
+                                     "the pool differ by 2 - 5 % end to end on the same build"}
         if not a.no_secondary and (a.height, a.width) != (480, 640):
             line["secondary"] = secondary_640x480(model, eng, dev, use_fp16, a.refine_iter, a.model)
             if B == 1:
