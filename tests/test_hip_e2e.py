@@ -148,7 +148,7 @@ def test_native_refine_step_is_bit_identical_and_rebinds_its_inputs(monkeypatch)
                 assert torch.equal(a, b), f"forward {k}"
     eng = next(iter(nat_m._engines.values()))
     plans = [v for k_, v in {**eng._bufs, **eng._plans}.items() if isinstance(k_, tuple) and k_[0] == "refine_plan" and isinstance(v, tuple)]
-    assert len(plans) == 3 and all(p[0].launches > 40 for p in plans), [p[0].launches for p in plans]
+    assert len(plans) == 3 and all(p[0].launches > 30 for p in plans), [p[0].launches for p in plans]
     monkeypatch.setenv("S2M2_GRAPH", "1")                          # graph path: two warm-ups, capture, replays
     g_m = build()
     with torch.autocast("cuda", dtype=torch.float16):
