@@ -41,17 +41,6 @@ def _layers(C, seed, with_bias=True, ln_affine=None):
     return qkv, bqkv, rest, b0, b2, weights, vectors
 
 
-def test_row_attn_packing_is_an_involution():
-    w = torch.arange(4 * 32, dtype=torch.float32).reshape(4, 32)
-    p = pack.rowattn_cols(w)
-    assert p[0, :16].tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15] and torch.equal(pack.rowattn_cols(p), w)
-    w2 = torch.randn(256, 128)
-    pk = pack.rowattn_pack(w2)
-    assert torch.equal(pack.rowattn_unpack(pk), w2)
-    # unit u of row r of the second layer at element (u * 128 + r) * 8 of its block
-    assert torch.equal(pk[128:].reshape(-1)[(3 * 128 + 5) * 8:(3 * 128 + 5) * 8 + 8], pack.rowattn_cols(w2)[128 + 5, 24:32])
-
-
 def _tokens(nimg, h, w, C, seed):
     g = torch.Generator(device="cuda").manual_seed(seed)
     base = torch.randn(nimg, h, w, C, device="cuda", generator=g)

@@ -181,3 +181,41 @@ def test_head_frag_matches_the_accumulator_layout_of_a_32x32_mfma():
                     ch = 32 * j + 8 * (2 * p + q) + 4 * half + e              # what lane (pixel, half) holds in quad 2p + q, element e
                     d2 += hf[0, 2 * j + p, 32 * half:32 * half + 32, e8][:, None] * y[:, ch][None, :]
     assert float((d2[:cout2] - w2 @ y[:, :k].T).abs().max()) < 1e-5 and float(d2[cout2:].abs().max()) == 0
+
+
+def test_row_attn_packing_is_an_involution():
+    from s2m2_amd import pack
+    w = torch.arange(4 * 32, dtype=torch.float32).reshape(4, 32)
+    p = pack.rowattn_cols(w)
+    assert p[0, :16].tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15] and torch.equal(pack.rowattn_cols(p), w)
+    w2 = torch.randn(256, 128)
+    pk = pack.rowattn_pack(w2)
+    assert torch.equal(pack.rowattn_unpack(pk), w2)
+    # unit u of row r of the second layer at element (u * 128 + r) * 8 of its block
+    assert torch.equal(pk[128:].reshape(-1)[(3 * 128 + 5) * 8:(3 * 128 + 5) * 8 + 8], pack.rowattn_cols(w2)[128 + 5, 24:32])
+
+
+
+
+def test_row_attn_vectors_and_reference_on_cpu():
+    """pack.rowattn_vectors' order is what the CPU restatement of s2m2_row_attn (tests/fake_hip.py) and the kernel read; the restatement itself
+    against a direct evaluation of the step with the plain weights (fp32, no rounding)."""
+    import torch.nn.functional as F
+    from fake_hip import row_attn_reference
+    from s2m2_amd import pack
+    g = torch.Generator().manual_seed(0)
+    C = 128
+    ws = [torch.randn(C, C, generator=g) / C ** 0.5 for _ in range(6)]
+    bv, b0, b2 = (torch.randn(C, generator=g) * 0.3 for _ in range(3))
+    vec = pack.rowattn_vectors((ws[0].sum(1), ws[1].sum(1), ws[2].sum(1), ws[4].sum(1)), (None, None, bv, None, b0, b2))
+    assert tuple(vec.shape) == (12, C) and torch.equal(vec[4], bv) and torch.equal(vec[5], ws[2].sum(1)) and torch.equal(vec[8], ws[4].sum(1))
+    x = torch.randn(2, 3, 20, C, generator=g)
+    out = row_attn_reference(x, 2, True, pack.rowattn_pack(torch.cat(ws, 0)), vec)
+    ln = lambda t: F.layer_norm(t, (C,))                                   # noqa: E731
+    src = x.roll(1, 0)
+    q, k, v = F.linear(ln(x), ws[0]), F.linear(ln(src), ws[1]), F.linear(ln(src), ws[2], bv)
+    sp = lambda t: t.reshape(6, 20, 2, 64).transpose(1, 2)                 # noqa: E731
+    o = (torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / 8.0, -1) @ sp(v)).transpose(1, 2).reshape(2, 3, 20, C)
+    z1 = x + F.linear(o, ws[3])
+    ref = z1 + F.linear(F.gelu(F.linear(ln(z1), ws[4], b0)), ws[5], b2)
+    assert float((out - ref).abs().max()) < 1e-4
