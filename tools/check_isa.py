@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Build-time guard of the scheduling assumptions behind K5 v5 (conv_frag_kernel, s2m2_amd/csrc/conv.hip), the direct form of K10
+"""Build-time guard of the scheduling assumptions behind K5 v5 (conv_frag_kernel, s2m2_amd/csrc/conv.hip), K14 (conv_block_kernel, convblock.hip: the
+same ring, check_ring_kernel), the direct form of K10
 (feature_fusion_direct_kernel, s2m2_amd/csrc/fusion.hip) and the shipped K1 (ln_corr_kernel<PRENORM>, s2m2_amd/csrc/ln_corr.hip: s2m2_corr).
 
 The kernel prefetches its weight fragments with loads the compiler does NOT track (common.h: global_load16_async) and waits for them with
@@ -211,6 +212,59 @@ def check_ln_corr(text):
     return bad
 
 
+def _asm_marked(lines):
+    """-> [(instruction text, is inside an ;;#ASMSTART / ;;#ASMEND pair, is a label)] of a function body"""
+    out, in_asm = [], False
+    for raw in lines:
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if re.match(r"^\.LBB\S*:", raw):
+            out.append(("", False, True))
+            continue
+        l = raw.split(";")[0].strip()
+        if l and not l.startswith((".", ";")):
+            out.append((l, in_asm, False))
+    return out
+
+
+def check_ring_kernel(name: str, lines):
+    """K14 (conv_block_kernel): the untracked ring of K5 v5 inside a kernel that also issues tracked 16-byte loads, so the ring is told apart by
+    the inline-asm markers.  Checked: ring starts = asm requests followed by straight-line code -- until the next wait, MFMA, branch or label nothing
+    writes or reads a register whose request is in flight (the allocator reuses the destination of a request whose value the program never consumes: the
+    round-6 memory fault of this kernel)."""
+    ins = _asm_marked(lines)
+    problems, nloops, starts = [], 0, 0
+    # (2) ring starts
+    flying = set()
+    for l, a, lab in ins:
+        if lab or l.startswith("v_mfma") or re.search(r"s_waitcnt\b.*vmcnt\(", l) or l.startswith(("s_cbranch", "s_branch", "s_barrier")):
+            flying.clear()
+            continue
+        ops = [t.strip().rstrip(",") for t in l.split()[1:]]
+        if a and l.startswith("global_load_dwordx4"):
+            if not flying:
+                starts += 1
+            flying |= regs_of(ops[0])
+            continue
+        if not flying or not ops:
+            continue
+        if l.startswith(("ds_write", "global_store", "scratch_store")):
+            if any(regs_of(t) & flying for t in ops):
+                problems.append(f"{name}: '{l}' reads a ring register whose request is in flight")
+        elif regs_of(ops[0]) & flying:
+            problems.append(f"{name}: '{l}' overwrites a ring register whose request is in flight")
+        elif any(regs_of(t) & flying for t in ops[1:]):
+            problems.append(f"{name}: '{l}' reads a ring register whose request is in flight")
+    if starts < 2:
+        problems.append(f"{name}: fewer than two ring starts found (the check no longer matches the generated code)")
+    return problems, nloops, starts
+
+
 def compile_asm(src: str, asm: str):
     defines = os.environ.get("S2M2_BUILD_DEFINES", "").split()
     r = subprocess.run([HIPCC, *FLAGS, *defines, src, "-o", asm], capture_output=True, text=True)
@@ -243,9 +297,19 @@ def main() -> int:
         ftext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "fusion.hip"), os.path.join(td, "fusion.s"))
         ktext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "ln_corr.hip"), os.path.join(td, "ln_corr.s"))
         ntext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "conv_narrow.hip"), os.path.join(td, "conv_narrow.s"))
-        if text is None or ftext is None or ktext is None or ntext is None:
+        btext = compile_asm(os.path.join(ROOT, "s2m2_amd", "csrc", "convblock.hip"), os.path.join(td, "convblock.s"))
+        if text is None or ftext is None or ktext is None or ntext is None or btext is None:
             return 2
     bad = check_ln_corr(ktext)
+    bfuncs = functions(btext, "_ZN4s2m217conv_block_kernel")
+    if not bfuncs:
+        print("check_isa: no conv_block_kernel instantiation found in the assembly")
+        return 1
+    for name, lines in bfuncs.items():
+        p1, nloops, starts = check_ring_kernel(name, lines)
+        m = re.search(r"CbCfgILi(\d+)ELi(\d+)E", name)
+        print(f"check_isa: conv_block_kernel<C {m.group(1)}, PH {m.group(2)}>: {starts} ring (re)start window(s), {len(p1)} problem(s) (its K loops are held bit for bit against K5 v5 by tests/test_hip_convblock.py)")
+        bad += p1
     nfuncs = functions(ntext, "_ZN4s2m218conv_narrow_kernel")
     if not nfuncs:
         print("check_isa: no conv_narrow_kernel instantiation found in the assembly")
