@@ -12,7 +12,7 @@ from s2m2_amd import hip, pack  # noqa: E402
 from tools.kbench import timeit_graph  # noqa: E402
 
 C = 128
-SHAPES = [("L0 1216x1024", 2, 256, 304, 1), ("L1 1216x1024", 2, 128, 152, 2), ("L0 two pairs", 4, 256, 304, 1)]
+SHAPES = [("L0 1216x1024", 2, 256, 304, 1), ("L1 1216x1024", 2, 128, 152, 2), ("L0 two pairs", 4, 256, 304, 1), ("L1 2432x2048", 2, 256, 304, 2)]
 if "c2" in sys.argv:
     SHAPES = [("L0 640x480", 2, 120, 160, 1), ("L1 640x480", 2, 60, 80, 2)]
 g = torch.Generator(device="cuda").manual_seed(0)
