@@ -404,6 +404,36 @@ def secondary_batched(model, dev, use_fp16, a, pairs=2, steps=10, warmup=3):
             "value": steps * pairs / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / (steps * pairs), "steps": steps, "warmup": warmup}
 
 
+def secondary_two_streams(model, dev, use_fp16, a, steps=20, warmup=3):
+    """Information only (not `value`): the SAME workload -- one pair per forward -- with two forwards in flight, consecutive pairs enqueued
+    alternately on two HIP streams (the module's calling contract: any stream, one captured graph and scratch set per stream).  The small
+    launches of one forward fill the CUs the other leaves idle at the coarse pyramid levels: what a serving loop with more than one
+    request queued gets without batching; the latency of a pair roughly doubles, the throughput is what is reported."""
+    import torch
+    from s2m2_amd.weights import noise_pair
+    pairs = [tuple(t.to(dev) for t in noise_pair(a.height, a.width, 1, seed=21 + k)) for k in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    cur = torch.cuda.current_stream(dev)
+    for s in streams:
+        s.wait_stream(cur)
+
+    def step(i):
+        with torch.cuda.stream(streams[i & 1]), torch.autocast("cuda", dtype=torch.float16, enabled=use_fp16):
+            return model(*pairs[i & 1])
+
+    for i in range(2 * max(warmup, 3)):                   # every stream: eager call, capture, replays
+        step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    finite = bool(all(torch.isfinite(o).all() for o in out))
+    return {"workload": f"{a.model}-model {a.width}x{a.height} refine_iter={a.refine_iter}, 1 pair per forward, TWO forwards in flight (two HIP streams), n_gpus=1 (rank 0)",
+            "value": steps / dt, "unit": "pairs/s", "ms_per_pair_throughput": 1e3 * dt / steps, "steps": steps, "outputs_finite": finite}
+
+
 def k1_source_hash():
     """sha256 over the sources K1 is compiled from -- what a PMC summary is valid for (tools/pmc_summary.py stores it)"""
     import hashlib
@@ -667,6 +697,11 @@ def main():
             line["secondary"] = secondary_640x480(model, eng, dev, use_fp16, a.refine_iter, a.model)
             if B == 1:
                 line["secondary_batched"] = secondary_batched(model, dev, use_fp16, a, pairs=2)
+                if world == 1:
+                    try:
+                        line["secondary_two_streams"] = secondary_two_streams(model, dev, use_fp16, a)
+                    except Exception as e:  # noqa: BLE001  (an extra, never the line)
+                        line["secondary_two_streams"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
         if devices is not None:
             line["rccl_ranks"], line["distinct_gpus"], line["gpu_uuids"] = world, len(set(devices)), devices
         if not a.no_secondary and world == 1 and (a.model, a.height, a.width, B) == ("S", 1024, 1216, 1) and use_fp16:
