@@ -383,7 +383,8 @@ def secondary_640x480(model, eng, dev, use_fp16, refine_iter, model_type, steps=
 def secondary_batched(model, dev, use_fp16, a, pairs=2, steps=10, warmup=3):
     """Information only (not `value`, whose workload is ONE pair per GPU per step as BASELINE's configs[2] shards them): the same model and
     size with `pairs` pairs per launch sequence on rank 0's GPU -- what batching buys when a caller has more than one pair per GPU
-    (every grid doubles: fewer partially filled rounds of blocks, twice the rows per launch on the coarse pyramid levels)."""
+    (r06: the module runs a batch as two chunks of ceil(B / 2) pairs on two side streams, model.py: _forward_pairs -- the CUs one chunk leaves
+    idle at the coarse pyramid levels run the other chunk's launches; S2M2_PAIR_STREAMS=0 is the single batched launch sequence of r05)."""
     import torch
     from s2m2_amd.weights import noise_pair
     left, right = (t.to(dev) for t in noise_pair(a.height, a.width, pairs, seed=11))
@@ -401,7 +402,8 @@ def secondary_batched(model, dev, use_fp16, a, pairs=2, steps=10, warmup=3):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"workload": f"{a.model}-model {a.width}x{a.height} refine_iter={a.refine_iter}, {pairs} pairs per step, n_gpus=1 (rank 0)",
-            "value": steps * pairs / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / (steps * pairs), "steps": steps, "warmup": warmup}
+            "value": steps * pairs / dt, "unit": "pairs/s", "ms_per_pair": 1e3 * dt / (steps * pairs), "steps": steps, "warmup": warmup,
+            "pair_streams": int(os.environ.get("S2M2_PAIR_STREAMS", "2"))}
 
 
 def secondary_two_streams(model, dev, use_fp16, a, steps=20, warmup=3):

@@ -51,19 +51,21 @@ class S2M2(nn.Module):
         self._engines: Dict[Tuple, "object"] = {}
         self._graphs: "OrderedDict[Tuple, object]" = OrderedDict()      # LRU of captured hipGraphs, see forward()
         self._seen = set()
+        self._side_streams: Dict[object, list] = {}                     # per device: the side streams of _forward_pairs
         self._epoch = 0                                                 # bumped by invalidate()
         self._lock = threading.RLock()                                  # host-side enqueue of one forward at a time per module
 
     # caches and the lock are process state, not model state: copy.deepcopy / pickling (torch.save(model)) drop them
     def __getstate__(self):
         st = self.__dict__.copy()
-        for k in ("_engines", "_graphs", "_seen", "_lock"):
+        for k in ("_engines", "_graphs", "_seen", "_lock", "_side_streams"):
             st.pop(k, None)
         return st
 
     def __setstate__(self, st):
         self.__dict__.update(st)
         self._engines, self._graphs, self._seen, self._lock = {}, OrderedDict(), set(), threading.RLock()
+        self._side_streams = {}
 
     # -- weights -------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -126,7 +128,7 @@ class S2M2(nn.Module):
 
     @torch.compiler.disable
     @torch.no_grad()
-    def _forward_impl(self, img0: torch.Tensor, img1: torch.Tensor, capture: Optional[dict] = None):
+    def _forward_impl(self, img0: torch.Tensor, img1: torch.Tensor, capture: Optional[dict] = None, _nosplit: bool = False):
         if not img0.is_cuda:
             raise RuntimeError("s2m2_amd.S2M2 runs on MI355X only: move the model and the images to a CUDA(HIP) device "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
@@ -145,6 +147,8 @@ class S2M2(nn.Module):
         with self._lock, torch.cuda.device(img0.device):         # the planner queries the images' device
             check_limits(img0.shape[2], img0.shape[3], self.feature_channels, img0.shape[0], dtype,
                          use_pe="feat_pyramid.enc3s.0.self_attn.attn.pe_proj.weight" in self._table)
+        if img0.shape[0] >= 2 and capture is None and not _nosplit and self._pair_streams() >= 2:
+            return self._forward_pairs(img0, img1)
         nb = max_batch(img0.shape[2], img0.shape[3])
         if img0.shape[0] > nb:                                   # K5 indexes pixels with 24 bits: large batches run in slices
             if capture is not None:
@@ -174,13 +178,57 @@ class S2M2(nn.Module):
                 self._graphs.move_to_end(key)
             return runner(img0, img1)
 
+    @staticmethod
+    def _pair_streams() -> int:
+        """S2M2_PAIR_STREAMS=n (default 2; 0 / 1: off): a batch of B >= 2 pairs runs as n chunks on n side streams instead of one batched launch
+        sequence.  The pairs of a batch are independent, one forward leaves most CUs idle at the coarse pyramid levels, and a
+        second forward in flight fills them (profiles/r06/ab_pair_streams.txt: 1216 x 1024 B = 2 6.87 -> 6.42 ms per pair)."""
+        try:
+            return int(os.environ.get("S2M2_PAIR_STREAMS", "2"))
+        except ValueError:
+            return 2
+
+    def _forward_pairs(self, img0: torch.Tensor, img1: torch.Tensor):
+        """The batch in n chunks, each a (batched) forward on its own side stream (one captured graph and scratch set per stream, as for any
+        caller stream): B = 2 is two single-pair forwards in flight, B = 8 two batches of four; the caller's stream waits for them before it
+        touches the results."""
+        dev = img0.device
+        n = self._pair_streams()
+        with self._lock:
+            streams = self._side_streams.get(dev)
+            if streams is None or len(streams) != n:
+                streams = self._side_streams[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        cur = torch.cuda.current_stream(dev)
+        for s in streams:
+            s.wait_stream(cur)                                     # the images were produced on the caller's stream
+        parts = []
+        B = img0.shape[0]
+        per = (B + n - 1) // n                                     # n chunks of the batch, each a batched forward on its own stream
+        for k, b0 in enumerate(range(0, B, per)):
+            with torch.cuda.stream(streams[k % n]):
+                parts.append(self._forward_impl(img0[b0:b0 + per], img1[b0:b0 + per], None, _nosplit=True))
+        for s in streams:
+            cur.wait_stream(s)
+        for p in parts:
+            for t in p:
+                t.record_stream(cur)                               # allocated on a side stream, consumed (and freed) on the caller's
+        return tuple(torch.cat([p[k] for p in parts], 0) for k in range(3))
+
     def is_warm(self, img_shape, dtype: torch.dtype = torch.float16) -> bool:
         """True when a captured graph exists for (B,3,H,W) ``img_shape`` on the current stream (next call = pure replay)."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             return False
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        return any(k[0] == tuple(img_shape) and k[1] == dtype and k[3] == stream for k in self._graphs)
+        B, n = int(img_shape[0]), self._pair_streams()
+        if B >= 2 and n >= 2:                              # the batch runs as chunks on the side streams (_forward_pairs)
+            streams = self._side_streams.get(dev)
+            if streams is None or len(streams) != n:
+                return False
+            per = (B + n - 1) // n
+            want = [((min(per, B - b0),) + tuple(img_shape[1:]), streams[k % n].cuda_stream) for k, b0 in enumerate(range(0, B, per))]
+        else:
+            want = [(tuple(img_shape), torch.cuda.current_stream(dev).cuda_stream)]
+        return all(any(k[0] == shp and k[1] == dtype and k[3] == st for k in self._graphs) for shp, st in want)
 
 
 def build_model(model_type: str, use_positivity: bool = True, refine_iter: int = 3, output_upsample: bool = False) -> S2M2:

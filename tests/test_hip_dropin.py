@@ -116,6 +116,30 @@ def test_graph_replay_batch_gt_one_and_batch_slicing(monkeypatch):
     assert float((sliced[0] - eager[0]).abs().max()) < 1e-3 and sliced[0].shape == eager[0].shape
 
 
+def test_batch_in_chunks_on_two_streams_equals_one_batched_forward(monkeypatch):
+    """S2M2_PAIR_STREAMS (model.py: _forward_pairs): a batch runs as two chunks on two side streams; per pair the results are those of the
+    batched launch sequence (pairs of a batch are independent; a chunk of one pair equals the single-pair forward bit for bit), the caller's
+    stream is ordered behind the side streams, and is_warm reports the chunk graphs."""
+    m = _direct(0)
+    for B in (2, 3, 5):
+        l, r = synthetic_pair(64, 96, B, 8, 20 + B)
+        l, r = l.cuda(), r.cuda()
+        monkeypatch.setenv("S2M2_PAIR_STREAMS", "0")
+        whole = [t.clone() for t in m(l, r)]
+        monkeypatch.setenv("S2M2_PAIR_STREAMS", "2")
+        assert not m.is_warm(l.shape, torch.float32)
+        for _ in range(3):                                     # eager, capture, replay of both chunks
+            got = m(l, r)
+            total = float(got[0].sum())                        # consumed on the caller's stream right away
+            for a, b in zip(got, whole):
+                assert a.shape == b.shape and float((a - b).abs().max()) < 1e-3
+            assert abs(total - float(whole[0].sum())) < 1e-1 * B
+        assert m.is_warm(l.shape, torch.float32)
+        if B == 2:
+            single = m(l[1:2], r[1:2])
+            assert torch.equal(single[0], got[0][1:2])
+
+
 def test_torch_compile_wrapper_is_accepted():
     m = _direct(0)
     l, r = synthetic_pair(64, 96, 1, 8, 4)
