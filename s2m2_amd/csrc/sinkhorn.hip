@@ -22,57 +22,111 @@
 // triangle, 19 on average.  The column accumulators are "lazy" log-sum-exp states: the stabiliser only moves when an element
 // exceeds it by more than 40 (checked once per 8 elements with a wave vote), otherwise an element costs a subtract, an exp and an
 // add -- the exact sum of exp(x - m) for a fixed m, just not the tightest m.
+//
+// Round 6: the kernel is VALU-issue bound (rocprofv3 counters, profiles/r06/pmc_k2_sq_lds.txt: one block of 8 waves per CU, VALU busy
+// 0.37 per wave = 0.74 per SIMD, ~15 instructions per element and pass), so the sweeps were rebuilt around the instruction count:
+//   * everything lives in the log2 domain (u, v, the marginals and the stabilisers are the natural-log quantities times log2 e):
+//     x = S * log2e + v is ONE fused multiply-add straight from the fp16 element (v_fma_mix_f32), exp2 is the bare v_exp_f32 -- the
+//     convert, the add and the multiply in front of every exp are gone.  Algebraically the same algorithm on S * (log2e rounded to
+//     fp32), i.e. on inputs perturbed by 1.4e-8 relative;
+//   * [TRI] the LDS copy of the triangle is stored MASKED (entries right of the diagonal = -inf inside the diagonal piece), holds the
+//     dustbin row (zeros) as row w, and has one all -inf piece that every read right of the diagonal / below the dustbin row is pointed
+//     at: the fused passes decode without a single compare or select, and no load sits under an exec mask;
+//   * v is padded to whole chunks: its 16-byte reads are unconditional;
+//   * the row loop is three loops with a compile-time number of live chunks (1, 2, .. NCH; under the triangle the early rows need
+//     fewer): straight-line code, no per-chunk branches;
+//   * subtract / row sum / column multiply-add work on register pairs (v_pk_add_f32, v_pk_fma_f32), the 16-lane reductions are
+//     v_max_f32_dpp / v_add_f32_dpp / v_min_i32_dpp (one instruction per butterfly step).
 #include "common.h"
 #include "plan.h"
 #include <stdlib.h>
 
 namespace s2m2 {
 
-constexpr float kLazy = 40.0f;          // exp(40) * (columns) stays far below the fp32 range
+constexpr float kLazy = 40.0f;          // 2^40 * (columns) stays far below the fp32 range
 constexpr float kNegBig = -1.0e30f;     // "no element yet" stabiliser (finite: -inf - -inf would be NaN)
+constexpr float kL2E = 1.44269504088896340736f;
 
-struct LSE {                            // running log-sum-exp state: z = sum of exp(x - m)
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }      // v_exp_f32 (arguments <= ~0 here: no denormal pre-scaling)
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }       // v_log_f32 (arguments >= 1e-30: normal numbers)
+
+struct LSE {                            // running log2-sum-exp2 state: z = sum of 2^(x - m)
     float m, z;
     __device__ __forceinline__ void init() { m = kNegBig; z = 0.f; }
     __device__ __forceinline__ void add_exact(float x) {       // online update with the maximum as stabiliser (x may be -inf: no-op)
-        if (x > m) { z = z * __expf(m - x) + 1.0f; m = x; }
-        else z += __expf(x - m);
+        if (x > m) { z = z * ex2(m - x) + 1.0f; m = x; }
+        else z += ex2(x - m);
     }
     __device__ __forceinline__ void merge(float m2, float z2) {
         const float mn = fmaxf(m, m2);
-        z = z * __expf(m - mn) + z2 * __expf(m2 - mn);
+        z = z * ex2(m - mn) + z2 * ex2(m2 - mn);
         m = mn;
     }
-    // logsumexp_stable: m + log(max(sum, 1e-30))
-    __device__ __forceinline__ float value() const { return m + __logf(fmaxf(z, 1e-30f)); }
+    // logsumexp_stable: m + log(max(sum, 1e-30))   (log2 domain: the same sum, the same clamp)
+    __device__ __forceinline__ float value() const { return m + lg2(fmaxf(z, 1e-30f)); }
 };
 
-template <int CTRL> __device__ __forceinline__ int dpp_movi(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+// butterfly steps inside aligned groups of 16 lanes as single DPP VALU instructions: quad_perm[1,0,3,2], quad_perm[2,3,0,1],
+// row_half_mirror, row_mirror.  (The s_nop covers the "VALU write -> DPP read" wait states, which nobody inserts inside inline asm.)
+#define S2M2_DPP16(NAME, TYPE, OP)                                                                                                   \
+    __device__ __forceinline__ TYPE NAME(TYPE x) {                                                                                   \
+        TYPE a, b, c, d;                                                                                                             \
+        asm("s_nop 1\n\t" OP " %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(x));                       \
+        asm("s_nop 1\n\t" OP " %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(b) : "v"(a));                       \
+        asm("s_nop 1\n\t" OP " %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(c) : "v"(b));                           \
+        asm("s_nop 1\n\t" OP " %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(c));                                \
+        return d;                                                                                                                    \
+    }
+S2M2_DPP16(row16_max_f, float, "v_max_f32_dpp")
+S2M2_DPP16(row16_sum_f, float, "v_add_f32_dpp")
+S2M2_DPP16(row16_min_i, int, "v_min_i32_dpp")
+#undef S2M2_DPP16
+
 // reductions over aligned groups of GL lanes, result in every lane of the group: 4 DPP steps cover 16 lanes, ds_bpermute the rest
 template <int GL> __device__ __forceinline__ float group_sum_f(float x) {
-    x += dpp_mov<0xB1>(x); x += dpp_mov<0x4E>(x); x += dpp_mov<0x141>(x); x += dpp_mov<0x140>(x);
+    x = row16_sum_f(x);
     if (GL >= 32) x += __shfl_xor(x, 16, 64);
     if (GL >= 64) x += __shfl_xor(x, 32, 64);
     return x;
 }
 template <int GL> __device__ __forceinline__ float group_max_f(float x) {
-    x = fmaxf(x, dpp_mov<0xB1>(x)); x = fmaxf(x, dpp_mov<0x4E>(x)); x = fmaxf(x, dpp_mov<0x141>(x)); x = fmaxf(x, dpp_mov<0x140>(x));
+    x = row16_max_f(x);
     if (GL >= 32) x = fmaxf(x, __shfl_xor(x, 16, 64));
     if (GL >= 64) x = fmaxf(x, __shfl_xor(x, 32, 64));
     return x;
 }
 template <int GL> __device__ __forceinline__ int group_min_i(int x) {
-    x = min(x, dpp_movi<0xB1>(x)); x = min(x, dpp_movi<0x4E>(x)); x = min(x, dpp_movi<0x141>(x)); x = min(x, dpp_movi<0x140>(x));
+    x = row16_min_i(x);
     if (GL >= 32) x = min(x, __shfl_xor(x, 16, 64));
     if (GL >= 64) x = min(x, __shfl_xor(x, 32, 64));
     return x;
 }
 
 // 16-byte pieces in front of row i of the LDS-resident triangle (row r holds its columns 0 .. r, rounded up to whole pieces)
-__device__ __forceinline__ int tri_pieces(int i, int ppe) {        // ppe: elements per piece
+__host__ __device__ __forceinline__ int tri_pieces(int i, int ppe) {        // ppe: elements per piece
     const int q = i / ppe, rem = i - q * ppe;
     return i + ppe * ((q * (q - 1)) >> 1) + q * rem;               // sum_{r < i} (floor(r / ppe) + 1)
 }
+
+// LDS layout of one block: u [ns] | pm [NWV][ns] | pz [NWV][ns] | flags [4] | v [nvs] | (TRI) the masked triangle, the dustbin row, the -inf piece
+template <int NWV, int GL, int NCH>
+struct K2Lds {
+    __host__ __device__ static int ns(int w) { return (w + 4) & ~3; }                   // w + 1 entries, 16-byte rows
+    __host__ __device__ static int nvs(int w) { return ns(w) > NCH * 8 * GL + 8 ? ns(w) : NCH * 8 * GL + 8; }     // v: whole chunks (unconditional 16-byte reads)
+    __host__ __device__ static size_t vec_bytes(int w) { return ((size_t)(1 + 2 * NWV) * ns(w) + 4 + nvs(w)) * sizeof(float); }
+    __host__ __device__ static size_t tri_pieces_total(int w, int vec) { return (size_t)tri_pieces(w, vec) + w / vec + 1; }
+};
+
+template <typename TI> __device__ __forceinline__ raw16_t pack_piece(const float* x);
+template <> __device__ __forceinline__ raw16_t pack_piece<half_t>(const float* x) {   // exact: the values came from fp16 (or are -inf / 0)
+    raw16_t r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = __builtin_bit_cast(float, __builtin_amdgcn_cvt_pkrtz(x[2 * k], x[2 * k + 1]));
+    return r;
+}
+template <> __device__ __forceinline__ raw16_t pack_piece<float>(const float* x) { return raw16_t{x[0], x[1], x[2], x[3]}; }
+
+template <int N> struct IC { static constexpr int value = N; };
 
 // TRI: the block keeps the row's lower cost-volume triangle (use_positivity: j <= i) in LDS -- pass 0 copies the pieces it reads from
 // global memory, the ot_iter later sweeps read LDS: the volume is read from HBM / MALL ONCE (the algorithmic minimum) and the latency
@@ -87,53 +141,61 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     constexpr int RPW = 64 / GL;                           // rows per wave and step
     constexpr int RPB = RPW * NWV;                         // rows per block and step
     constexpr int NE = 8 * NCH;                            // columns per lane
+    using L = K2Lds<NWV, GL, NCH>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = w + 1;                                   // padded size
-    const int ns = (n + 3) & ~3;                           // row stride of the LDS vectors (16-byte aligned rows)
-    float* u = reinterpret_cast<float*>(smem);             // [ns]
-    float* v = u + ns;                                     // [ns]
-    float* pm = v + ns;                                    // [NWV][ns]  per-wave column partial stabiliser
+    const int ns = L::ns(w);                               // row stride of the LDS vectors (16-byte aligned rows)
+    float* u = reinterpret_cast<float*>(smem);             // [ns]                               (log2 domain, like v)
+    float* pm = u + ns;                                    // [NWV][ns]  per-wave column partial stabiliser
     float* pz = pm + NWV * ns;                             // [NWV][ns]  per-wave column partial sum
-    // [TRI] packed lower triangle behind the vectors and the three flag words, 16-byte aligned
-    raw16_t* tri = reinterpret_cast<raw16_t*>(smem + (((size_t)(2 + 2 * NWV) * ns * sizeof(float) + 16 + 15) & ~(size_t)15));
+    int* flags = reinterpret_cast<int*>(pz + NWV * ns);    // [4]
+    float* v = reinterpret_cast<float*>(flags + 4);        // [nvs]
+    // [TRI] masked lower triangle behind the vectors, 16-byte aligned; row w = the dustbin row (zeros); then one piece of -inf
+    raw16_t* tri = reinterpret_cast<raw16_t*>(smem + ((L::vec_bytes(w) + 15) & ~(size_t)15));
+    const int ninf_idx = tri_pieces(w, VEC) + w / VEC;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = lane / GL, pl = lane % GL;             // row group inside the wave, position inside the group
     const TI* S = cv + (size_t)blockIdx.x * w * pitch;          // volume rows `pitch` elements apart (>= w, multiple of 8)
-    const float log_row = -__logf(2.0f * w);               // log(1/(2w))   marginal of a regular row/column
-    const float log_bin = __logf(0.5f);                    // log(w/(2w))   marginal of the dustbin
-    const float log2w = __logf(2.0f * w);
+    const float log_row = -lg2(2.0f * w);                  // log2(1/(2w))   marginal of a regular row/column
+    const float log_bin = -1.0f;                           // log2(w/(2w))   marginal of the dustbin
+    const float log2w = lg2(2.0f * w);
     float* od = disp + (size_t)blockIdx.x * w;
     float* oc = conf + (size_t)blockIdx.x * w;
     float* oo = occ + (size_t)blockIdx.x * w;
 
-    // row i (i == w: the dustbin row, S = 0, never masked): raw 16-byte pieces of the lane's columns j = c*CW + pl*8 + 0..7
-    // SRC 0: global memory; 1: global memory + copy into the LDS triangle (pass 0 of a TRI block); 2: the LDS triangle
-    auto fetch_row_from = [&](int i, raw16_t (&raw)[NCH][PPC], int src) __attribute__((always_inline)) {
+    // row i (i == w: the dustbin row, S = 0, never masked): raw 16-byte pieces of the lane's columns j = c*CW + pl*8 + 0..7 from global memory
+    auto fetch_global = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
         const TI* Si = S + (size_t)(i < w ? i : 0) * pitch;
         const int jend = i < w ? (use_pos ? i + 1 : w) : 0;
-        raw16_t* trow = tri;
-        if constexpr (TRI) trow = tri + tri_pieces(i < w ? i : 0, VEC);
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int q = 0; q < PPC; ++q) {
                 const int j0 = c * CW + pl * 8 + q * VEC;
-                if (j0 < jend) {                                            // w % 8 == 0: a piece starting inside [0, w) is whole
-                    if (TRI && src == 2) raw[c][q] = trow[j0 / VEC];
-                    else {
-                        raw[c][q] = global_load16(Si + j0);
-                        if (TRI && src == 1) trow[j0 / VEC] = raw[c][q];
-                    }
-                }
+                if (j0 < jend) raw[c][q] = global_load16(Si + j0);          // w % 8 == 0: a piece starting inside [0, w) is whole
             }
     };
-    auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) { fetch_row_from(i, raw, TRI ? 2 : 0); };
+    // [TRI] the same pieces from the masked LDS triangle: rows 0 .. w hold what they hold, everything else is the -inf piece
+    auto fetch_tri = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
+        const int jl = i < w ? i + 1 : (i == w ? w : 0);
+        const int base = tri_pieces(i < w ? i : w, VEC) + pl * PPC;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < PPC; ++q) {
+                const int j0 = c * CW + pl * 8 + q * VEC;
+                raw[c][q] = tri[j0 < jl ? base + c * (CW / VEC) + q : ninf_idx];
+            }
+    };
+    auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
+        if constexpr (TRI) fetch_tri(i, raw);
+        else if (i <= w) fetch_global(i, raw);
+    };
+    // raw pieces of row i -> natural-domain floats: masked triangle / past the row = -inf, the dustbin row = 0.
     // nfast: leading chunks whose columns are valid for EVERY row of this wave in this step (regular rows, nothing masked): a plain
     // convert.  nchw: chunks that hold any unmasked column of the wave (later ones are never touched by any sweep, see chunks_needed).
-    // The per-element compare / select (two instructions per element) is left to the one or two chunks the diagonal crosses -- measured
-    // before this split: 126 of the ~410 VALU instructions of a 4-row step were the decode of 24 elements per lane, half of them masked.
     auto decode_row = [&](int i, const raw16_t (&raw)[NCH][PPC], float (&x)[NE], int nfast, int nchw) __attribute__((always_inline)) {
         const int jend = i < w ? (use_pos ? i + 1 : w) : (i == w ? w : 0);
 #pragma unroll
@@ -154,7 +216,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
                     const int j = c * CW + pl * 8 + q * VEC + e;
-                    x[c * 8 + q * VEC + e] = j < jend ? (i < w ? to_f32(r.v[e]) : 0.f) : -INFINITY;   // masked triangle / past the row
+                    x[c * 8 + q * VEC + e] = j < jend ? (i < w ? to_f32(r.v[e]) : 0.f) : -INFINITY;
                 }
             }
         }
@@ -175,12 +237,17 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     };
     // fast column sweep lost a column (underflow): redo the pass exactly.  Three flags used in turn: pass p raises flags[p % 3] and
     // clears flags[(p + 1) % 3] for its successor, so a wave still reading the flag of pass p - 1 never sees it reset
-    int* flags = reinterpret_cast<int*>(pz + NWV * ns);
     if (tid < 3) flags[tid] = 0;                           // (ordered before the first use by the barriers of pass 0)
-    // the padding of v (entries n .. ns-1) is never written by the sweeps but IS read: the 16-byte read of v that holds the dustbin entry
-    // v[w] also covers v[w+1 .. w+3], added to masked (-inf) columns -- whatever the previous kernel left in LDS there (+inf / NaN patterns)
-    // would turn exp(-inf + garbage - m) into NaN and poison the row sum
-    if (tid < ns - n) { v[n + tid] = 0.f; u[n + tid] = 0.f; }
+    // the padding of v (entries n .. nvs-1) is never written by the sweeps but IS read by the unconditional 16-byte reads: it is added
+    // to masked (-inf) columns only, and must be finite for that (whatever the previous kernel left in LDS may be +inf / NaN)
+    for (int j = n + tid; j < L::nvs(w); j += NWV * 64) v[j] = 0.f;
+    if (tid < ns - n) u[n + tid] = 0.f;
+    if constexpr (TRI) {
+        if (tid == 0) {
+            const float ninf = __builtin_bit_cast(float, sizeof(TI) == 2 ? 0xFC00FC00u : 0xFF800000u);
+            tri[ninf_idx] = raw16_t{ninf, ninf, ninf, ninf};
+        }
+    }
 
     // ---- exact column sweep: v_j = log nu_j - LSE_i(S_ij + u_i) with lazy-maximum accumulators (pass 0, where u = 0, and the
     // fallback of the fast sweep below)
@@ -198,22 +265,49 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             for (int c = 0; c < NCH; ++c)
 #pragma unroll
                 for (int q = 0; q < PPC; ++q) raw[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f};
-            if (active) fetch_row_from(i, raw, use_u ? (TRI ? 2 : 0) : (TRI ? 1 : 0));
             float x[NE];
-            decode_row(active ? i : w + 1, raw, x, chunks_fast(i0), nchw);
+            if (TRI && use_u) {
+                fetch_tri(i, raw);                                // (masked copy: plain converts)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c >= nchw) continue;
+#pragma unroll
+                    for (int q = 0; q < PPC; ++q) {
+                        const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[c][q]);
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) x[c * 8 + q * VEC + e] = to_f32(r.v[e]);
+                    }
+                }
+            } else {
+                if (active) fetch_global(i, raw);
+                decode_row(active ? i : w + 1, raw, x, chunks_fast(i0), nchw);
+                if constexpr (TRI) {
+                    if (active) {                                 // the masked copy of this row (the dustbin row: zeros) for the later passes
+                        const int jl = i < w ? i + 1 : w;
+                        raw16_t* trow = tri + tri_pieces(i, VEC) + pl * PPC;
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) {
+                            if (c >= nchw) continue;
+#pragma unroll
+                            for (int q = 0; q < PPC; ++q)
+                                if (c * CW + pl * 8 + q * VEC < jl) trow[c * (CW / VEC) + q] = pack_piece<TI>(&x[c * 8 + q * VEC]);
+                        }
+                    }
+                }
+            }
             const float ua = active ? (use_u ? u[i] : 0.f) : -INFINITY;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (c >= nchw) continue;
                 float t[8], dmax = -INFINITY;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { t[e] = x[c * 8 + e] + ua; dmax = fmaxf(dmax, t[e] - col[c * 8 + e].m); }
+                for (int e = 0; e < 8; ++e) { t[e] = __builtin_fmaf(x[c * 8 + e], kL2E, ua); dmax = fmaxf(dmax, t[e] - col[c * 8 + e].m); }
                 if (__builtin_amdgcn_ballot_w64(dmax > kLazy)) {                  // rare: a stabiliser is too far below its new element
 #pragma unroll
                     for (int e = 0; e < 8; ++e) col[c * 8 + e].add_exact(t[e]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) col[c * 8 + e].z += __expf(t[e] - col[c * 8 + e].m);
+                    for (int e = 0; e < 8; ++e) col[c * 8 + e].z += ex2(t[e] - col[c * 8 + e].m);
                 }
             }
             bin.add_exact(ua);
@@ -246,17 +340,18 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 
     exact_cols(false);                                     // pass 0: v = log nu - LSE_i(S)
 
-    // ---- passes 1 .. ot_iter: row sweep (exact max-then-sum) fused with the next column sweep.  With e_ij = exp(S_ij + v_j - m_i)
-    // from the row sweep, the column term is exp(S_ij + u_i - (c0 - v_j)) = e_ij * exp(u_i + m_i - c0): ONE multiply-add per element
+    // ---- passes 1 .. ot_iter: row sweep (exact max-then-sum) fused with the next column sweep.  With e_ij = 2^(S_ij + v_j - m_i)
+    // from the row sweep, the column term is 2^(S_ij + u_i - (c0 - v_j)) = e_ij * 2^(u_i + m_i - c0): ONE multiply-add per element
     // against the per-row factor f_i -- the stabiliser c0 - v_j is the column's previous log-sum-exp up to a constant, and
     // f_i <= 1 for c0 = log(1/2) (u_i + m_i <= log mu_i), so nothing can overflow; a column whose sum underflows (it would need a
     // dynamic range of e^80 inside the volume) raises a flag and the pass is redone with exact_cols.
     const float c0 = log_bin;
     for (int pass = 1; pass <= ot_iter; ++pass) {
         const bool last = pass == ot_iter;
-        float zc[NE], zbin = 0.f;
+        float2_t zc[NE / 2];
+        float zbin = 0.f;
 #pragma unroll
-        for (int c = 0; c < NE; ++c) zc[c] = 0.f;
+        for (int c = 0; c < NE / 2; ++c) zc[c] = float2_t{0.f, 0.f};
         const float vbin = v[w];
         int* flag = flags + pass % 3;
         if (tid == 0) flags[(pass + 1) % 3] = 0;
@@ -266,66 +361,93 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
             for (int q = 0; q < PPC; ++q) { rcur[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f}; rnext[c][q] = rcur[c][q]; }
         fetch_row(r0, rcur);
-        for (int i0 = 0; i0 <= w; i0 += RPB) {             // uniform trip count for every wave (groups past row w idle)
+
+        // one step = RPW rows per wave with NC live chunks (compile time: straight-line code)
+        auto row_step = [&](auto nc_tag, int i0) __attribute__((always_inline)) {
+            constexpr int NC = decltype(nc_tag)::value;
             const int i = i0 + r0;
             const bool active = i <= w;
-            const int nchw = chunks_needed(i0);
-            if (i + RPB <= w) fetch_row(i + RPB, rnext);          // in flight under this row's arithmetic
-            float x[NE];
-            decode_row(active ? i : w + 1, rcur, x, chunks_fast(i0), nchw);
+            if (TRI || i + RPB <= w) fetch_row(i + RPB, rnext);   // in flight under this row's arithmetic
+            // ---- x = S * log2e + v: the row sweep's exponent, dustbin column apart (S = 0)
+            float2_t x[NC * 4];
+            float mloc = -INFINITY;
+            if constexpr (TRI) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float* vp = v + c * CW + pl * 8;
+                    const float4_t va = *reinterpret_cast<const float4_t*>(vp), vb = *reinterpret_cast<const float4_t*>(vp + 4);
+                    const float vv[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+                    for (int q = 0; q < PPC; ++q) {
+                        const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, rcur[c][q]);
+#pragma unroll
+                        for (int e = 0; e < VEC; e += 2) {
+                            float2_t t;
+                            t[0] = __builtin_fmaf(to_f32(r.v[e]), kL2E, vv[q * VEC + e]);
+                            t[1] = __builtin_fmaf(to_f32(r.v[e + 1]), kL2E, vv[q * VEC + e + 1]);
+                            x[c * 4 + (q * VEC + e) / 2] = t;
+                            mloc = fmaxf(mloc, fmaxf(t[0], t[1]));
+                        }
+                    }
+                }
+            } else {
+                float s[NE];
+                decode_row(active ? i : w + 1, rcur, s, chunks_fast(i0), NC);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float* vp = v + c * CW + pl * 8;
+                    const float4_t va = *reinterpret_cast<const float4_t*>(vp), vb = *reinterpret_cast<const float4_t*>(vp + 4);
+                    const float vv[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        float2_t t;
+                        t[0] = __builtin_fmaf(s[c * 8 + e], kL2E, vv[e]);
+                        t[1] = __builtin_fmaf(s[c * 8 + e + 1], kL2E, vv[e + 1]);
+                        x[c * 4 + e / 2] = t;
+                        mloc = fmaxf(mloc, fmaxf(t[0], t[1]));
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < NCH; ++c)
 #pragma unroll
                 for (int q = 0; q < PPC; ++q) rcur[c][q] = rnext[c][q];
-            // ---- row sweep: u_i = log mu_i - LSE_j(S_ij + v_j), dustbin column included (S = 0)
-            float mloc = -INFINITY;
+            // ---- row sweep: u_i = log mu_i - LSE_j(S_ij + v_j), dustbin column included
+            const float gmax = group_max_f<GL>(mloc);             // (-inf for an idle row: vbin takes over)
+            const float m = fmaxf(gmax, vbin);
+            const float2_t m2 = float2_t{m, m};
+            float2_t s2 = float2_t{0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c >= nchw) continue;
-                const int j0 = c * CW + pl * 8;
-                const float4_t va = j0 < n ? *reinterpret_cast<const float4_t*>(v + j0) : float4_t{0.f, 0.f, 0.f, 0.f};
-                const float4_t vb = j0 + 4 < n ? *reinterpret_cast<const float4_t*>(v + j0 + 4) : float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { x[c * 8 + e] += e < 4 ? va[e] : vb[e - 4]; mloc = fmaxf(mloc, x[c * 8 + e]); }   // x <- S + v (masked: -inf)
+            for (int k = 0; k < NC * 4; ++k) {
+                const float2_t d = x[k] - m2;
+                x[k] = float2_t{ex2(d[0]), ex2(d[1])};                            // x <- e_ij
+                s2 += x[k];
             }
-            const float m = fmaxf(group_max_f<GL>(mloc), vbin);
-            float sloc = 0.f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c >= nchw) continue;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { x[c * 8 + e] = __expf(x[c * 8 + e] - m); sloc += x[c * 8 + e]; }               // x <- e_ij
-            }
-            const float srow = group_sum_f<GL>(sloc);
-            const float ebin = __expf(vbin - m);
-            const float ui = (i == w ? log_bin : log_row) - (m + __logf(fmaxf(srow + ebin, 1e-30f)));
+            const float srow = group_sum_f<GL>(s2[0] + s2[1]);
+            const float ebin = ex2(vbin - m);
+            const float ui = (i == w ? log_bin : log_row) - (m + lg2(fmaxf(srow + ebin, 1e-30f)));
             if (!last) {
                 if (pl == 0 && active) u[i] = ui;                                 // (only the exact fallback reads it)
-                const float f = active ? __expf(ui + m - c0) : 0.f;
+                const float f = active ? ex2(ui + m - c0) : 0.f;
+                const float2_t f2 = float2_t{f, f};
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (c >= nchw) continue;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) zc[c * 8 + e] = __builtin_fmaf(x[c * 8 + e], f, zc[c * 8 + e]);
-                }
+                for (int k = 0; k < NC * 4; ++k) zc[k] = x[k] * f2 + zc[k];
                 zbin = __builtin_fmaf(ebin, f, zbin);
             } else if (i < w) {
-                // ---- probabilities P_ij = e_ij * exp(m_i + u_i + log 2w), argmax (first max wins), window regression, row mass
+                // ---- probabilities P_ij = e_ij * 2^(m_i + u_i + log 2w), argmax (first max wins), window regression, row mass
                 const float ci = ui + log2w;
-                const float gsc = __expf(m + ci);
+                const float gsc = ex2(m + ci);
                 const int jend = use_pos ? i + 1 : w;
                 float best = -1.f;
                 int bj = 0x7fffffff;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (c >= nchw) continue;
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int j = c * CW + pl * 8 + e;
-                        const float pr = x[c * 8 + e] * gsc;
+                        const float pr = x[c * 4 + e / 2][e & 1] * gsc;
                         if (j < jend && pr > best) { best = pr; bj = j; }        // strict: keeps the first maximum of this lane
                     }
-                }
                 const float bmax = group_max_f<GL>(best);
                 bj = group_min_i<GL>(best == bmax ? bj : 0x7fffffff);
                 const float mass = srow * gsc;
@@ -333,7 +455,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                 const TI* Si = TRI ? reinterpret_cast<const TI*>(tri + tri_pieces(i, VEC)) : S + (size_t)i * pitch;
                 const int jj = bj + pl - 2;
                 float pk = 0.f;
-                if (pl < 5 && jj >= 0 && jj < jend) pk = __expf(to_f32(Si[jj]) + ci + v[jj]);
+                if (pl < 5 && jj >= 0 && jj < jend) pk = ex2(__builtin_fmaf(to_f32(Si[jj]), kL2E, ci + v[jj]));
                 float cf = 0.f, num = 0.f;
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {                                     // same summation order as the reference loop
@@ -349,13 +471,22 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                     if (amax) amax[(size_t)blockIdx.x * w + i] = bj;
                 }
             }
+        };
+        {
+            int i0 = 0;                                    // uniform trip count for every wave (groups past row w idle)
+            if constexpr (NCH >= 2) for (; i0 <= w && chunks_needed(i0) <= 1; i0 += RPB) row_step(IC<1>{}, i0);
+            if constexpr (NCH >= 3) for (; i0 <= w && chunks_needed(i0) <= 2; i0 += RPB) row_step(IC<2>{}, i0);
+            for (; i0 <= w; i0 += RPB) row_step(IC<NCH>{}, i0);
         }
         if (last) break;
         // ---- combine the partial column sums: across the row groups of a wave (lanes with equal pl), then across waves through LDS
 #pragma unroll
         for (int off = GL; off < 64; off <<= 1) {
 #pragma unroll
-            for (int c = 0; c < NE; ++c) zc[c] += __shfl_xor(zc[c], off, 64);
+            for (int c = 0; c < NE / 2; ++c) {
+                zc[c][0] += __shfl_xor(zc[c][0], off, 64);
+                zc[c][1] += __shfl_xor(zc[c][1], off, 64);
+            }
             zbin += __shfl_xor(zbin, off, 64);
         }
         __syncthreads();                                   // every row sweep of this pass has read v
@@ -363,7 +494,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
             for (int c = 0; c < NE; ++c) {
                 const int j = (c / 8) * CW + pl * 8 + (c % 8);
-                if (j < w) pz[wv * ns + j] = zc[c];
+                if (j < w) pz[wv * ns + j] = zc[c / 2][c & 1];
             }
             if (pl == 0) pz[wv * ns + w] = zbin;
         }
@@ -373,7 +504,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
             for (int k = 0; k < NWV; ++k) z += pz[k * ns + j];
             if (!(z > 1e-30f) || !(z < 3.0e38f)) *flag = 1;                       // underflow (or NaN): this pass needs the exact sweep
-            v[j] = (j == w ? log_bin : log_row) - ((c0 - v[j]) + __logf(z));
+            v[j] = (j == w ? log_bin : log_row) - ((c0 - v[j]) + lg2(z));
         }
         __syncthreads();
         if (*flag) exact_cols(true);                       // uniform for the block; rewrites every v_j from S and u
@@ -385,12 +516,12 @@ static int launch_sinkhorn(const void* cv, float* disp, float* conf, float* occ,
                            int use_pos, int pitch, hipStream_t st) {
     // 16 waves per row block where a lane's state (8 * NCH columns: values + two accumulator words each) fits 128 registers, else 8
     constexpr int NWV = NCH == 1 ? 16 : 8;
+    using L = K2Lds<NWV, GL, NCH>;
     auto kern = sinkhorn_regress_kernel<TI, NWV, GL, NCH, TRI>;
-    size_t lds = (size_t)(2 + 2 * NWV) * ((w + 4) & ~3) * sizeof(float) + 16;
+    size_t lds = L::vec_bytes(w);
     if (TRI) {
         constexpr int VEC = 16 / sizeof(TI);
-        const size_t pieces = (size_t)w + (size_t)VEC * ((size_t)(w / VEC) * (w / VEC - 1) / 2);       // tri_pieces(w): w % VEC == 0
-        const size_t tri_bytes = ((lds + 15) & ~(size_t)15) + pieces * 16;
+        const size_t tri_bytes = ((lds + 15) & ~(size_t)15) + L::tri_pieces_total(w, VEC) * 16;
         static const bool off = getenv("S2M2_K2_TRI") != nullptr && atoi(getenv("S2M2_K2_TRI")) == 0;   // A/B switch
         if (!use_pos || off || tri_bytes > 160 * 1024)
             return launch_sinkhorn<TI, GL, NCH, false>(cv, disp, conf, occ, amax, rows, w, ot_iter, use_pos, pitch, st);

@@ -43,7 +43,10 @@ def test_sinkhorn_regress_vs_reference_golden(hip, name):
     disp, conf, occ, am = disp.cpu(), conf.cpu(), occ.cpu(), am.cpu()
     rd, rc, ro = (T(g[k]) for k in (("disp", "conf", "occ") if name.startswith("op_") else ("disp0", "conf0", "occ0")))
     top1, top2 = g["top2"][..., 0], g["top2"][..., 1]
-    sure = T((top1 - top2) > 1e-4 * top1) | T(top1 == top2)
+    # (an exact tie top1 == top2 in the reference's fp32 plan is NOT "sure": op_dispinit_pos holds one between two columns whose scores differ by
+    # 1.4 -- a coincidence of its rounding, which any other summation order resolves either way; ties between identical scores are pinned by
+    # test_sinkhorn_first_maximum_wins_on_exact_ties)
+    sure = T((top1 - top2) > 1e-4 * top1)
     same = am == T(g["argmax"])
     assert bool(same[sure].all()), f"{int((~same[sure]).sum())} argmax mismatches on well separated pixels"
     assert float(sure.float().mean()) > 0.97
