@@ -252,9 +252,10 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
     // ---- exact column sweep: v_j = log nu_j - LSE_i(S_ij + u_i) with lazy-maximum accumulators (pass 0, where u = 0, and the
     // fallback of the fast sweep below)
     auto exact_cols = [&](bool use_u) __attribute__((always_inline)) {        // (use_u false = pass 0: the one sweep that reads global memory in a TRI block)
-        LSE col[NE], bin;
+        float2_t cm[NE / 2], cz[NE / 2];                   // per column: stabiliser and sum of 2^(t - stabiliser)
+        LSE bin;
 #pragma unroll
-        for (int c = 0; c < NE; ++c) col[c].init();
+        for (int c = 0; c < NE / 2; ++c) { cm[c] = float2_t{kNegBig, kNegBig}; cz[c] = float2_t{0.f, 0.f}; }
         bin.init();
         for (int i0 = 0; i0 <= w; i0 += RPB) {
             const int i = i0 + r0;
@@ -299,16 +300,25 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 if (c >= nchw) continue;
-                float t[8], dmax = -INFINITY;
+                float2_t t[4], d[4];
+                float dmax = -INFINITY;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { t[e] = __builtin_fmaf(x[c * 8 + e], kL2E, ua); dmax = fmaxf(dmax, t[e] - col[c * 8 + e].m); }
-                if (__builtin_amdgcn_ballot_w64(dmax > kLazy)) {                  // rare: a stabiliser is too far below its new element
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) col[c * 8 + e].add_exact(t[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) col[c * 8 + e].z += ex2(t[e] - col[c * 8 + e].m);
+                for (int k = 0; k < 4; ++k) {
+                    t[k] = float2_t{__builtin_fmaf(x[c * 8 + 2 * k], kL2E, ua), __builtin_fmaf(x[c * 8 + 2 * k + 1], kL2E, ua)};
+                    d[k] = t[k] - cm[c * 4 + k];
+                    dmax = fmaxf(dmax, fmaxf(d[k][0], d[k][1]));
                 }
+                if (__builtin_amdgcn_ballot_w64(dmax > kLazy)) {                  // rare: a stabiliser is too far below its new element -> it moves up to it
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            if (t[k][h] > cm[c * 4 + k][h]) { cz[c * 4 + k][h] *= ex2(cm[c * 4 + k][h] - t[k][h]); cm[c * 4 + k][h] = t[k][h]; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) d[k] = t[k] - cm[c * 4 + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cz[c * 4 + k] += float2_t{ex2(d[k][0]), ex2(d[k][1])};
             }
             bin.add_exact(ua);
         }
@@ -316,7 +326,11 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
         for (int off = GL; off < 64; off <<= 1) {
 #pragma unroll
-            for (int c = 0; c < NE; ++c) col[c].merge(__shfl_xor(col[c].m, off, 64), __shfl_xor(col[c].z, off, 64));
+            for (int c = 0; c < NE; ++c) {
+                LSE t{cm[c / 2][c & 1], cz[c / 2][c & 1]};
+                t.merge(__shfl_xor(t.m, off, 64), __shfl_xor(t.z, off, 64));
+                cm[c / 2][c & 1] = t.m; cz[c / 2][c & 1] = t.z;
+            }
             bin.merge(__shfl_xor(bin.m, off, 64), __shfl_xor(bin.z, off, 64));
         }
         __syncthreads();                                   // readers of pm / pz / v of the previous pass are done
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
 #pragma unroll
             for (int c = 0; c < NE; ++c) {
                 const int j = (c / 8) * CW + pl * 8 + (c % 8);
-                if (j < w) { pm[wv * ns + j] = col[c].m; pz[wv * ns + j] = col[c].z; }
+                if (j < w) { pm[wv * ns + j] = cm[c / 2][c & 1]; pz[wv * ns + j] = cz[c / 2][c & 1]; }
             }
             if (pl == 0) { pm[wv * ns + w] = bin.m; pz[wv * ns + w] = bin.z; }
         }
@@ -363,8 +377,9 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
         fetch_row(r0, rcur);
 
         // one step = RPW rows per wave with NC live chunks (compile time: straight-line code)
-        auto row_step = [&](auto nc_tag, int i0) __attribute__((always_inline)) {
+        auto row_step = [&](auto nc_tag, auto last_tag, int i0) __attribute__((always_inline)) {
             constexpr int NC = decltype(nc_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value != 0;
             const int i = i0 + r0;
             const bool active = i <= w;
             if (TRI || i + RPB <= w) fetch_row(i + RPB, rnext);   // in flight under this row's arithmetic
@@ -426,7 +441,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             const float srow = group_sum_f<GL>(s2[0] + s2[1]);
             const float ebin = ex2(vbin - m);
             const float ui = (i == w ? log_bin : log_row) - (m + lg2(fmaxf(srow + ebin, 1e-30f)));
-            if (!last) {
+            if constexpr (!LAST) {
                 if (pl == 0 && active) u[i] = ui;                                 // (only the exact fallback reads it)
                 const float f = active ? ex2(ui + m - c0) : 0.f;
                 const float2_t f2 = float2_t{f, f};
@@ -438,18 +453,15 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                 const float ci = ui + log2w;
                 const float gsc = ex2(m + ci);
                 const int jend = use_pos ? i + 1 : w;
-                float best = -1.f;
-                int bj = 0x7fffffff;
+                // the maximum of the row is the element whose exponent was the row maximum: e == 2^(gmax - m) bit for bit (the same instruction
+                // on the same operands).  Masked entries are 0 and column 0 is never masked, so they cannot win; scanning the lane's elements
+                // backwards leaves its FIRST match.  (P = e * gsc is monotone in e: the argmax of the plan up to ties below one ulp.)
+                const float emax = ex2(gmax - m);
+                int bk = 0x7fffffff;
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int j = c * CW + pl * 8 + e;
-                        const float pr = x[c * 4 + e / 2][e & 1] * gsc;
-                        if (j < jend && pr > best) { best = pr; bj = j; }        // strict: keeps the first maximum of this lane
-                    }
-                const float bmax = group_max_f<GL>(best);
-                bj = group_min_i<GL>(best == bmax ? bj : 0x7fffffff);
+                for (int k = NC * 8 - 1; k >= 0; --k) bk = x[k / 2][k & 1] == emax ? k : bk;
+                int bj = bk == 0x7fffffff ? bk : (bk >> 3) * CW + pl * 8 + (bk & 7);
+                bj = group_min_i<GL>(bj);
                 const float mass = srow * gsc;
                 // 5 taps around the argmax, evaluated by lanes 0..4 of the group (zero outside [0,w) and in the masked triangle)
                 const TI* Si = TRI ? reinterpret_cast<const TI*>(tri + tri_pieces(i, VEC)) : S + (size_t)i * pitch;
@@ -474,9 +486,15 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
         };
         {
             int i0 = 0;                                    // uniform trip count for every wave (groups past row w idle)
-            if constexpr (NCH >= 2) for (; i0 <= w && chunks_needed(i0) <= 1; i0 += RPB) row_step(IC<1>{}, i0);
-            if constexpr (NCH >= 3) for (; i0 <= w && chunks_needed(i0) <= 2; i0 += RPB) row_step(IC<2>{}, i0);
-            for (; i0 <= w; i0 += RPB) row_step(IC<NCH>{}, i0);
+            if (!last) {
+                if constexpr (NCH >= 2) for (; i0 <= w && chunks_needed(i0) <= 1; i0 += RPB) row_step(IC<1>{}, IC<0>{}, i0);
+                if constexpr (NCH >= 3) for (; i0 <= w && chunks_needed(i0) <= 2; i0 += RPB) row_step(IC<2>{}, IC<0>{}, i0);
+                for (; i0 <= w; i0 += RPB) row_step(IC<NCH>{}, IC<0>{}, i0);
+            } else {
+                if constexpr (NCH >= 2) for (; i0 <= w && chunks_needed(i0) <= 1; i0 += RPB) row_step(IC<1>{}, IC<1>{}, i0);
+                if constexpr (NCH >= 3) for (; i0 <= w && chunks_needed(i0) <= 2; i0 += RPB) row_step(IC<2>{}, IC<1>{}, i0);
+                for (; i0 <= w; i0 += RPB) row_step(IC<NCH>{}, IC<1>{}, i0);
+            }
         }
         if (last) break;
         // ---- combine the partial column sums: across the row groups of a wave (lanes with equal pl), then across waves through LDS
