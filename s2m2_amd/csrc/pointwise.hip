@@ -206,50 +206,80 @@ extern "C" int s2m2_refine_update(const void* dco, int dco_stride, float* disp, 
 // ---------------------------------------------------------------------------------------------------------------
 // stem: the two 1x1 layers at the head of the CNN encoder, conv0 = Conv2d(3,16,1) - GELU - Conv2d(16,16,1) (reference
 // submodules.py:68-71), on FULL-resolution pixels (2.5 M per pair at 1216x1024).  With K = 8 / 16 and N = 16 a GEMM tile is
-// all padding and per-block overhead (K5: 145 + 134 us); per pixel it is 384 FMAs + 16 GELUs, so one thread takes one pixel:
-// weights are wave-uniform (scalar loads), the 16-channel intermediate never leaves registers (rounded to the I/O dtype where
-// the separate layers stored it), 16 bytes in, 32 bytes out per pixel.
+// all padding and per-block overhead (K5: 145 + 134 us); per pixel it is 384 FMAs + 16 GELUs on the VALU: weights are wave-uniform
+// (scalar loads), the 16-channel intermediate never leaves registers (rounded to the I/O dtype where the separate layers stored it),
+// 16 bytes in, 32 bytes out per pixel.
+// Round 6 (the pass was VALU-bound at 47.8 us, 2.5 TB/s): a thread takes TWO consecutive pixels as the halves of packed fp32 registers
+// -- every multiply-add is a v_pk_fma_f32 with the weight broadcast from an SGPR, the GELU is the packed form as it stands -- and
+// input columns whose 16 weights are all zero (5 of the 8: the tensor carries 3 image planes) are skipped behind a wave-uniform test
+// (their terms are + 0 * x: bit-identical for finite x).  Same summation order, same rounding points as before.
 // ---------------------------------------------------------------------------------------------------------------
 namespace s2m2 {
 template <typename T>
 __global__ __launch_bounds__(256) void stem_mlp_kernel(const T* __restrict__ x8, const float* __restrict__ w0, const float* __restrict__ b0,
                                                        const float* __restrict__ w1, const float* __restrict__ b1, T* __restrict__ out,
                                                        long long npix) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 2;
     if (i >= npix) return;
-    float x[8];
+    const long long i1 = i + 1 < npix ? i + 1 : i;                 // (odd pixel count: the last thread computes its pixel twice)
+    float2_t x[8];
     if constexpr (sizeof(T) == 2) {
-        const Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(x8 + i * 8);
+        raw16_t ra = global_load16(x8 + i * 8), rb = global_load16(x8 + i1 * 8);           // (whole pieces: the columns' uses sit behind branches)
+        asm volatile("" : "+v"(ra), "+v"(rb));
+        const Vec16<T> va = __builtin_bit_cast(Vec16<T>, ra), vb = __builtin_bit_cast(Vec16<T>, rb);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = to_f32(v.v[k]);
+        for (int k = 0; k < 8; ++k) x[k] = float2_t{to_f32(va.v[k]), to_f32(vb.v[k])};
     } else {
-        const Vec16<T> v0 = *reinterpret_cast<const Vec16<T>*>(x8 + i * 8), v1 = *reinterpret_cast<const Vec16<T>*>(x8 + i * 8 + 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { x[k] = to_f32(v0.v[k]); x[4 + k] = to_f32(v1.v[k]); }
+        for (int q = 0; q < 2; ++q) {
+            const Vec16<T> va = *reinterpret_cast<const Vec16<T>*>(x8 + i * 8 + 4 * q), vb = *reinterpret_cast<const Vec16<T>*>(x8 + i1 * 8 + 4 * q);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[4 * q + k] = float2_t{to_f32(va.v[k]), to_f32(vb.v[k])};
+        }
     }
-    float h[16];
+    float2_t h[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) h[j] = float2_t{b0[j], b0[j]};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsigned any = 0;                                          // (uniform integer arithmetic: scalar unit)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) any |= __builtin_bit_cast(unsigned, w0[j * 8 + k]) << 1;
+        if (any == 0) continue;                                    // a column of (+-) zeros
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float w = w0[j * 8 + k];
+            h[j] = __builtin_elementwise_fma(float2_t{w, w}, x[k], h[j]);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        float a = b0[j];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a = __builtin_fmaf(w0[j * 8 + k], x[k], a);
-        h[j] = to_f32(from_f32<T>(activate_to<S2M2_ACT_GELU, T>(a)));
+        if constexpr (sizeof(T) == 2 && S2M2_GELU16_POLY) h[j] = fast_gelu16x2(h[j]);
+        else h[j] = float2_t{activate_to<S2M2_ACT_GELU, T>(h[j][0]), activate_to<S2M2_ACT_GELU, T>(h[j][1])};
+        h[j] = float2_t{to_f32(from_f32<T>(h[j][0])), to_f32(from_f32<T>(h[j][1]))};
     }
-    float y[16];
+    float2_t y[16];
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
-        float a = b1[o];
+        float2_t a = float2_t{b1[o], b1[o]};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a = __builtin_fmaf(w1[o * 16 + j], h[j], a);
+        for (int j = 0; j < 16; ++j) {
+            const float w = w1[o * 16 + j];
+            a = __builtin_elementwise_fma(float2_t{w, w}, h[j], a);
+        }
         y[o] = a;
     }
     constexpr int VEC = 16 / sizeof(T);
 #pragma unroll
-    for (int q = 0; q < 16 / VEC; ++q) {
-        Vec16<T> v;
+    for (int px = 0; px < 2; ++px) {
+        if (px == 1 && i1 == i) break;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(y[q * VEC + e]);
-        *reinterpret_cast<Vec16<T>*>(out + i * 16 + q * VEC) = v;
+        for (int q = 0; q < 16 / VEC; ++q) {
+            Vec16<T> v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.v[e] = from_f32<T>(y[q * VEC + e][px]);
+            *reinterpret_cast<Vec16<T>*>(out + (i + px) * 16 + q * VEC) = v;
+        }
     }
 }
 
@@ -260,8 +290,9 @@ static int stem_mlp_impl(const void* x8, const float* w0, const float* b0, const
     using namespace s2m2;
     S2M2_REQUIRE(x8 && w0 && b0 && w1 && b1 && out && npix > 0, "stem_mlp: bad arguments");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == S2M2_F16) hipLaunchKernelGGL((stem_mlp_kernel<half_t>), grid1(npix), dim3(256), 0, st, (const half_t*)x8, w0, b0, w1, b1, (half_t*)out, npix);
-    else if (dtype == S2M2_F32) hipLaunchKernelGGL((stem_mlp_kernel<float>), grid1(npix), dim3(256), 0, st, (const float*)x8, w0, b0, w1, b1, (float*)out, npix);
+    const dim3 grid = grid1((npix + 1) / 2);                                      // two pixels per thread
+    if (dtype == S2M2_F16) hipLaunchKernelGGL((stem_mlp_kernel<half_t>), grid, dim3(256), 0, st, (const half_t*)x8, w0, b0, w1, b1, (half_t*)out, npix);
+    else if (dtype == S2M2_F32) hipLaunchKernelGGL((stem_mlp_kernel<float>), grid, dim3(256), 0, st, (const float*)x8, w0, b0, w1, b1, (float*)out, npix);
     else return set_error("stem_mlp: unsupported dtype %d", dtype);
     return check_launch("stem_mlp");
 }

@@ -81,7 +81,6 @@ S2M2_DPP16(row16_max_f, float, "v_max_f32_dpp")
 S2M2_DPP16(row16_sum_f, float, "v_add_f32_dpp")
 S2M2_DPP16(row16_min_i, int, "v_min_i32_dpp")
 #undef S2M2_DPP16
-
 // reductions over aligned groups of GL lanes, result in every lane of the group: 4 DPP steps cover 16 lanes, ds_bpermute the rest
 template <int GL> __device__ __forceinline__ float group_sum_f(float x) {
     x = row16_sum_f(x);
@@ -127,6 +126,10 @@ template <> __device__ __forceinline__ raw16_t pack_piece<half_t>(const float* x
 template <> __device__ __forceinline__ raw16_t pack_piece<float>(const float* x) { return raw16_t{x[0], x[1], x[2], x[3]}; }
 
 template <int N> struct IC { static constexpr int value = N; };
+// f(IC<J0>), f(IC<J0 + 1>), ... f(IC<J1 - 1>)
+template <int J0, int J1, typename F> __device__ __forceinline__ void static_range(F&& f) {
+    if constexpr (J0 < J1) { f(IC<J0>{}); static_range<J0 + 1, J1>(f); }
+}
 
 // TRI: the block keeps the row's lower cost-volume triangle (use_positivity: j <= i) in LDS -- pass 0 copies the pieces it reads from
 // global memory, the ot_iter later sweeps read LDS: the volume is read from HBM / MALL ONCE (the algorithmic minimum) and the latency
@@ -178,46 +181,43 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             }
     };
     // [TRI] the same pieces from the masked LDS triangle: rows 0 .. w hold what they hold, everything else is the -inf piece
-    auto fetch_tri = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
+    auto fetch_tri = [&](int i, raw16_t (&raw)[NCH][PPC], int nc) __attribute__((always_inline)) {
         const int jl = i < w ? i + 1 : (i == w ? w : 0);
         const int base = tri_pieces(i < w ? i : w, VEC) + pl * PPC;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int q = 0; q < PPC; ++q) {
+                if (c >= nc) continue;
                 const int j0 = c * CW + pl * 8 + q * VEC;
                 raw[c][q] = tri[j0 < jl ? base + c * (CW / VEC) + q : ninf_idx];
             }
     };
     auto fetch_row = [&](int i, raw16_t (&raw)[NCH][PPC]) __attribute__((always_inline)) {
-        if constexpr (TRI) fetch_tri(i, raw);
+        if constexpr (TRI) fetch_tri(i, raw, NCH);
         else if (i <= w) fetch_global(i, raw);
     };
-    // raw pieces of row i -> natural-domain floats: masked triangle / past the row = -inf, the dustbin row = 0.
-    // nfast: leading chunks whose columns are valid for EVERY row of this wave in this step (regular rows, nothing masked): a plain
-    // convert.  nchw: chunks that hold any unmasked column of the wave (later ones are never touched by any sweep, see chunks_needed).
-    auto decode_row = [&](int i, const raw16_t (&raw)[NCH][PPC], float (&x)[NE], int nfast, int nchw) __attribute__((always_inline)) {
+    // raw pieces of chunk c of row i -> natural-domain floats: masked triangle / past the row = -inf, the dustbin row = 0.
+    // fast: every column of the chunk is valid for EVERY row of this wave in this step (regular rows, nothing masked): a plain convert.
+    // The per-element compare / select (two instructions per element) is left to the one or two chunks the diagonal crosses.
+    auto decode_chunk = [&](int c, int i, const raw16_t (&raw)[PPC], float (&x)[8], bool fast) __attribute__((always_inline)) {
         const int jend = i < w ? (use_pos ? i + 1 : w) : (i == w ? w : 0);
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            if (c >= nchw) continue;                              // (wave-uniform)
-            if (c < nfast) {
-#pragma unroll
-                for (int q = 0; q < PPC; ++q) {
-                    const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[c][q]);
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e) x[c * 8 + q * VEC + e] = to_f32(r.v[e]);
-                }
-                continue;
-            }
+        if (fast) {
 #pragma unroll
             for (int q = 0; q < PPC; ++q) {
-                const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[c][q]);
+                const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[q]);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const int j = c * CW + pl * 8 + q * VEC + e;
-                    x[c * 8 + q * VEC + e] = j < jend ? (i < w ? to_f32(r.v[e]) : 0.f) : -INFINITY;
-                }
+                for (int e = 0; e < VEC; ++e) x[q * VEC + e] = to_f32(r.v[e]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < PPC; ++q) {
+            const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[q]);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int j = c * CW + pl * 8 + q * VEC + e;
+                x[q * VEC + e] = j < jend ? (i < w ? to_f32(r.v[e]) : 0.f) : -INFINITY;
             }
         }
     };
@@ -266,45 +266,32 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             for (int c = 0; c < NCH; ++c)
 #pragma unroll
                 for (int q = 0; q < PPC; ++q) raw[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f};
-            float x[NE];
-            if (TRI && use_u) {
-                fetch_tri(i, raw);                                // (masked copy: plain converts)
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (c >= nchw) continue;
-#pragma unroll
-                    for (int q = 0; q < PPC; ++q) {
-                        const Vec16<TI> r = __builtin_bit_cast(Vec16<TI>, raw[c][q]);
-#pragma unroll
-                        for (int e = 0; e < VEC; ++e) x[c * 8 + q * VEC + e] = to_f32(r.v[e]);
-                    }
-                }
-            } else {
-                if (active) fetch_global(i, raw);
-                decode_row(active ? i : w + 1, raw, x, chunks_fast(i0), nchw);
-                if constexpr (TRI) {
-                    if (active) {                                 // the masked copy of this row (the dustbin row: zeros) for the later passes
-                        const int jl = i < w ? i + 1 : w;
-                        raw16_t* trow = tri + tri_pieces(i, VEC) + pl * PPC;
-#pragma unroll
-                        for (int c = 0; c < NCH; ++c) {
-                            if (c >= nchw) continue;
-#pragma unroll
-                            for (int q = 0; q < PPC; ++q)
-                                if (c * CW + pl * 8 + q * VEC < jl) trow[c * (CW / VEC) + q] = pack_piece<TI>(&x[c * 8 + q * VEC]);
-                        }
-                    }
-                }
-            }
+            const bool from_tri = TRI && use_u;
+            if (from_tri) fetch_tri(i, raw, nchw);                      // (masked copy: plain converts)
+            else if (active) fetch_global(i, raw);
+            const int nfast = chunks_fast(i0);
+            const int idec = active ? i : w + 1;
             const float ua = active ? (use_u ? u[i] : 0.f) : -INFINITY;
+            raw16_t* trow = tri;
+            if constexpr (TRI) trow = tri + tri_pieces(i < w ? i : w, VEC) + pl * PPC;
+            const int jl = i < w ? i + 1 : w;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                if (c >= nchw) continue;
+                if (c >= nchw) continue;                          // (wave-uniform)
+                float x[8];
+                decode_chunk(c, idec, raw[c], x, from_tri || c < nfast);
+                if constexpr (TRI) {
+                    if (!use_u && active) {                       // pass 0: the masked copy of this row (the dustbin row: zeros) for the later passes
+#pragma unroll
+                        for (int q = 0; q < PPC; ++q)
+                            if (c * CW + pl * 8 + q * VEC < jl) trow[c * (CW / VEC) + q] = pack_piece<TI>(&x[q * VEC]);
+                    }
+                }
                 float2_t t[4], d[4];
                 float dmax = -INFINITY;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    t[k] = float2_t{__builtin_fmaf(x[c * 8 + 2 * k], kL2E, ua), __builtin_fmaf(x[c * 8 + 2 * k + 1], kL2E, ua)};
+                    t[k] = float2_t{__builtin_fmaf(x[2 * k], kL2E, ua), __builtin_fmaf(x[2 * k + 1], kL2E, ua)};
                     d[k] = t[k] - cm[c * 4 + k];
                     dmax = fmaxf(dmax, fmaxf(d[k][0], d[k][1]));
                 }
@@ -374,7 +361,7 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
             for (int q = 0; q < PPC; ++q) { rcur[c][q] = (raw16_t){0.f, 0.f, 0.f, 0.f}; rnext[c][q] = rcur[c][q]; }
-        fetch_row(r0, rcur);
+        if constexpr (!TRI) fetch_row(r0, rcur);
 
         // one step = RPW rows per wave with NC live chunks (compile time: straight-line code)
         auto row_step = [&](auto nc_tag, auto last_tag, int i0) __attribute__((always_inline)) {
@@ -382,7 +369,8 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
             constexpr bool LAST = decltype(last_tag)::value != 0;
             const int i = i0 + r0;
             const bool active = i <= w;
-            if (TRI || i + RPB <= w) fetch_row(i + RPB, rnext);   // in flight under this row's arithmetic
+            if constexpr (TRI) fetch_tri(i, rcur, NC);              // (LDS: no prefetch distance needed -- and 4 NCH registers fewer)
+            else if (i + RPB <= w) fetch_row(i + RPB, rnext);     // global memory: the next row is in flight under this row's arithmetic
             // ---- x = S * log2e + v: the row sweep's exponent, dustbin column apart (S = 0)
             float2_t x[NC * 4];
             float mloc = -INFINITY;
@@ -406,27 +394,30 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
                     }
                 }
             } else {
-                float s[NE];
-                decode_row(active ? i : w + 1, rcur, s, chunks_fast(i0), NC);
+                const int nfast = chunks_fast(i0);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
+                    float s[8];
+                    decode_chunk(c, active ? i : w + 1, rcur[c], s, c < nfast);
                     const float* vp = v + c * CW + pl * 8;
                     const float4_t va = *reinterpret_cast<const float4_t*>(vp), vb = *reinterpret_cast<const float4_t*>(vp + 4);
                     const float vv[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         float2_t t;
-                        t[0] = __builtin_fmaf(s[c * 8 + e], kL2E, vv[e]);
-                        t[1] = __builtin_fmaf(s[c * 8 + e + 1], kL2E, vv[e + 1]);
+                        t[0] = __builtin_fmaf(s[e], kL2E, vv[e]);
+                        t[1] = __builtin_fmaf(s[e + 1], kL2E, vv[e + 1]);
                         x[c * 4 + e / 2] = t;
                         mloc = fmaxf(mloc, fmaxf(t[0], t[1]));
                     }
                 }
             }
+            if constexpr (!TRI) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c)
+                for (int c = 0; c < NCH; ++c)
 #pragma unroll
-                for (int q = 0; q < PPC; ++q) rcur[c][q] = rnext[c][q];
+                    for (int q = 0; q < PPC; ++q) rcur[c][q] = rnext[c][q];
+            }
             // ---- row sweep: u_i = log mu_i - LSE_j(S_ij + v_j), dustbin column included
             const float gmax = group_max_f<GL>(mloc);             // (-inf for an idle row: vbin takes over)
             const float m = fmaxf(gmax, vbin);
@@ -487,12 +478,14 @@ __global__ __launch_bounds__(NWV * 64) void sinkhorn_regress_kernel(const TI* __
         {
             int i0 = 0;                                    // uniform trip count for every wave (groups past row w idle)
             if (!last) {
-                if constexpr (NCH >= 2) for (; i0 <= w && chunks_needed(i0) <= 1; i0 += RPB) row_step(IC<1>{}, IC<0>{}, i0);
-                if constexpr (NCH >= 3) for (; i0 <= w && chunks_needed(i0) <= 2; i0 += RPB) row_step(IC<2>{}, IC<0>{}, i0);
+                static_range<1, NCH>([&](auto nc) __attribute__((always_inline)) {
+                    for (; i0 <= w && chunks_needed(i0) <= decltype(nc)::value; i0 += RPB) row_step(nc, IC<0>{}, i0);
+                });
                 for (; i0 <= w; i0 += RPB) row_step(IC<NCH>{}, IC<0>{}, i0);
             } else {
-                if constexpr (NCH >= 2) for (; i0 <= w && chunks_needed(i0) <= 1; i0 += RPB) row_step(IC<1>{}, IC<1>{}, i0);
-                if constexpr (NCH >= 3) for (; i0 <= w && chunks_needed(i0) <= 2; i0 += RPB) row_step(IC<2>{}, IC<1>{}, i0);
+                static_range<1, NCH>([&](auto nc) __attribute__((always_inline)) {
+                    for (; i0 <= w && chunks_needed(i0) <= decltype(nc)::value; i0 += RPB) row_step(nc, IC<1>{}, i0);
+                });
                 for (; i0 <= w; i0 += RPB) row_step(IC<NCH>{}, IC<1>{}, i0);
             }
         }
@@ -552,7 +545,10 @@ static int launch_sinkhorn(const void* cv, float* disp, float* conf, float* occ,
     return check_launch("sinkhorn_regress");
 }
 
-// lanes per row so that a row needs at most 3 chunks of 8 columns per lane: 16 lanes up to w = 384, 32 up to 768, 64 up to 1536
+// lanes per row so that a row needs at most 3 chunks of 8 columns per lane: 16 lanes up to w = 384, 32 up to 768, 64 up to 1536.
+// (r06, measured and dropped: 8 lanes per row with up to five 64-column chunks for w <= 320 -- the chunk is the granularity at which the masked
+// part of a row is skipped, 184 instead of 223 columns swept per row at w = 304, and a step covers 8 rows per wave: 46.08 vs 46.02 us at c3,
+// 23.9 vs 24.4 at c2, for ten more instantiations.)
 template <typename TI>
 static int dispatch_ppl(const void* cv, float* disp, float* conf, float* occ, int32_t* amax, int rows, int w, int ot_iter,
                         int use_pos, int pitch, hipStream_t st) {
