@@ -752,10 +752,12 @@ class Engine:
 
     # ---- whole forward, in three stages (bench.py brackets the middle one, K1, with HIP events) ----------
     @torch.no_grad()
-    def features(self, img0: Tensor, img1: Tensor):
-        """normalise -> CNN backbone -> feature pyramid -> multi-resolution transformer (s2m2.py:140-150)."""
+    def features(self, img0: Tensor, img1: Tensor, x8: Optional[Tensor] = None):
+        """normalise -> CNN backbone -> feature pyramid -> multi-resolution transformer (s2m2.py:140-150).  ``x8``: the normalised 8-channel
+        image tensor when the caller has already run hip.image_prep (GraphRunner: eagerly, straight from the caller's images)."""
         B = img0.shape[0]
-        x8 = hip.image_prep(img0, img1, self.dtype)                             # (2B,H,W,8): channels 1..3 = normalised RGB, 0 free
+        if x8 is None:
+            x8 = hip.image_prep(img0, img1, self.dtype)                         # (2B,H,W,8): channels 1..3 = normalised RGB, 0 free
         p = "cnn_backbone"                                                      # CNNEncoder (submodules.py:63-93)
         c0, c2 = self._conv0(), self.std(p + ".conv0.2")
         if tuple(c0[0].shape) == (16, 8) and tuple(c2[0].shape) == (16, 16) and c0[2] == 1 and c2[2] == 1:
@@ -860,8 +862,8 @@ class Engine:
         return tuple(hip.convex_upsample([d_up, o_up, c_up], m1, 2 if up else 1, scales=[2.0 if up else 1.0, 1.0, 1.0], logit_up2=up))
 
     @torch.no_grad()
-    def run(self, img0: Tensor, img1: Tensor, cap: Optional[dict] = None):
-        tr, py0, f2_left, x8 = self.features(img0, img1)
+    def run(self, img0: Tensor, img1: Tensor, cap: Optional[dict] = None, x8: Optional[Tensor] = None):
+        tr, py0, f2_left, x8 = self.features(img0, img1, x8)
         normed = self._tokens_normed
         if cap is not None and "feature_tr_4x" in (cap.get("inject") or {}):           # parity tests only, see finish()
             tr = cap["inject"]["feature_tr_4x"].to(tr.device, tr.dtype).permute(0, 2, 3, 1).contiguous()
@@ -949,14 +951,20 @@ class GraphRunner:
         # thread-local capture mode: with torch.distributed initialised, the RCCL watchdog thread polls events while this thread
         # captures; in the default (global) mode such a call from another thread invalidates the capture
         mode = "thread_local"
+        # S2M2_EAGER_PREP (default 1): image_prep runs eagerly in front of the replay, straight from the caller's images into the graph's
+        # static 8-channel tensor -- the two device-to-device copies of the images into static input buffers (2 x 15 MB at 1216 x 1024,
+        # 14 us per forward) are gone; 0: the images are copied into static buffers and image_prep is the graph's first node
+        self.x8 = None
+        if os.environ.get("S2M2_EAGER_PREP", "1") != "0":
+            self.x8 = hip.image_prep(self.l, self.r, eng.dtype)
         if not split_k1:
             self.g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g, capture_error_mode=mode):
-                self.out = eng.run(self.l, self.r)
+                self.out = eng.run(self.l, self.r, x8=self.x8)
         else:
             self.ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.ga, capture_error_mode=mode):
-                self.state = eng.features(self.l, self.r)
+                self.state = eng.features(self.l, self.r, self.x8)
             tr = self.state[0]
             self.normed = eng._tokens_normed
             self.cv = eng.cv_buffer(tr)
@@ -966,8 +974,11 @@ class GraphRunner:
                 self.out = eng.finish(*self.state, self.cv)
 
     def __call__(self, img0: Tensor, img1: Tensor):
-        self.l.copy_(img0)
-        self.r.copy_(img1)
+        if self.x8 is not None:
+            hip.image_prep(img0, img1, self.eng.dtype, out=self.x8)
+        else:
+            self.l.copy_(img0)
+            self.r.copy_(img1)
         if not self.split:
             self.g.replay()
         else:

@@ -973,15 +973,20 @@ def cv_lookup_into(cv: torch.Tensor, disp: torch.Tensor, buf: torch.Tensor, off1
 _IMG_DT = {torch.float32: 0, torch.float16: 1, torch.uint8: 2}
 
 
-def image_prep(img0: torch.Tensor, img1: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-    """img0, img1 (B,3,H,W) fp32 / fp16 / uint8 in [0,255] -> x8 (2B,H,W,8): channels 1..3 = normalised RGB, others 0."""
+def image_prep(img0: torch.Tensor, img1: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """img0, img1 (B,3,H,W) fp32 / fp16 / uint8 in [0,255] -> x8 (2B,H,W,8): channels 1..3 = normalised RGB, others 0 (``out``: written in place)."""
     if img0.dtype not in _IMG_DT:
         img0 = img0.float()
     img1 = img1.to(img0.dtype)
     img0, img1 = img0.contiguous(), img1.contiguous()
     _dev(img0, img1)
     B, _, H, W = img0.shape
-    x8 = torch.empty((2 * B, H, W, 8), device=img0.device, dtype=dtype)
+    if out is not None:
+        if tuple(out.shape) != (2 * B, H, W, 8) or out.dtype != dtype or not out.is_contiguous() or out.device != img0.device:
+            raise RuntimeError(f"image_prep: out must be a contiguous {(2 * B, H, W, 8)} {dtype} tensor on {img0.device}")
+        x8 = out
+    else:
+        x8 = torch.empty((2 * B, H, W, 8), device=img0.device, dtype=dtype)
     _check(load().s2m2_image_prep(img0.data_ptr(), img1.data_ptr(), x8.data_ptr(), B, H, W, _IMG_DT[img0.dtype], _DT[dtype], _stream()),
            "s2m2_image_prep")
     return x8

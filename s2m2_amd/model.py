@@ -51,7 +51,7 @@ class S2M2(nn.Module):
         self._engines: Dict[Tuple, "object"] = {}
         self._graphs: "OrderedDict[Tuple, object]" = OrderedDict()      # LRU of captured hipGraphs, see forward()
         self._seen = set()
-        self._side_streams: Dict[object, list] = {}                     # per device: the side streams of _forward_pairs
+        self._side_streams: Dict[object, list] = {}                     # per (device, caller stream): the side streams of _forward_pairs
         self._epoch = 0                                                 # bumped by invalidate()
         self._lock = threading.RLock()                                  # host-side enqueue of one forward at a time per module
 
@@ -194,11 +194,14 @@ class S2M2(nn.Module):
         touches the results."""
         dev = img0.device
         n = self._pair_streams()
-        with self._lock:
-            streams = self._side_streams.get(dev)
-            if streams is None or len(streams) != n:
-                streams = self._side_streams[dev] = [torch.cuda.Stream(device=dev) for _ in range(n)]
         cur = torch.cuda.current_stream(dev)
+        # side streams per CALLER stream: the chunk graphs replay into static output buffers, and only the wait_stream pairs below order
+        # a replay behind the caller's reads of the previous results -- two callers on two streams must not share them
+        skey = (dev, cur.cuda_stream)
+        with self._lock:
+            streams = self._side_streams.get(skey)
+            if streams is None or len(streams) != n:
+                streams = self._side_streams[skey] = [torch.cuda.Stream(device=dev) for _ in range(n)]
         for s in streams:
             s.wait_stream(cur)                                     # the images were produced on the caller's stream
         parts = []
@@ -221,7 +224,7 @@ class S2M2(nn.Module):
             return False
         B, n = int(img_shape[0]), self._pair_streams()
         if B >= 2 and n >= 2:                              # the batch runs as chunks on the side streams (_forward_pairs)
-            streams = self._side_streams.get(dev)
+            streams = self._side_streams.get((dev, torch.cuda.current_stream(dev).cuda_stream))
             if streams is None or len(streams) != n:
                 return False
             per = (B + n - 1) // n

@@ -138,6 +138,28 @@ def test_batch_in_chunks_on_two_streams_equals_one_batched_forward(monkeypatch):
         if B == 2:
             single = m(l[1:2], r[1:2])
             assert torch.equal(single[0], got[0][1:2])
+    # two host threads, each on its own stream, each with batches of two: every caller stream has its own side streams (the chunk graphs
+    # replay into static buffers that only the caller's wait_stream pairs protect)
+    data = {}
+    for tag, seed in (("a", 31), ("b", 32)):
+        l, r = synthetic_pair(64, 96, 2, 8, seed)
+        data[tag] = (l.cuda(), r.cuda())
+        data[tag + "_ref"] = m(*data[tag])[0].clone()
+    torch.cuda.synchronize()
+    res = {}
+
+    def work(tag):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for _ in range(6):
+                out = m(*data[tag])
+                acc = out[0].clone()                           # read right away on the caller's stream
+            res[tag] = acc
+        st.synchronize()
+    ts = [threading.Thread(target=work, args=(t,)) for t in ("a", "b")]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert torch.equal(res["a"], data["a_ref"]) and torch.equal(res["b"], data["b_ref"])
 
 
 def test_torch_compile_wrapper_is_accepted():
