@@ -3,7 +3,7 @@
 rocprofv3 --pmc pass (SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY) the share of the
 SIMD cycles with the matrix pipe busy and with a VALU instruction issuing (SQ_ACTIVE_INST_* count quad-cycles, MI355X_MICROARCH.md), the VALU
 instructions per wave and the share of wave-cycles spent waiting.
-    python tools/pmc_forward.py <kernel_trace.csv> <counter_collection.csv>     (tools/tmp/run_pmc_forward.sh made both)"""
+    python tools/pmc_forward.py <kernel_trace.csv> <counter_collection.csv>     (tools/pmc_forward.sh makes both)"""
 import collections
 import csv
 import re
