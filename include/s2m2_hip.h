@@ -122,7 +122,9 @@ int s2m2_pack_frag(const s2m2_pack_desc* desc, void* stream);
  * Recorded launch plans (ABI 500): a sequence of library calls replayed from C.  Between s2m2_plan_begin and s2m2_plan_end every launch-type entry
  * point the CALLING THREAD invokes is executed as always AND appended to the plan (arguments by value, descriptors copied).  s2m2_plan_end
  * declares the plan's EXTERNAL buffers -- next ranges [ext_base[i], ext_base[i] + ext_bytes[i]) of device memory: every recorded pointer into
- * range i is stored relative to it -- and s2m2_plan_run re-issues the whole sequence on `stream` with the externals at ext_ptrs[i] (same count
+ * range i is stored relative to it (ABI 600: only the pointer-typed arguments and the pointer fields of the descriptors are compared with the
+ * ranges -- a size, a stride or a pair of ints that falls inside a range is never rewritten) -- and s2m2_plan_run re-issues the whole sequence
+ * on `stream` with the externals at ext_ptrs[i] (same count
  * and order; a NULL external is accepted if no recorded call points into it).  All other pointers (weights, scratch, the intermediate tensors
  * of the recorded run) are replayed as recorded: the owner of the plan keeps those allocations alive and unshared for the life of the plan.
  * A plan is immutable once sealed; concurrent runs on different streams are safe when their externals differ and the caller accepts that the

@@ -101,11 +101,12 @@ extern "C" int s2m2_debug_poison_lds(void* stream) {
 // s2m2_plan_end -- each as a flat argument blob plus a trampoline (plan.h) -- with the pointers into the caller's EXTERNAL buffers (declared at
 // s2m2_plan_end) stored relative to their buffer, so that s2m2_plan_run can re-issue the whole sequence from C++ with the externals somewhere
 // else.  Every other pointer (weights, the scratch and intermediate tensors of the recorded run) is replayed as recorded: whoever records keeps
-// those allocations alive for the life of the plan.  The blobs are scanned for external pointers as 8-byte words -- a device address is a
-// 64-bit value in a range no size, stride or flag field of the descriptors reaches.
+// those allocations alive for the life of the plan.  Only the POINTER words of a blob (plan.h: PlanPtrMask -- from the argument types of a
+// positional pack, from the pointer-field list of a descriptor) are compared with the external ranges: a size, a stride or a pair of ints that
+// happens to fall inside a range is left alone.
 // ------------------------------------------------------------------------------------------------------------------------------------
 struct s2m2_plan {
-    struct Call { int (*tramp)(const void*, void*); size_t off, words; const char* name; };
+    struct Call { int (*tramp)(const void*, void*); size_t off, words; const char* name; s2m2::PlanPtrMask mask; };
     struct Patch { int call; int word; int slot; long long delta; };
     std::vector<unsigned long long> arena;      // the blobs, 8-byte aligned
     std::vector<Call> calls;
@@ -120,14 +121,18 @@ static thread_local s2m2_plan* g_plan = nullptr;
 
 bool plan_recording() { return g_plan != nullptr; }
 
-int plan_append(int (*tramp)(const void*, void*), const void* blob, size_t bytes, const char* name) {
+int plan_append(int (*tramp)(const void*, void*), const void* blob, size_t bytes, const char* name, const PlanPtrMask& mask) {
     s2m2_plan* p = g_plan;
     if (!p) return 0;
     const size_t words = (bytes + 7) / 8;
+    if (mask.overflow || words > 64 * (size_t)kPlanMaskWords) {
+        p->failed = true;
+        return set_error("plan: %s has a pointer argument outside the %d words the pointer mask covers (or a misaligned one)", name, 64 * kPlanMaskWords);
+    }
     const size_t off = p->arena.size();
     p->arena.resize(off + words, 0ULL);
     memcpy(p->arena.data() + off, blob, bytes);
-    p->calls.push_back({tramp, off, words, name});
+    p->calls.push_back({tramp, off, words, name, mask});
     if (words > p->max_words) p->max_words = words;
     return 0;
 }
@@ -151,6 +156,7 @@ extern "C" int s2m2_plan_end(s2m2_plan* plan, const void* const* ext_base, const
     for (int c = 0; c < (int)plan->calls.size(); ++c) {
         const auto& call = plan->calls[c];
         for (size_t wd = 1; wd < call.words; ++wd) {               // word 0 is the function pointer of the call
+            if (!call.mask.test(wd)) continue;                     // not a pointer argument / field
             const unsigned long long v = plan->arena[call.off + wd];
             for (int s = 0; s < next; ++s) {
                 const unsigned long long b = (unsigned long long)(uintptr_t)ext_base[s];

@@ -168,6 +168,10 @@ struct UpsampleBlob {
     const float* x[3]; float* out[3]; float scale[3];
     int nmaps; const void* logits; int logit_stride, B, hs, ws, factor, logit_up2; void* chan_out; long long chan_stride; int dtype;
 };
+namespace s2m2 {
+S2M2_PLAN_PTRS(UpsampleBlob, S2M2_OFF_I(UpsampleBlob, x, 0), S2M2_OFF_I(UpsampleBlob, x, 1), S2M2_OFF_I(UpsampleBlob, x, 2), S2M2_OFF_I(UpsampleBlob, out, 0),
+               S2M2_OFF_I(UpsampleBlob, out, 1), S2M2_OFF_I(UpsampleBlob, out, 2), S2M2_OFF(UpsampleBlob, logits), S2M2_OFF(UpsampleBlob, chan_out))
+}
 static int convex_upsample_blob(const UpsampleBlob* b, void* stream) {
     return convex_upsample_impl(b->x, b->out, b->scale, b->nmaps, b->logits, b->logit_stride, b->B, b->hs, b->ws, b->factor, b->logit_up2,
                                 b->chan_out, b->chan_stride, b->dtype, stream);

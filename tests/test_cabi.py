@@ -217,3 +217,28 @@ def test_conv_frag_chunk_rule_of_the_header_is_the_rule_of_the_packers(tmp_path)
     out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     assert out == [pack.frag_chunk(co, ci) for co, ci in shapes]
     assert pack.frag_chunk(192, 192) == 192 and pack.frag_chunk(192, 384) == 192 and pack.frag_chunk(384, 384) == 128
+
+
+def test_plan_pointer_masks_list_every_pointer_field_of_the_recorded_descriptors():
+    """Plans (s2m2_plan_*, csrc/plan.h) relocate external pointers in the POINTER words of a recorded call only; the descriptors that go through
+    plans name those words by hand (S2M2_PLAN_PTRS).  A pointer field added to include/s2m2_hip.h without its entry would silently stop following
+    the external buffers on replay: the lists are checked against the header here."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "s2m2_hip.h")).read()
+    plan_h = open(os.path.join(root, "s2m2_amd", "csrc", "plan.h")).read()
+    recorded = set()
+    for src in os.listdir(os.path.join(root, "s2m2_amd", "csrc")):
+        if src.endswith(".hip"):
+            recorded |= set(re.findall(r"plan_dispatch_desc<(s2m2_\w+)>", open(os.path.join(root, "s2m2_amd", "csrc", src)).read()))
+    assert recorded >= {"s2m2_conv_desc", "s2m2_chain_desc", "s2m2_corr_desc", "s2m2_rowattn_desc", "s2m2_convblock_desc", "s2m2_pw_desc", "s2m2_narrow_desc"}
+    for name in sorted(recorded):
+        body = header[header.index("typedef struct %s {" % name):header.index("} %s;" % name)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        assert not re.search(r"\*\s*\w+\s*,", body), f"{name}: one pointer declarator per line, please (this check parses them)"
+        fields = set()
+        for m in re.finditer(r"\*\s*(\w+)\s*(\[(\d+)\])?\s*;", body):
+            fields |= {(m.group(1), i) for i in range(int(m.group(3)))} if m.group(3) else {(m.group(1), None)}
+        blk = plan_h[plan_h.index("S2M2_PLAN_PTRS(%s," % name):]
+        blk = blk[:blk.index("))\n") + 2]
+        listed = {(m.group(2), int(m.group(4)) if m.group(4) else None) for m in re.finditer(r"S2M2_OFF(_I)?\(%s, (\w+)(, (\d))?\)" % name, blk)}
+        assert fields == listed, (name, fields ^ listed)
