@@ -306,7 +306,7 @@ typedef struct s2m2_chain_desc {
        16-byte piece (cout o, channels 8q .. 8q+7) at 16-byte slot ((o/32) * (C/16) + q/2) * 64 + (q%2) * 32 + o%32 (per fan-out layer for
        fan_weight) -- and the launch runs the DIRECT form: a wave's weight fragments go from global memory straight into its MFMA operand
        registers, one whole stage ahead, no weight tile in LDS and no block barrier inside a stage.  For SHORT row counts (the 1/32 .. 1/8
-       pyramid levels: a block lives for the latency of its weight stream, not for its arithmetic).  fp16, C = 128 / 256: ask
+       pyramid levels: a block lives for the latency of its weight stream, not for its arithmetic).  fp16, C = 128 / 192 / 256 / 384 / 512: ask
        s2m2_mlp_chain_frag_supported.  Same arithmetic and rounding points as the row-major form.  With nstage = 0 and nfan = 1 .. 4 the
        fan-out layers alone run in this form (any row count; nstage = 0 exists in this form only: ask s2m2_mlp_fan_supported). */
     int weight_frag;

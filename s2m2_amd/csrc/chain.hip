@@ -80,7 +80,8 @@ struct ChainCfg {
 #endif
     // weight chunks in flight.  Direct form: a whole stage (C / 16 fragments) up to C = 256; at C = 384 half a stage -- 12 waves per block are
     // three per SIMD, 168 registers each: 24 fragments in flight spilled (tools/kernel_resources.py)
-    static constexpr int D = DIRECT ? (CPS > 16 ? CPS / 2 : CPS) : WP == 8 ? 2 : (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;
+    // (C = 512: an eighth -- 16 waves per block are four per SIMD, 128 registers each: 16 fragments in flight spilled 68 - 244 bytes, 8 still 8 - 60)
+    static constexpr int D = DIRECT ? (CPS > 24 ? CPS / 8 : CPS > 16 ? CPS / 2 : CPS) : WP == 8 ? 2 : (S2M2_CHAIN_DEPTH8 && CPS % 8 == 0 && sizeof(T) == 2 && C <= 256) ? 8 : 4;
     static constexpr int WROWS = NT / WP;                 // weight rows covered by one pass of the loader threads (WP pieces per row)
     static constexpr int B_IT = DIRECT ? WN / 32 : C / WROWS;   // 16-byte weight pieces per thread and chunk (direct: one per 32-cout tile)
     static constexpr int PPR = C / VEC;                   // 16-byte pieces per activation row
@@ -597,8 +598,13 @@ extern "C" int s2m2_mlp_chain_supported(int C, int dtype) {
     return 0;
 }
 
-// direct form: one wave per 32 couts (C / 32 waves per block: 4, 6, 8, 12), a whole stage of C / 16 fragments in flight per wave
-extern "C" int s2m2_mlp_chain_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 192 || C == 256 || C == 384); }
+// direct form: one wave per 32 couts (C / 32 waves per block: 4, 6, 8, 12, 16), a whole stage of C / 16 fragments in flight per wave (half a stage at
+// C = 384 / 512).  C = 512 (r06: the L model's 1/16 and 1/32 levels, 54 launches per forward on the LDS-staged form before): 16 waves = four per SIMD,
+// 128 registers each, 32-row tiles only
+extern "C" int s2m2_mlp_chain_frag_supported(int C, int dtype) {
+    static const bool no512 = getenv("S2M2_CHAIN_FRAG512") != nullptr && atoi(getenv("S2M2_CHAIN_FRAG512")) == 0;      // A/B switch
+    return dtype == S2M2_F16 && (C == 128 || C == 192 || C == 256 || C == 384 || (C == 512 && !no512));
+}
 
 namespace s2m2 {
 // direct form, by width: 32-row tiles while they fit the chip in about one round, else 64-row tiles (half the weight traffic per row)
@@ -608,12 +614,13 @@ static int launch_chain_direct(const ChainArgs& a, int C, bool tall, hipStream_t
         case 128: return tall ? launch_chain<half_t, 128, 64, NST, 4, 0>(a, st) : launch_chain<half_t, 128, 32, NST, 4, 0>(a, st);
         case 192: return tall ? launch_chain<half_t, 192, 64, NST, 6, 0>(a, st) : launch_chain<half_t, 192, 32, NST, 6, 0>(a, st);
         case 256: return tall ? launch_chain<half_t, 256, 64, NST, 8, 0>(a, st) : launch_chain<half_t, 256, 32, NST, 8, 0>(a, st);
+        case 512: return launch_chain<half_t, 512, 32, NST, 16, 0>(a, st);
         default: return tall ? launch_chain<half_t, 384, 64, NST, 12, 0>(a, st) : launch_chain<half_t, 384, 32, NST, 12, 0>(a, st);
     }
 }
 static bool chain_direct_tall(int C, long long rows) {
     static const int force_bm = getenv("S2M2_CHAIN_DIRECT_BM") ? atoi(getenv("S2M2_CHAIN_DIRECT_BM")) : 0;      // 32 / 64 forces one (tuning)
-    if (C == 384) return false;                                    // (64-row tiles at 12 waves per block spill: 55 - 88 registers)
+    if (C >= 384) return false;                                    // (64-row tiles at 12 waves per block spill: 55 - 88 registers; 16 waves: 128 registers each)
     return force_bm ? force_bm == 64 : rows > (C == 128 ? 24576 : C == 192 ? 16384 : 8192);
 }
 }  // namespace s2m2
@@ -625,7 +632,7 @@ static int mlp_chain_impl(const s2m2_chain_desc* d, void* stream) {
     S2M2_REQUIRE(d, "mlp_chain: null descriptor");
     S2M2_REQUIRE(d->x, "mlp_chain: null x");
     S2M2_REQUIRE(d->weight_frag == 0 || (d->weight_frag == 1 && (d->nstage > 0 || d->nfan > 0) && s2m2_mlp_chain_frag_supported(d->C, d->dtype)),
-                 "mlp_chain: weight_frag=%d needs fp16 and C = 128 / 192 / 256 / 384", d->weight_frag);
+                 "mlp_chain: weight_frag=%d needs fp16 and C = 128 / 192 / 256 / 384 / 512", d->weight_frag);
     S2M2_REQUIRE((d->pool_h == 0 && d->pool_w == 0) ||
                  (d->weight_frag && d->pool_h >= 2 && d->pool_w >= 2 && d->rows % ((long long)(d->pool_h / 2) * (d->pool_w / 2)) == 0),
                  "mlp_chain: pool_h / pool_w need weight_frag, an input of at least 2x2 pixels and rows = N * (pool_h/2) * (pool_w/2)");
@@ -648,10 +655,10 @@ static int mlp_chain_impl(const s2m2_chain_desc* d, void* stream) {
         hipStream_t fst = static_cast<hipStream_t>(stream);
         return launch_chain_direct<0>(f, d->C, chain_direct_tall(d->C, d->rows), fst);
     }
-    S2M2_REQUIRE(d->nstage != 0, "mlp_chain: fan-out only (nstage = 0) exists in the direct form: weight_frag = 1, fp16, C = 128 / 192 / 256 / 384");
+    S2M2_REQUIRE(d->nstage != 0, "mlp_chain: fan-out only (nstage = 0) exists in the direct form: weight_frag = 1, fp16, C = 128 / 192 / 256 / 384 / 512");
     S2M2_REQUIRE(d->out, "mlp_chain: null out");
     S2M2_REQUIRE(d->nstage >= 1 && d->nstage <= 3, "mlp_chain: nstage=%d (0..3)", d->nstage);
-    S2M2_REQUIRE(d->weight_frag || s2m2_mlp_chain_supported(d->C, d->dtype), "mlp_chain: C=%d dtype=%d is not supported (fp16: 128/256/384/512, fp32: 128/256; direct form fp16: 128/192/256/384)", d->C, d->dtype);
+    S2M2_REQUIRE(d->weight_frag || s2m2_mlp_chain_supported(d->C, d->dtype), "mlp_chain: C=%d dtype=%d is not supported (fp16: 128/256/384/512, fp32: 128/256; direct form fp16: 128/192/256/384/512)", d->C, d->dtype);
     S2M2_REQUIRE(d->rows > 0 && d->rows < (1LL << 31), "mlp_chain: rows=%lld", d->rows);
     S2M2_REQUIRE(d->x_stride >= d->C && d->x_stride % 8 == 0 && d->out_stride >= d->C && d->out_stride % 8 == 0,
                  "mlp_chain: row strides %lld/%lld must be multiples of 8 and at least C", d->x_stride, d->out_stride);

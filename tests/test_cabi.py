@@ -78,9 +78,9 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     c.C, c.carry, c.res_stage = 128, 1, -1
     c.weight[0] = c.weight[1] = 4096
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"carry" in lib.s2m2_last_error()
-    # the direct form (weight_frag) exists for fp16 C = 128 / 192 / 256 / 384 only; the pooled tile load needs it and whole pooled images
+    # the direct form (weight_frag) exists for fp16 C = 128 / 192 / 256 / 384 / 512 only; the pooled tile load needs it and whole pooled images
     c = hip.ChainDesc()
-    c.x, c.out, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.out_stride, c.res_stage = 4096, 4096, 512, 1, hip.F16, 8, 512, 512, -1
+    c.x, c.out, c.C, c.nstage, c.dtype, c.rows, c.x_stride, c.out_stride, c.res_stage = 4096, 4096, 640, 1, hip.F16, 8, 640, 640, -1
     c.weight[0], c.weight_frag = 4096, 1
     assert lib.s2m2_mlp_chain(ctypes.byref(c), None) != 0 and b"weight_frag" in lib.s2m2_last_error()
     c.C, c.x_stride, c.out_stride, c.dtype = 128, 128, 128, hip.F32
@@ -150,7 +150,7 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert lib.s2m2_feature_fusion_frag_supported(256, hip.F16) == 1 and lib.s2m2_feature_fusion_frag_supported(128, hip.F32) == 0
     assert lib.s2m2_feature_fusion_frag(4096, 4096, 4096, 128, 128, 128, 64, 128, 4096, 4096, 4096, 4096, 0, 0, hip.F32, None) != 0
     assert b"not supported" in lib.s2m2_last_error()
-    assert lib.s2m2_mlp_chain_frag_supported(128, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(384, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(512, hip.F16) == 0
+    assert lib.s2m2_mlp_chain_frag_supported(128, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(384, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(512, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(640, hip.F16) == 0
     assert lib.s2m2_stem_mlp(None, None, None, None, None, None, 8, hip.F16, None) != 0
 
 

@@ -259,10 +259,10 @@ def test_chain_direct_form_layernorm_output_and_strided_rows(hip):
 
 
 def test_chain_direct_form_rejects_unsupported(hip):
-    assert all(hip.mlp_chain_frag_supported(c, torch.float16) for c in (128, 192, 256, 384))
-    assert not hip.mlp_chain_frag_supported(512, torch.float16) and not hip.mlp_chain_frag_supported(128, torch.float32)
-    x = torch.randn(4, 512, device="cuda").half()
-    w = torch.randn(512, 512, device="cuda").half()
+    assert all(hip.mlp_chain_frag_supported(c, torch.float16) for c in (128, 192, 256, 384, 512))
+    assert not hip.mlp_chain_frag_supported(640, torch.float16) and not hip.mlp_chain_frag_supported(128, torch.float32)
+    x = torch.randn(4, 640, device="cuda").half()
+    w = torch.randn(640, 640, device="cuda").half()
     with pytest.raises(RuntimeError, match="weight_frag"):
         hip.mlp_chain(x, [(w, None, 0, None)], frag=True)
 
@@ -276,6 +276,18 @@ def test_chain_direct_form_rejects_unsupported(hip):
 ])
 def test_chain_direct_form_c384_equals_row_major_form_bit_for_bit(hip, C, shp, nst, res_stage, carry, ln_stage, acts, nfan, fan_ln):
     """C = 384 has both forms: the direct form (half a stage of fragments in flight, 12 waves) reproduces the LDS-staged one bit for bit"""
+    test_chain_direct_form_equals_row_major_form_bit_for_bit(hip, C, shp, nst, res_stage, carry, ln_stage, acts, nfan, fan_ln)
+
+
+# ---- the L model's coarse levels (C = 512, r06: sixteen waves per block, four fragments in flight per wave) -------------------------------------------
+@pytest.mark.parametrize("C,shp,nst,res_stage,carry,ln_stage,acts,nfan,fan_ln", [
+    (512, (2, 32, 38), 3, 0, True, 1, (0, 1, 0), 3, True),          # the 1/32 attention block of the L model with the next Q|K|V
+    (512, (2, 64, 76), 3, 0, True, 1, (0, 1, 0), 0, False),         # 9728 rows
+    (512, (1, 5, 7), 2, 1, False, 0, (1, 2), 2, True),
+    (512, (1, 1, 1), 1, 0, False, 0, (1,), 1, False),
+])
+def test_chain_direct_form_c512_equals_row_major_form_bit_for_bit(hip, C, shp, nst, res_stage, carry, ln_stage, acts, nfan, fan_ln):
+    """C = 512 has both forms as well"""
     test_chain_direct_form_equals_row_major_form_bit_for_bit(hip, C, shp, nst, res_stage, carry, ln_stage, acts, nfan, fan_ln)
 
 
@@ -365,10 +377,11 @@ def test_fan_only_direct_form_m_xl_widths(hip, C, shp, nfan, ln, pool):
 
 
 @pytest.mark.parametrize("C,shp,nfan,ln", [(256, (2, 32, 38), 3, True), (256, (2, 64, 76), 3, True), (128, (2, 128, 152), 3, True),
-                                           (128, (1, 256, 304), 3, True), (128, (1, 7, 9), 1, False), (256, (1, 5, 3), 4, False)])
+                                           (128, (1, 256, 304), 3, True), (128, (1, 7, 9), 1, False), (256, (1, 5, 3), 4, False),
+                                           (512, (2, 32, 38), 3, True)])
 def test_fan_only_direct_form(hip, C, shp, nfan, ln):
     """nstage = 0 with weight_frag: the fan-out layers alone (a block's first Q | K | V projection) in the direct form == the K5 launch with the
-    folded pre-LayerNorm within fp16 rounding; the form exists for fp16 at C = 128 / 256 only."""
+    folded pre-LayerNorm within fp16 rounding; the form exists for fp16 at the direct form's widths only."""
     dtype = torch.float16
     g = torch.Generator(device="cuda").manual_seed(C + nfan)
     wide = (torch.randn(*shp, C + 8, device="cuda", generator=g) * 1.5 + 0.3).to(dtype)
@@ -383,7 +396,7 @@ def test_fan_only_direct_form(hip, C, shp, nfan, ln):
         y = hip.mlp_fan(x, wf, bp, ws, frag=True)
         assert y.shape == ref.shape
         assert float((y.float() - ref.float()).abs().max()) < 1.5e-2
-    assert hip.mlp_fan_supported(C, nfan, dtype) and not hip.mlp_fan_supported(512, nfan, dtype) and not hip.mlp_fan_supported(C, nfan, torch.float32)
+    assert hip.mlp_fan_supported(C, nfan, dtype) and not hip.mlp_fan_supported(640, nfan, dtype) and not hip.mlp_fan_supported(C, nfan, torch.float32)
     with pytest.raises(ValueError, match="direct form"):
         hip.mlp_fan(x, wp, bp, ws, frag=False)
     t = F.layer_norm(x.float(), (C,)) if ln else x.float()
