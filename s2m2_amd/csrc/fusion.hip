@@ -444,14 +444,18 @@ extern "C" int s2m2_feature_fusion_supported(int C, int dtype) {
     return (dtype == S2M2_F16 || dtype == S2M2_F32) && (C == 128 || C == 256);
 }
 
-extern "C" int s2m2_feature_fusion_frag_supported(int C, int dtype) { return dtype == S2M2_F16 && (C == 128 || C == 192 || C == 256 || C == 384); }
+// (C = 512, r06: the L model's 1/16 level, ten fusions per forward that ran as two K5 launches each; 16 waves per block, ring of 6 fragments: 8 spill)
+extern "C" int s2m2_feature_fusion_frag_supported(int C, int dtype) {
+    static const bool no512 = getenv("S2M2_FUSION_FRAG512") != nullptr && atoi(getenv("S2M2_FUSION_FRAG512")) == 0;        // A/B switch
+    return dtype == S2M2_F16 && (C == 128 || C == 192 || C == 256 || C == 384 || (C == 512 && !no512));
+}
 
 static int feature_fusion_frag_impl(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,
                                         long long rows, int C, const void* w_stream, const float* b1, const float* bg, const float* bf,
                                         int z1_coarse_h, int z1_coarse_w, int dtype, void* stream) {
     using namespace s2m2;
     S2M2_REQUIRE(z0 && z1 && out && w_stream && b1 && bg && bf, "feature_fusion_frag: null pointer");
-    S2M2_REQUIRE(s2m2_feature_fusion_frag_supported(C, dtype), "feature_fusion_frag: C=%d dtype=%d is not supported (fp16, C = 128, 192, 256 or 384)", C, dtype);
+    S2M2_REQUIRE(s2m2_feature_fusion_frag_supported(C, dtype), "feature_fusion_frag: C=%d dtype=%d is not supported (fp16, C = 128, 192, 256, 384 or 512)", C, dtype);
     S2M2_REQUIRE(rows > 0 && rows < (1LL << 31), "feature_fusion_frag: rows=%lld", rows);
     S2M2_REQUIRE(z0_stride >= C && z1_stride >= C && out_stride >= C && z0_stride % 8 == 0 && z1_stride % 8 == 0 && out_stride % 8 == 0,
                  "feature_fusion_frag: row strides must be multiples of 8 and at least C");
@@ -470,6 +474,7 @@ static int feature_fusion_frag_impl(const void* z0, const void* z1, void* out, l
     if (C == 128) return tall ? launch_fusion_direct<128, 64, 4, 12>(a, st) : launch_fusion_direct<128, 32, 4, 24>(a, st);
     if (C == 192) return tall ? launch_fusion_direct<192, 64, 6, 12>(a, st) : launch_fusion_direct<192, 32, 6, 24>(a, st);
     if (C == 384) return launch_fusion_direct<384, 32, 12, 16>(a, st);   // 12 waves: three per SIMD, <= 168 registers (64-row tiles spill)
+    if (C == 512) return launch_fusion_direct<512, 32, 16, 6>(a, st);    // 16 waves: four per SIMD, <= 128 registers (a ring of 8 spills 6)
     return tall ? launch_fusion_direct<256, 64, 8, 16>(a, st) : launch_fusion_direct<256, 32, 8, 24>(a, st);
 }
 extern "C" int s2m2_feature_fusion_frag(const void* z0, const void* z1, void* out, long long z0_stride, long long z1_stride, long long out_stride,

@@ -147,7 +147,7 @@ def test_argument_validation_of_the_gemm_entry_points(lib):
     assert b"not supported" in lib.s2m2_last_error()
     assert lib.s2m2_feature_fusion(4096, 4096, 4096, 128, 128, 128, 60, 128, 4096, 4096, 4096, 4096, 4096, 4, 4, hip.F16, None) != 0
     assert b"whole number" in lib.s2m2_last_error()
-    assert lib.s2m2_feature_fusion_frag_supported(256, hip.F16) == 1 and lib.s2m2_feature_fusion_frag_supported(128, hip.F32) == 0
+    assert lib.s2m2_feature_fusion_frag_supported(256, hip.F16) == 1 and lib.s2m2_feature_fusion_frag_supported(512, hip.F16) == 1 and lib.s2m2_feature_fusion_frag_supported(128, hip.F32) == 0
     assert lib.s2m2_feature_fusion_frag(4096, 4096, 4096, 128, 128, 128, 64, 128, 4096, 4096, 4096, 4096, 0, 0, hip.F32, None) != 0
     assert b"not supported" in lib.s2m2_last_error()
     assert lib.s2m2_mlp_chain_frag_supported(128, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(384, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(512, hip.F16) == 1 and lib.s2m2_mlp_chain_frag_supported(640, hip.F16) == 0

@@ -131,16 +131,17 @@ def test_feature_fusion_direct_form_equals_lds_form_bit_for_bit(hip, C, shp, coa
 
 
 def test_feature_fusion_direct_form_rejects_unsupported(hip):
-    z = torch.zeros(4, 512, device="cuda").half()
+    z = torch.zeros(4, 640, device="cuda").half()
     with pytest.raises(RuntimeError, match="not supported"):
-        hip.feature_fusion(z, z, torch.zeros(9 * 512 * 512, device="cuda").half(), torch.zeros(3 * 512, device="cuda"), None,
-                           torch.zeros(512, device="cuda"), torch.zeros(512, device="cuda"), frag=True)
+        hip.feature_fusion(z, z, torch.zeros(9 * 640 * 640, device="cuda").half(), torch.zeros(3 * 640, device="cuda"), None,
+                           torch.zeros(640, device="cuda"), torch.zeros(640, device="cuda"), frag=True)
 
 
 @pytest.mark.parametrize("C,shp,coarse", [(192, (2, 50, 61), False), (192, (1, 128, 152), True), (192, (2, 128, 152), False), (192, (1, 1, 1), False),
-                                          (384, (2, 32, 38), True), (384, (1, 64, 76), False), (384, (1, 9, 7), True)])
+                                          (384, (2, 32, 38), True), (384, (1, 64, 76), False), (384, (1, 9, 7), True),
+                                          (512, (2, 32, 38), True), (512, (2, 64, 76), False), (512, (1, 9, 7), True)])
 def test_feature_fusion_direct_form_m_xl_widths(hip, C, shp, coarse):
-    """C = 192 / 384 (the M and XL models) exist in the direct form only: against the fp32 reference of the block (rounded where the kernel
+    """C = 192 / 384 (the M and XL models) and C = 512 (the L model's 1/16 level, r06) exist in the direct form only: against the fp32 reference of the block (rounded where the kernel
     rounds) and against the K5 launches it replaces; repeated launches must be bit-identical to each other."""
     dtype = torch.float16
     assert hip.feature_fusion_frag_supported(C, dtype) and not hip.feature_fusion_supported(C, dtype)
