@@ -8,6 +8,7 @@
 //    atomicAdd pair per block and group), then the normalise+affine sweep.
 // Both compute in fp32 regardless of the I/O dtype.
 #include "common.h"
+#include <stdlib.h>
 #include "plan.h"
 
 namespace s2m2 {
@@ -80,6 +81,7 @@ static int dispatch_ln(const void* x, void* y, long long rows, int C, long long 
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm on NHWC.  stats[(n*G + g)*2 + {0,1}] = sum, sum of squares (fp64).
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int kGnReplicas = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, long long HW,
                                                               int C, int G, int pix_per_block) {
@@ -130,8 +132,12 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const T* __restric
     if (threadIdx.x < G) {
         const float a = red[0][threadIdx.x][0] + red[0][threadIdx.x][1] + red[0][threadIdx.x][2] + red[0][threadIdx.x][3];
         const float b = red[1][threadIdx.x][0] + red[1][threadIdx.x][1] + red[1][threadIdx.x][2] + red[1][threadIdx.x][3];
-        atomicAdd(&stats[((long long)n * G + threadIdx.x) * 2 + 0], (double)a);
-        atomicAdd(&stats[((long long)n * G + threadIdx.x) * 2 + 1], (double)b);
+        // kGnReplicas copies of the 2 N G sums, block b adds to copy b % kGnReplicas: 1216 blocks x 16 fp64 atomics on 32 addresses cost
+        // ~17 us of a 46 us pass at (2, 512 x 608, 128) -- the atomics of one address are served one after the other (r06: tools A/B with
+        // the pixels per block, 128 / 256 / 512 / 1024 px: 167 / 121 / 96 / 88 us per GroupNorm)
+        double* rep = stats + (size_t)(blockIdx.x % kGnReplicas) * 2 * gridDim.y * G;
+        atomicAdd(&rep[((long long)n * G + threadIdx.x) * 2 + 0], (double)a);
+        atomicAdd(&rep[((long long)n * G + threadIdx.x) * 2 + 1], (double)b);
     }
 }
 
@@ -152,8 +158,14 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const T* __restric
     const int c0 = pi * VEC;
     const int g = c0 / cpg;
     const double cnt = (double)HW * cpg;
-    const double m = stats[((long long)n * G + g) * 2] / cnt;
-    double var = stats[((long long)n * G + g) * 2 + 1] / cnt - m * m;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < kGnReplicas; ++r) {                         // (fixed order: the copies themselves are order-independent up to fp64 rounding)
+        const double* rep = stats + (size_t)r * 2 * gridDim.y * G;
+        s1 += rep[((long long)n * G + g) * 2];
+        s2 += rep[((long long)n * G + g) * 2 + 1];
+    }
+    const double m = s1 / cnt;
+    double var = s2 / cnt - m * m;
     var = var > 0 ? var : 0;
     const float mean = (float)m, rstd = rsqrtf((float)var + eps);
     float ga[VEC], be[VEC];
@@ -175,8 +187,9 @@ static int run_groupnorm(const void* x, void* y, const float* gamma, const float
                          float eps, hipStream_t st) {
     constexpr int VEC = 16 / sizeof(T);
     const int P = C / VEC;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * N * G, st) != hipSuccess) return set_error("groupnorm: memset failed");
-    const int ppb = 512;                                           // pixels per block of the statistics pass
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * N * G * kGnReplicas, st) != hipSuccess) return set_error("groupnorm: memset failed");
+    static const int ppb_env = getenv("S2M2_GN_PPB") ? atoi(getenv("S2M2_GN_PPB")) : 0;      // tuning only
+    const int ppb = ppb_env > 0 ? ppb_env : 512;                   // pixels per block of the statistics pass
     dim3 g1((unsigned)((HW + ppb - 1) / ppb), N);
     hipLaunchKernelGGL((groupnorm_stats_kernel<T>), g1, dim3(256), 0, st, static_cast<const T*>(x), ws, HW, C, G, ppb);
     if (int rc = check_launch("groupnorm_stats")) return rc;
@@ -206,7 +219,7 @@ extern "C" int s2m2_layernorm(const void* x, void* y, long long rows, int C, lon
 }
 
 
-extern "C" size_t s2m2_groupnorm_workspace_bytes(int N, int G) { return sizeof(double) * 2 * (size_t)N * G; }
+extern "C" size_t s2m2_groupnorm_workspace_bytes(int N, int G) { return sizeof(double) * 2 * (size_t)N * G * s2m2::kGnReplicas; }
 
 static int groupnorm_nhwc_impl(const void* x, void* y, const float* gamma, const float* beta, void* workspace, int N,
                                    long long HW, int C, int G, float eps, int dtype, void* stream) {
